@@ -1,0 +1,22 @@
+"""Drop-in for the reference's pybind module `_gridencoder`
+(modules/radnerfs/encoders/gridencoder/src/bindings.cpp:5-9)."""
+import torch
+
+from ..lib import check, current_stream, lib, ptr
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
+    if embeddings.dtype != torch.float32:
+        raise RuntimeError("grid_encode_forward: only float32 embeddings are built (reference inference is fp32)")
+    check(lib().gf_grid_encode_forward(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
+                                       ptr(outputs, torch.float32), B, D, C, L, float(S), H,
+                                       ptr(dy_dx, torch.float32, allow_none=True), gridtype, int(bool(align_corners)), interp,
+                                       current_stream(inputs.device)))
+
+
+def grid_encode_backward(*a, **k):
+    raise NotImplementedError("_gridencoder.grid_encode_backward: training path, outside this round's scope (SURVEY.md 8f-2)")
+
+
+def grad_total_variation(*a, **k):
+    raise NotImplementedError("_gridencoder.grad_total_variation: no caller in GeneFace (SURVEY.md 2.2B)")

@@ -1,0 +1,63 @@
+"""hipcc build of libgeneface_hip.so (gfx950 only, in-tree so it travels with the repo snapshot).
+
+    python -m geneface_amd.csrc.build [--force]
+
+Every translation unit is compiled to an object (cached by mtime of the source and the headers),
+then linked into geneface_amd/csrc/libgeneface_hip.so.  No torch headers are involved: the library
+is a plain C-ABI (include/geneface_hip.h) consumed through ctypes.
+"""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libgeneface_hip.so")
+OBJ_DIR = os.path.join(HERE, "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.cpp")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")))
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+    newest = max(os.path.getmtime(p) for p in [src, __file__, *headers()])
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj, False
+    cmd = [HIPCC, *COMMON, "-x", "hip", "-c", src, "-o", obj, "-I", HERE, "-I", os.path.join(HERE, "..", "..", "include")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), sources()))
+    objs = [o for o, _ in results]
+    if force or any(ch for _, ch in results) or not os.path.exists(OUT):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print("linked", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

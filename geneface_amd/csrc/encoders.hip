@@ -1,0 +1,159 @@
+// Stand-alone encoder operators behind the `_gridencoder`, `_shencoder`, `_freqencoder` seams.
+//   grid : /root/reference/modules/radnerfs/encoders/gridencoder/src/gridencoder.cu:88-244, launch :370-400
+//   SH   : .../encoders/shencoder/src/shencoder.cu:28-68 (degree <= 4), launch :385-391
+//   freq : .../encoders/freqencoder/src/freqencoder.cu:30-58, launch :96-110
+#include "common.hpp"
+#include "grid_core.hpp"
+#include "sh_core.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// LAYOUT_BLC == false : outputs [L,B,C] (what the pybind seam promises, grid.py:47)
+// LAYOUT_BLC == true  : outputs [B,L*C] directly (what GridEncoder.forward returns after its permute)
+template <uint32_t D, uint32_t C, bool LAYOUT_BLC>
+__global__ void __launch_bounds__(kBlock) k_grid_encode(const float* __restrict__ inputs, const float* __restrict__ embeddings,
+                                                        const int* __restrict__ offsets, float* __restrict__ outputs, uint32_t B,
+                                                        gf::GridLevels lv, float* __restrict__ dy_dx, uint32_t gridtype,
+                                                        bool align_corners, uint32_t interp) {
+    uint32_t b, level;
+    if (LAYOUT_BLC) {  // consecutive lanes -> consecutive levels of one point: coalesced [B, L*C] stores
+        const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+        b = tid / lv.L;
+        level = tid - b * lv.L;
+    } else {           // level-major like the reference: one level's table per blockIdx.y
+        b = blockIdx.x * kBlock + threadIdx.x;
+        level = blockIdx.y;
+    }
+    if (b >= B) return;
+    const uint32_t L = lv.L;
+
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0 || x[d] > 1);
+    }
+    float* out = LAYOUT_BLC ? outputs + (size_t)b * L * C + level * C : outputs + ((size_t)level * B + b) * C;
+    float* dd = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
+    float res[C];
+    if (oob) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) res[c] = 0.0f;
+        if (dd) for (uint32_t i = 0; i < D * C; i++) dd[i] = 0.0f;
+    } else {
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        gf::grid_level_lookup<D, C>(embeddings + (size_t)off * C, hashmap_size, lv.scale[level], lv.resolution[level], gridtype,
+                                    align_corners, interp, x, res, dd);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) out[c] = res[c];
+}
+
+template <uint32_t D, uint32_t C>
+int launch_grid(bool blc, const float* inputs, const float* embeddings, const int* offsets, float* outputs, uint32_t B,
+                const gf::GridLevels& lv, float* dy_dx, uint32_t gridtype, bool align_corners, uint32_t interp, hipStream_t s) {
+    if (blc) {
+        const uint64_t total = (uint64_t)B * lv.L;
+        hipLaunchKernelGGL((k_grid_encode<D, C, true>), dim3((uint32_t)gf_div_up<uint64_t>(total, kBlock)), dim3(kBlock), 0, s, inputs,
+                           embeddings, offsets, outputs, B, lv, dy_dx, gridtype, align_corners, interp);
+    } else {
+        hipLaunchKernelGGL((k_grid_encode<D, C, false>), dim3(gf_div_up(B, (uint32_t)kBlock), lv.L), dim3(kBlock), 0, s, inputs, embeddings,
+                           offsets, outputs, B, lv, dy_dx, gridtype, align_corners, interp);
+    }
+    return gf_check_launch("grid_encode_forward");
+}
+
+template <uint32_t D>
+int dispatch_c(uint32_t C, bool blc, const float* inputs, const float* embeddings, const int* offsets, float* outputs, uint32_t B,
+               const gf::GridLevels& lv, float* dy_dx, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
+    switch (C) {
+        case 1: return launch_grid<D, 1>(blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 2: return launch_grid<D, 2>(blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 4: return launch_grid<D, 4>(blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 8: return launch_grid<D, 8>(blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+}
+
+int grid_encode_any(bool blc, const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                    uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
+                    uint32_t interp, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!inputs || !embeddings || !offsets || !outputs) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward: null pointer");
+    if (gridtype > 1 || interp > 1) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward: gridtype/interp must be 0 or 1");
+    if (C >= 2 && ((uintptr_t)embeddings & (C >= 4 ? 15u : 7u))) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward: embeddings misaligned");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: return dispatch_c<2>(C, blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 3: return dispatch_c<3>(C, blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 4: return dispatch_c<4>(C, blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 5: return dispatch_c<5>(C, blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sh(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t degree) {
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    float sh[16];
+    gf::sh4(inputs[(size_t)b * 3], inputs[(size_t)b * 3 + 1], inputs[(size_t)b * 3 + 2], sh);
+    const uint32_t n = degree * degree;
+    float* o = outputs + (size_t)b * n;
+    for (uint32_t i = 0; i < n; i++) o[i] = sh[i];
+}
+
+// one lane per output element, like the reference (the output row is what bounds this kernel)
+__global__ void __launch_bounds__(kBlock) k_freq(const float* __restrict__ inputs, uint32_t B, uint32_t D, uint32_t C, float* __restrict__ outputs) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (uint64_t)B * C) return;
+    const uint32_t b = (uint32_t)(t / C), c = (uint32_t)(t - (uint64_t)b * C);
+    const float* in = inputs + (size_t)b * D;
+    outputs[t] = gf::freq_element(in, D, c);
+}
+
+}  // namespace
+
+GF_EXPORT int gf_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                                     uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
+                                     int align_corners, uint32_t interp, void* stream) {
+    return grid_encode_any(false, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, stream);
+}
+
+GF_EXPORT int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                                         uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
+                                         int align_corners, uint32_t interp, void* stream) {
+    return grid_encode_any(true, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, stream);
+}
+
+GF_EXPORT int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out, uint32_t* resolution_out) {
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_level_meta: L must be in [1,32]");
+    for (uint32_t l = 0; l < L; l++) { scale_out[l] = lv.scale[l]; resolution_out[l] = lv.resolution[l]; }
+    return GF_OK;
+}
+
+GF_EXPORT int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx, void* stream) {
+    if (B == 0) return GF_OK;
+    if (D != 3) return gf_set_error(GF_ERR_INVALID, "SH encoder only support input dim == 3");
+    if (degree < 1 || degree > 4) return gf_set_error(GF_ERR_UNSUPPORTED, "SH encoder: this build implements degree 1..4 (GeneFace uses 4)");
+    if (dy_dx) return gf_set_error(GF_ERR_UNSUPPORTED, "SH encoder: dy_dx (training) is not built yet");
+    if (!inputs || !outputs) return gf_set_error(GF_ERR_INVALID, "sh_encode_forward: null pointer");
+    hipLaunchKernelGGL(k_sh, dim3(gf_div_up(B, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), inputs, outputs, B, degree);
+    return gf_check_launch("sh_encode_forward");
+}
+
+GF_EXPORT int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream) {
+    if (B == 0) return GF_OK;
+    if (C != D + 2 * D * deg) return gf_set_error(GF_ERR_INVALID, "freq_encode_forward: C must equal D + 2*D*deg");
+    if (!inputs || !outputs) return gf_set_error(GF_ERR_INVALID, "freq_encode_forward: null pointer");
+    const uint64_t total = (uint64_t)B * C;
+    hipLaunchKernelGGL(k_freq, dim3((uint32_t)gf_div_up<uint64_t>(total, kBlock)), dim3(kBlock), 0, gf_stream(stream), inputs, B, D, C, outputs);
+    return gf_check_launch("freq_encode_forward");
+}

@@ -1,0 +1,48 @@
+// Direction / frequency encodings shared by the op kernels and the fused field kernels.
+//   real spherical harmonics, bands 0..3 (16 values): contract = kernel_sh,
+//     /root/reference/modules/radnerfs/encoders/shencoder/src/shencoder.cu:50-68
+//   NeRF frequency encoding: contract = kernel_freq, .../freqencoder/src/freqencoder.cu:30-58
+#pragma once
+#include "common.hpp"
+
+namespace gf {
+
+// sh[0..15] for a (unit) direction.  Band ordering and signs follow the reference's basis.
+__device__ __forceinline__ void sh4(float x, float y, float z, float (&sh)[16]) {
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
+    constexpr float k1 = 0.48860251190291987f;   // sqrt(3/(4pi))
+    constexpr float k2 = 1.0925484305920792f;    // sqrt(15/(4pi))
+    constexpr float k3a = 0.59004358992664352f;  // sqrt(35/(32pi))
+    constexpr float k3b = 0.45704579946446572f;  // sqrt(21/(32pi))
+    sh[0] = 0.28209479177387814f;
+    sh[1] = -k1 * y;
+    sh[2] = k1 * z;
+    sh[3] = -k1 * x;
+    sh[4] = k2 * xy;
+    sh[5] = -k2 * yz;
+    sh[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    sh[7] = -k2 * xz;
+    sh[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    sh[9] = k3a * y * (-3.0f * x2 + y2);
+    sh[10] = 2.8906114426405538f * xy * z;
+    const float m5z = 1.0f - 5.0f * z2;
+    sh[11] = k3b * y * m5z;
+    sh[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    sh[13] = k3b * x * m5z;
+    sh[14] = 1.4453057213202769f * z * (x2 - y2);
+    sh[15] = k3a * x * (-x2 + 3.0f * y2);
+}
+
+// element c of the [D + 2*D*deg] frequency encoding of in[0..D):
+//   [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...], cos evaluated as sin(. + pi/2) with pi/2 rounded to fp32
+__device__ __forceinline__ float freq_element(const float* __restrict__ in, uint32_t D, uint32_t c) {
+    if (c < D) return in[c];
+    const uint32_t col = c / D - 1, d = c - (col + 1) * D, freq = col >> 1;
+    const float phase = (col & 1u) ? (3.141592653589793f / 2) : 0.0f;
+    // the reference's __sinf is a hardware-specific fast sine (error grows with |x|, and the torso's
+    // 2^9 x reaches ~400 rad); the correctly-rounded-ish sinf is the centroid every fast sine approximates
+    return sinf(scalbnf(in[d], (int)freq) + phase);
+}
+
+}  // namespace gf

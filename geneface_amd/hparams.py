@@ -1,0 +1,60 @@
+"""The hparams the RAD-NeRF render path reads, with the May `lm3d_radnerf(_torso)` values.
+
+The reference resolves these through a yaml chain
+(egs/datasets/videos/May/lm3d_radnerf_torso.yaml -> egs/egs_bases/radnerf/lm3d_radnerf.yaml
+ -> egs/egs_bases/radnerf/base.yaml:49-122) into a global mutable dict
+(utils/commons/hparams.py:25-132) and forwards the *whole* dict into render(**hparams)
+(tasks/radnerfs/radnerf.py:169).  We keep plain-dict semantics; only the keys the hot path
+reads are listed.  tests/test_hparams.py checks these values against the reference yaml chain
+when the reference tree is present.
+"""
+import copy
+
+_MAY_BASE = {
+    # NeRF / marcher (base.yaml:52-80)
+    "near": 0.3, "far": 0.9, "n_rays": 65536, "cuda_ray": True,
+    "max_steps": 16, "num_steps": 16, "upsample_steps": 0, "update_extra_interval": 16, "max_ray_batch": 4096,
+    "min_near": 0.05, "bound": 1, "camera_scale": 4.0, "camera_offset": [0, 0, 0],
+    "grid_size": 128, "desired_resolution": 2048, "log2_hashmap_size": 16,
+    "dt_gamma": 0.00390625, "density_thresh": 10, "density_thresh_torso": 0.01, "torso_shrink": 0.8,
+    "smooth_lips": False,
+    # network (base.yaml:85-102)
+    "grid_type": "tiledgrid", "grid_interpolation_type": "linear", "with_att": True, "use_window_cond": True,
+    "torso_head_aware": False,
+    "num_layers_sigma": 3, "hidden_dim_sigma": 128, "geo_feat_dim": 128,
+    "num_layers_color": 2, "hidden_dim_color": 128, "cond_out_dim": 64,
+    "num_layers_ambient": 3, "hidden_dim_ambient": 128, "ambient_out_dim": 2,
+    "individual_embedding_num": 13000, "individual_embedding_dim": 4, "torso_individual_embedding_dim": 8,
+    # lm3d_radnerf.yaml:4-7
+    "cond_type": "idexp_lm3d_normalized", "cond_win_size": 1, "smo_win_size": 5,
+    "task_cls": "tasks.radnerfs.radnerf.RADNeRFTask",
+    # infer (base.yaml:104-116)
+    "infer_scale_factor": 1.0, "infer_lm3d_clamp_std": 2.5, "infer_smooth_camera_path": True,
+    "infer_smooth_camera_path_kernel_size": 7, "infer_bg_img_fname": "",
+    # gui (base.yaml:118-123)
+    "gui_w": 512, "gui_h": 512, "gui_radius": 3.35, "gui_fovy": 21.24, "gui_max_spp": 1,
+    "amp": True, "seed": 9999, "video_id": "May",
+}
+
+_MAY_TORSO = {
+    "task_cls": "tasks.radnerfs.radnerf_torso.RADNeRFTorsoTask",
+    "head_model_dir": "checkpoints/May/lm3d_radnerf",
+    "torso_train_mode": 1,
+}
+
+
+def may_hparams(torso: bool = True) -> dict:
+    hp = copy.deepcopy(_MAY_BASE)
+    if torso:
+        hp.update(copy.deepcopy(_MAY_TORSO))
+    return hp
+
+
+#: the process-global dict, mirroring `utils.commons.hparams.hparams`
+hparams = {}
+
+
+def set_hparams(new: dict) -> dict:
+    hparams.clear()
+    hparams.update(new)
+    return hparams

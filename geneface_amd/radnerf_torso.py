@@ -1,0 +1,103 @@
+"""Head + 2-D deformable torso renderer.
+
+Drop-in for `RADNeRFTorso` of modules/radnerfs/radnerf_torso.py:17-241 on the inference branch:
+`forward_torso` :51-84 and `render` :86-198 keep their signatures and result keys
+(`rgb_map, depth_map, torso_alpha_map, torso_rgb_map, deform`).  Unlike the reference, `torso_shrink`
+and `torso_head_aware` are read from the hparams given to the constructor rather than from a
+process-global dict.  `torso_head_aware=True` (random branch at inference, :175-179) is not built.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import raymarching
+from .cond_encoder import MLP
+from .encoders import get_encoder
+from .radnerf import RADNeRF
+
+
+class RADNeRFTorso(RADNeRF):
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        self.register_buffer("density_grid_torso", torch.zeros([self.grid_size ** 2]))
+        self.mean_density_torso = 0  # not in the state_dict: a freshly loaded model thresholds at 0
+        self.density_thresh_torso = hparams["density_thresh_torso"]
+        self.torso_shrink = hparams["torso_shrink"]
+        if hparams.get("torso_head_aware", False):
+            raise NotImplementedError("torso_head_aware=True takes a random branch per frame in the reference; not built")
+
+        self.torso_individual_embedding_num = hparams["individual_embedding_num"]
+        self.torso_individual_embedding_dim = hparams["torso_individual_embedding_dim"]
+        if self.torso_individual_embedding_dim > 0:
+            self.torso_individual_codes = nn.Parameter(
+                torch.randn(self.torso_individual_embedding_num, self.torso_individual_embedding_dim) * 0.1)
+
+        self.torso_pose_embedder, self.pose_embedding_dim = get_encoder("frequency", input_dim=6, multires=4)
+        self.torso_deform_pos_embedder, self.torso_deform_pos_dim = get_encoder("frequency", input_dim=2, multires=10)
+        self.torso_embedder, self.torso_in_dim = get_encoder("tiledgrid", input_dim=2, num_levels=16, level_dim=2,
+                                                             base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
+        deform_in = self.torso_deform_pos_dim + self.pose_embedding_dim + self.torso_individual_embedding_dim
+        self.torso_deform_net = MLP(deform_in, 2, 64, 3)
+        self.torso_canonicial_net = MLP(self.torso_in_dim + deform_in, 4, 32, 3)
+
+    def _torso_code(self):
+        return self.torso_individual_codes[0] if self.torso_individual_embedding_dim > 0 else None
+
+    def forward_torso(self, x, poses, c=None, image=None, weights_sum=None):
+        """x [m,2] in [-1,1], poses [1,6], c [8] -> alpha [m,1], colour [m,3], dx [m,2]."""
+        m = x.shape[0]
+        x = x * self.torso_shrink
+        parts = [self.torso_deform_pos_embedder(x), self.torso_pose_embedder(poses).reshape(1, -1).expand(m, -1)]
+        if c is not None:
+            parts.append(c.reshape(1, -1).expand(m, -1))
+        h = torch.cat(parts, dim=-1)
+        dx = self.torso_deform_net(h)
+        xc = (x + dx).clamp(-1, 1).float()
+        h = self.torso_canonicial_net(torch.cat([self.torso_embedder(xc, bound=1), h], dim=-1))
+        return torch.sigmoid(h[..., :1]), torch.sigmoid(h[..., 1:]), dx
+
+    def torso_mask(self, bg_coords):
+        thresh = min(self.density_thresh_torso, self.mean_density_torso)
+        occ = F.grid_sample(self.density_grid_torso.view(1, 1, self.grid_size, self.grid_size), bg_coords.view(1, -1, 1, 2),
+                            align_corners=True).view(-1)
+        return occ > thresh
+
+    def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False,
+               force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
+        if self.training:
+            raise NotImplementedError("RADNeRFTorso.render: the training branch is outside this round's scope (SURVEY.md 8f-2)")
+        impl = kwargs.get("render_impl", self.render_impl)
+        if impl == "fused":
+            from .fused import render_torso_fused
+            return render_torso_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh)
+        with torch.no_grad():
+            prefix = rays_o.shape[:-1]
+            rays_o = rays_o.contiguous().view(-1, 3)
+            rays_d = rays_d.contiguous().view(-1, 3)
+            bg_coords = bg_coords.contiguous().view(-1, 2)
+            N, device = rays_o.shape[0], rays_o.device
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+            cond_feat = self.cal_cond_feat(cond)
+            weights_sum, depth, image = self._march_head_ops(rays_o, rays_d, nears, fars, cond_feat, self._ind_code(),
+                                                             dt_gamma, perturb, max_steps, T_thresh)
+            if bg_color is None:
+                bg_color = 1
+            results = {}
+            mask = self.torso_mask(bg_coords)
+            torso_alpha = torch.zeros([N, 1], device=device)
+            torso_color = torch.zeros([N, 3], device=device)
+            if mask.any():
+                a, c, deform = self.forward_torso(bg_coords[mask], poses, self._torso_code())
+                torso_alpha[mask] = a.float()
+                torso_color[mask] = c.float()
+                results["deform"] = deform
+            bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
+            results["torso_alpha_map"] = torso_alpha
+            results["torso_rgb_map"] = bg_color
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            results["rgb_map"] = image.view(*prefix, 3).clamp(0, 1)
+            results["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+            return results
+
+    def update_extra_state(self, decay=0.95, S=128):
+        raise NotImplementedError("density-grid maintenance is the next scope row (SURVEY.md 8f-1)")

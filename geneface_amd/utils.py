@@ -1,0 +1,80 @@
+"""Camera / pose helpers of the render path (torch, tiny, once per frame or per sequence).
+
+Behaviour follows modules/radnerfs/utils.py of the reference: trunc_exp :36-49 (forward = exp),
+nerf_matrix_to_ngp :53-60, matrix_to_euler_angles :160-199 ('XYZ'), convert_poses :263-269,
+get_bg_coords :273-278, get_rays :282-363 (full-image branch, N = -1), and
+tasks/radnerfs/dataset_utils.py:16-36 smooth_camera_path.
+"""
+import numpy as np
+import torch
+
+
+def trunc_exp(x):
+    return torch.exp(x.float())
+
+
+def nerf_matrix_to_ngp(pose, scale=4, offset=(0, 0, 0)):
+    p = np.asarray(pose)
+    return np.array([
+        [p[1, 0], -p[1, 1], -p[1, 2], p[1, 3] * scale + offset[0]],
+        [p[2, 0], -p[2, 1], -p[2, 2], p[2, 3] * scale + offset[1]],
+        [p[0, 0], -p[0, 1], -p[0, 2], p[0, 3] * scale + offset[2]],
+        [0, 0, 0, 1]], dtype=np.float32)
+
+
+def matrix_to_euler_angles_xyz(m: torch.Tensor) -> torch.Tensor:
+    """XYZ Tait-Bryan angles of rotation matrices [...,3,3] (pytorch3d convention used by the reference)."""
+    central = torch.asin(m[..., 0, 2])
+    a0 = torch.atan2(-m[..., 1, 2], m[..., 2, 2])
+    a2 = torch.atan2(-m[..., 0, 1], m[..., 0, 0])
+    return torch.stack((a0, central, a2), -1)
+
+
+def convert_poses(poses: torch.Tensor) -> torch.Tensor:
+    """[B,4,4] cam2world -> [B,6] (XYZ euler, translation): the torso network's pose input."""
+    out = torch.empty(poses.shape[0], 6, dtype=torch.float32, device=poses.device)
+    out[:, :3] = matrix_to_euler_angles_xyz(poses[:, :3, :3].float())
+    out[:, 3:] = poses[:, :3, 3]
+    return out
+
+
+def get_bg_coords(H, W, device):
+    X = torch.arange(H, device=device) / (H - 1) * 2 - 1
+    Y = torch.arange(W, device=device) / (W - 1) * 2 - 1
+    xs, ys = torch.meshgrid(X, Y, indexing="ij")
+    return torch.cat([xs.reshape(-1, 1), ys.reshape(-1, 1)], dim=-1).unsqueeze(0)
+
+
+def get_rays(poses, intrinsics, H, W, N=-1):
+    """All-pixel pinhole rays: pixel centres at +0.5, unit directions rotated by pose[:3,:3], row-major order."""
+    if N > 0:
+        raise NotImplementedError("get_rays: random / patch / rect sampling is a training feature (SURVEY.md 8f-2)")
+    device = poses.device
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsics
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device), indexing="ij")
+    i = i.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+    j = j.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+    zs = torch.ones_like(i)
+    xs = (i - cx) / fx * zs
+    ys = (j - cy) / fy * zs
+    directions = torch.stack((xs, ys, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    return {"i": i, "j": j, "inds": torch.arange(H * W, device=device).expand([B, H * W]), "rays_o": rays_o, "rays_d": rays_d}
+
+
+def smooth_camera_path(poses: np.ndarray, kernel_size=7) -> np.ndarray:
+    """Box-filter translations and chordal-mean rotations over a centred window (in place, like the reference)."""
+    from scipy.spatial.transform import Rotation
+    N, K = poses.shape[0], kernel_size // 2
+    trans, rots = poses[:, :3, 3].copy(), poses[:, :3, :3].copy()
+    for i in range(N):
+        s, e = max(0, i - K), min(N, i + K + 1)
+        poses[i, :3, 3] = trans[s:e].mean(0)
+        try:
+            poses[i, :3, :3] = Rotation.from_matrix(rots[s:e]).mean().as_matrix()
+        except Exception:
+            poses[i, :3, :3] = rots[i] if i == 0 else poses[i - 1, :3, :3]
+    return poses

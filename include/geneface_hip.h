@@ -1,0 +1,90 @@
+/*
+ * geneface_hip.h -- C ABI of libgeneface_hip.so, the MI355X (gfx950) RAD-NeRF render path for GeneFace.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; tensors are contiguous, row-major, fp32
+ *     unless stated; outputs are pre-allocated by the caller and written in place (the convention of the
+ *     reference's pybind modules, where every at::Tensor output is allocated by the Python wrapper);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work;
+ *   - return value: 0 on success, non-zero otherwise (GF_ERR_*); gf_last_error() returns the message the
+ *     reference would have thrown (std::runtime_error / TORCH_CHECK text where one exists).
+ * Each entry point cites the reference interface it replaces (paths relative to the GeneFace repository).
+ */
+#ifndef GENEFACE_HIP_H
+#define GENEFACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_OK 0
+#define GF_ERR_INVALID 1
+#define GF_ERR_HIP 2
+#define GF_ERR_UNSUPPORTED 3
+
+const char* gf_last_error(void);
+const char* gf_version(void);
+int gf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * `_raymarching_face`   modules/radnerfs/raymarching/src/bindings.cpp:5-21, raymarching.h:7-20
+ * ---------------------------------------------------------------------------------------------- */
+
+/* near_far_from_aabb (raymarching.h:7, kernel raymarching.cu:92-145).  rays_o/rays_d [N,3], aabb [6], nears/fars [N]. */
+int gf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                          float* nears, float* fars, void* stream);
+
+/* march_rays (raymarching.h:19, kernel raymarching.cu:828-929).  rays_alive i32[>=n_alive], rays_t/nears/fars [N],
+ * grid u8[C*H^3/8], xyzs/dirs [n_alive*n_step,3] and deltas [n_alive*n_step,2] ZERO-FILLED by the caller, noises [n_alive]. */
+int gf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                  const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                  const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                  const float* noises, void* stream);
+
+/* composite_rays (raymarching.h:20, kernel raymarching.cu:943-1029).  In-place on rays_alive (-1 = terminated), rays_t,
+ * weights_sum [N], depth [N], image [N,3]. */
+int gf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                      const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                      float* image, void* stream);
+
+/* occupancy-grid maintenance: morton3D (raymarching.h:9, .cu:214-226), morton3D_invert (:10, .cu:237-254),
+ * packbits (:11, .cu:268-289; N = number of output bytes), morton3D_dilation (:12, .cu:304-335). */
+int gf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+int gf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+int gf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+int gf_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_dilation, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * `_gridencoder`   modules/radnerfs/encoders/gridencoder/src/bindings.cpp:5-9, gridencoder.h:11
+ * ---------------------------------------------------------------------------------------------- */
+
+/* grid_encode_forward (kernel gridencoder.cu:88-244).  inputs [B,D] in [0,1]; embeddings [sO,C]; offsets i32[L+1];
+ * outputs [L,B,C]; S = log2(per_level_scale); H = base resolution; dy_dx NULL or [B, L*D*C];
+ * gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.  D in {2,3,4,5}, C in {1,2,4,8}. */
+int gf_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                           uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
+                           int align_corners, uint32_t interp, void* stream);
+/* same arithmetic, outputs laid out [B, L*C] (what GridEncoder.forward returns after grid.py:57's permute). */
+int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
+                               int align_corners, uint32_t interp, void* stream);
+/* HOST helper: per-level scale / resolution exactly as the kernels use them (gridencoder.cu:138-139). */
+int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out_host, uint32_t* resolution_out_host);
+
+/* ------------------------------------------------------------------------------------------------
+ * `_shencoder`   modules/radnerfs/encoders/shencoder/src/bindings.cpp, shencoder.h:9
+ * `_freqencoder` modules/radnerfs/encoders/freqencoder/src/bindings.cpp, freqencoder.h:7
+ * ---------------------------------------------------------------------------------------------- */
+
+/* sh_encode_forward (kernel shencoder.cu:28-68).  inputs [B,3], outputs [B,degree^2]; degree 1..4; dy_dx must be NULL. */
+int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx, void* stream);
+
+/* freq_encode_forward (kernel freqencoder.cu:30-58).  inputs [B,D], outputs [B,C], C = D + 2*D*deg. */
+int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENEFACE_HIP_H */

@@ -1,0 +1,31 @@
+"""Build recipe for the parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Compiles oracle/radnerf_kernels.c with gcc into oracle/_build/liboracle_radnerf.so.
+The output directory is git-ignored but travels to the GPU box with the snapshot.
+There is no oracle/_ref: the reference's kernels are CUDA sources (no nvcc here), so the
+real reference cannot be compiled in this image ("Oracle").
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "radnerf_kernels.c")
+OUT_DIR = os.path.join(HERE, "_build")
+OUT = os.path.join(OUT_DIR, "liboracle_radnerf.so")
+
+# -ffp-contract=off: every a*b+c rounds twice unless written as fmaf() (file header explains why)
+CFLAGS = ["-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+          "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wextra"]
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(SRC):
+        return OUT
+    cmd = ["gcc", *CFLAGS, SRC, "-o", OUT, "-lm"]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,238 @@
+"""Model-level oracle (TEST INFRASTRUCTURE ONLY): the RAD-NeRF head / head+torso frame on CPU.
+
+A functional (state_dict in, tensors out) torch-fp32 restatement of the reference's Python layers
+on top of the C kernels in radnerf_kernels.c.  It needs neither /root/reference nor a GPU, so it
+is what the `-m gpu` parity tests, smoke() and bench.py's cpu_baseline leg check against on the
+GPU box.  It is itself pinned, in the build container, against the reference's own unmodified
+Python (oracle/refshim.py) by tests/test_oracle_vs_reference.py and the committed golden vectors.
+
+Reference lines followed (relative to /root/reference):
+  cond encoder    modules/radnerfs/cond_encoder.py:44-52 (AudioNet), :79-89 (AudioAttNet), :106-111 (MLP)
+  head field      modules/radnerfs/radnerf.py:61-105
+  march loop      modules/radnerfs/renderer.py:263-367 (inference branch :314-351)
+  torso           modules/radnerfs/radnerf_torso.py:51-84, :156-198
+  op wrappers     raymarching/raymarching.py:18-48, :347-420; gridencoder/grid.py:27-63, :145-161;
+                  shencoder/sphere_harmonics.py:14-40; freqencoder/freq.py:15-36
+  rays / poses    modules/radnerfs/utils.py:263-363
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+
+RM, GE, SH, FQ = K.raymarching_face, K.gridencoder, K.shencoder, K.freqencoder
+
+
+# ----------------------------------------------------------------------------- op wrappers
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
+    N = rays_o.shape[0]
+    nears, fars = torch.empty(N), torch.empty(N)
+    RM.near_far_from_aabb(rays_o.contiguous(), rays_d.contiguous(), aabb.contiguous(), N, min_near, nears, fars)
+    return nears, fars
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfield, C, H, nears, fars, align, dt_gamma, max_steps):
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+    noises = torch.zeros(n_alive)  # perturb=False at inference
+    RM.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bitfield, nears, fars,
+                  xyzs, dirs, deltas, noises)
+    return xyzs, dirs, deltas
+
+
+def grid_encode(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interp):
+    x01 = x01.contiguous()
+    B, D = x01.shape
+    L, C = offsets.shape[0] - 1, embeddings.shape[1]
+    out = torch.empty(L, B, C)
+    GE.grid_encode_forward(x01, embeddings.contiguous(), offsets, out, B, D, C, L, float(np.log2(per_level_scale)), base_resolution,
+                           None, gridtype, align_corners, interp)
+    return out.permute(1, 0, 2).reshape(B, L * C)
+
+
+def sh_encode(d, degree=4):
+    d = d.contiguous()
+    out = torch.empty(d.shape[0], degree * degree)
+    SH.sh_encode_forward(d, out, d.shape[0], 3, degree, None)
+    return out
+
+
+def freq_encode(x, degree):
+    x = x.contiguous()
+    B, D = x.shape
+    C = D + 2 * D * degree
+    out = torch.empty(B, C)
+    FQ.freq_encode_forward(x, B, D, degree, C, out)
+    return out
+
+
+# ----------------------------------------------------------------------------- small networks
+def mlp(sd, prefix, x, num_layers):
+    for l in range(num_layers):
+        x = F.linear(x, sd[f"{prefix}.net.{l}.weight"])
+        if l != num_layers - 1:
+            x = F.relu(x)
+    return x
+
+
+def cal_cond_feat(sd, hp, cond):
+    """cond [smo_win, cond_win, C] -> [cond_out_dim]"""
+    strides = {1: (1, 1, 1, 1), 2: (2, 1, 1, 1), 3: (2, 2, 1, 1), 4: (2, 2, 1, 1), 16: (2, 2, 2, 2)}[hp["cond_win_size"]]
+    x = cond.permute(0, 2, 1)
+    for i, s in enumerate(strides):
+        x = F.leaky_relu(F.conv1d(x, sd[f"cond_prenet.encoder_conv.{2 * i}.weight"], sd[f"cond_prenet.encoder_conv.{2 * i}.bias"],
+                                  stride=s, padding=1), 0.02)
+    x = x.squeeze(-1)
+    x = F.leaky_relu(F.linear(x, sd["cond_prenet.encoder_fc1.0.weight"], sd["cond_prenet.encoder_fc1.0.bias"]), 0.02)
+    x = F.linear(x, sd["cond_prenet.encoder_fc1.2.weight"], sd["cond_prenet.encoder_fc1.2.bias"]).squeeze()
+    if not hp["with_att"]:
+        return x
+    seq = hp["smo_win_size"]
+    y = x[:, :hp["cond_out_dim"]].permute(1, 0).unsqueeze(0)
+    for i in range(5):
+        y = F.leaky_relu(F.conv1d(y, sd[f"cond_att_net.attentionConvNet.{2 * i}.weight"], sd[f"cond_att_net.attentionConvNet.{2 * i}.bias"],
+                                  stride=1, padding=1), 0.02)
+    y = F.linear(y.view(1, seq), sd["cond_att_net.attentionNet.0.weight"], sd["cond_att_net.attentionNet.0.bias"])
+    y = torch.softmax(y, dim=1).view(seq, 1)
+    return torch.sum(y * x, dim=0)
+
+
+def _grid_args(hp, desired_resolution):
+    pls = np.exp2(np.log2(desired_resolution / 16) / (16 - 1))
+    gridtype = {"hashgrid": 0, "tiledgrid": 1}[hp["grid_type"]]
+    interp = {"linear": 0, "smoothstep": 1}[hp["grid_interpolation_type"]]
+    return pls, gridtype, interp
+
+
+def head_field(sd, hp, position, direction, cond_feat, ind_code):
+    """RADNeRF.forward: -> sigma [M], color [M,3], ambient_pos [M,2]"""
+    M = position.shape[0]
+    bound = hp["bound"]
+    pls3, gt, ip = _grid_args(hp, hp["desired_resolution"] * bound)
+    pls2, _, _ = _grid_args(hp, hp["desired_resolution"])
+    pos_feat = grid_encode((position + bound) / (2 * bound), sd["position_embedder.embeddings"], sd["position_embedder.offsets"],
+                           pls3, 16, gt, False, ip)
+    ambient_in = torch.cat([pos_feat, cond_feat.reshape(1, -1).repeat(M, 1)], dim=1)
+    ambient_pos = torch.tanh(mlp(sd, "ambient_net", ambient_in, hp["num_layers_ambient"]).float())
+    ambient_feat = grid_encode((ambient_pos + 1) / 2, sd["ambient_embedder.embeddings"], sd["ambient_embedder.offsets"], pls2, 16,
+                               gt, False, ip)
+    h = mlp(sd, "sigma_net", torch.cat([pos_feat, ambient_feat], dim=-1), hp["num_layers_sigma"])
+    sigma = torch.exp(h[..., 0])
+    parts = [sh_encode(direction), h[..., 1:]]
+    if ind_code is not None:
+        parts.append(ind_code.reshape(1, -1).repeat(M, 1))
+    color = torch.sigmoid(mlp(sd, "color_net", torch.cat(parts, dim=-1), hp["num_layers_color"]))
+    return sigma, color, ambient_pos
+
+
+def torso_field(sd, hp, x, poses6, code):
+    """RADNeRFTorso.forward_torso: x [m,2], poses6 [1,6], code [8] -> alpha [m,1], color [m,3], dx [m,2]"""
+    m = x.shape[0]
+    x = x * hp["torso_shrink"]
+    parts = [freq_encode(x, 10), freq_encode(poses6.reshape(1, 6), 4).repeat(m, 1)]
+    if code is not None:
+        parts.append(code.reshape(1, -1).repeat(m, 1))
+    h = torch.cat(parts, dim=-1)
+    dx = mlp(sd, "torso_deform_net", h, 3)
+    xc = (x + dx).clamp(-1, 1).float()
+    pls = np.exp2(np.log2(2048 / 16) / 15)
+    feat = grid_encode((xc + 1) / 2, sd["torso_embedder.embeddings"], sd["torso_embedder.offsets"], pls, 16, 1, False, 0)
+    h = mlp(sd, "torso_canonicial_net", torch.cat([feat, h], dim=-1), 3)
+    return torch.sigmoid(h[..., :1]), torch.sigmoid(h[..., 1:]), dx
+
+
+# ----------------------------------------------------------------------------- frame
+def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace=None):
+    N = rays_o.shape[0]
+    cascade = 1 + math.ceil(math.log2(hp["bound"]))
+    nears, fars = near_far_from_aabb(rays_o, rays_d, sd["aabb_infer"], hp["min_near"])
+    ind_code = sd["individual_embeddings"][0] if hp["individual_embedding_dim"] > 0 else None
+    weights_sum, depth, image = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+    rays_alive = torch.arange(N, dtype=torch.int32)
+    rays_t = nears.clone()
+    step = 0
+    while step < max_steps:
+        n_alive = rays_alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, float(hp["bound"]), sd["density_bitfield"],
+                                        cascade, hp["grid_size"], nears, fars, 128, dt_gamma, max_steps)
+        sigmas, rgbs, _ = head_field(sd, hp, xyzs, dirs, cond_feat, ind_code)
+        if trace is not None:
+            trace.append({"n_alive": n_alive, "n_step": n_step, "n_valid": int((deltas[:, 0] > 0).sum())})
+        RM.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(), deltas, weights_sum,
+                          depth, image)
+        rays_alive = rays_alive[rays_alive >= 0].contiguous()
+        step += n_step
+    return weights_sum, depth, image, nears, fars
+
+
+def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_gamma=None, max_steps=None, T_thresh=1e-4, trace=None):
+    """One frame: the dict `NeRFRenderer.render` / `RADNeRFTorso.render` return at inference."""
+    dt_gamma = hp["dt_gamma"] if dt_gamma is None else dt_gamma
+    max_steps = hp["max_steps"] if max_steps is None else max_steps
+    with torch.no_grad():
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        cond_feat = cal_cond_feat(sd, hp, cond)
+        weights_sum, depth, image, nears, fars = march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace)
+        if bg_color is None:
+            bg_color = 1
+        out = {}
+        if torso:
+            bg_coords = bg_coords.contiguous().view(-1, 2)
+            G = hp["grid_size"]
+            occ = F.grid_sample(sd["density_grid_torso"].view(1, 1, G, G), bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
+            mask = occ > min(hp["density_thresh_torso"], 0)  # mean_density_torso is 0 after a fresh load
+            torso_alpha, torso_color = torch.zeros(N, 1), torch.zeros(N, 3)
+            if mask.any():
+                code = sd["torso_individual_codes"][0] if hp["torso_individual_embedding_dim"] > 0 else None
+                a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code)
+                torso_alpha[mask], torso_color[mask] = a, c
+                out["deform"] = deform
+            bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
+            out["torso_alpha_map"], out["torso_rgb_map"] = torso_alpha, bg_color
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        out["rgb_map"] = image.view(*prefix, 3).clamp(0, 1)
+        out["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+        out["weights_sum"] = weights_sum
+        return out
+
+
+# ----------------------------------------------------------------------------- rays / poses
+def get_rays(pose44, intrinsics, H, W):
+    fx, fy, cx, cy = intrinsics
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i = i.t().reshape(1, H * W) + 0.5
+    j = j.t().reshape(1, H * W) + 0.5
+    zs = torch.ones_like(i)
+    directions = torch.stack(((i - cx) / fx * zs, (j - cy) / fy * zs, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ pose44[:, :3, :3].transpose(-1, -2)
+    rays_o = pose44[..., :3, 3][..., None, :].expand_as(rays_d)
+    return rays_o, rays_d
+
+
+def get_bg_coords(H, W):
+    X = torch.arange(H) / (H - 1) * 2 - 1
+    Y = torch.arange(W) / (W - 1) * 2 - 1
+    xs, ys = torch.meshgrid(X, Y, indexing="ij")
+    return torch.cat([xs.reshape(-1, 1), ys.reshape(-1, 1)], dim=-1).unsqueeze(0)
+
+
+def convert_poses(pose44):
+    m = pose44[:, :3, :3]
+    out = torch.empty(pose44.shape[0], 6)
+    out[:, 0] = torch.atan2(-m[:, 1, 2], m[:, 2, 2])
+    out[:, 1] = torch.asin(m[:, 0, 2])
+    out[:, 2] = torch.atan2(-m[:, 0, 1], m[:, 0, 0])
+    out[:, 3:] = pose44[:, :3, 3]
+    return out
