@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- rendered 512x512 fps (head+torso) of the RAD-NeRF frame renderer on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]                     (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: cond encoder + ray generation + occupancy-grid march + per-sample field + composite for
+the head, then the torso pass and the final blend, uint8 conversion and the async D2H copy -- for the May
+`lm3d_radnerf` + `lm3d_radnerf_torso` configuration (BASELINE.json configs[2]) on the seeded synthetic fixture
+(random-init weights of that architecture, analytic head occupancy; there are no offline checkpoints).  Inputs
+(landmark windows, poses, background, weights) are resident in HBM before the timed region.  Frames shard
+across ranks with no data-path collective (weak scaling: every rank renders K frames); the one collective is
+the weight broadcast before the loop.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_HEAD_SAMPLE = 178_688   # 2*(96*128+128*128+128*2 + 64*128+128*128+128*129 + 148*128+128*3)
+FLOP_PER_TORSO_PIXEL = 32_768    # 2*(104*64+64*64+64*2 + 136*32+32*32+32*4)
+BYTES_PER_HEAD_SAMPLE = 1_536    # fp32 table gathers: 16 levels * (8 + 4 corners) * 8 B
+BYTES_PER_TORSO_PIXEL = 512
+BYTES_PER_RAY = 56
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense MFMA peak for f32 inputs
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--impl", default=None, choices=[None, "ops", "fused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--profile-frames", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(hp, sd, seq, n_frames):
+    """The oracle (CPU port of the reference's render path: torch-fp32 layers over the C kernels) timed on the host
+    cores of this box, on a bounded sample of the same workload."""
+    import torch
+    from oracle import radnerf_ref as R
+    H, W = seq["H"], seq["W"]
+    bgc = R.get_bg_coords(H, W)
+    bg = torch.from_numpy(seq["bg_img"]).view(1, -1, 3)
+
+    def one(i):
+        pose = torch.from_numpy(seq["poses"][i:i + 1])
+        ro, rd = R.get_rays(pose, seq["intrinsics"], H, W)
+        return R.render(sd, hp, ro, rd, torch.from_numpy(seq["cond_wins"][i]), bgc, R.convert_poses(pose), bg, torso=True)
+    one(0)  # warm-up (thread pools, page faults)
+    t0 = time.perf_counter()
+    for i in range(1, 1 + n_frames):
+        one(i)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_frames} head+torso {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.infer import FramePipeline, broadcast_model_, shard_range
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+
+    impl = args.impl
+    if impl is None:
+        try:
+            import geneface_amd.fused  # noqa: F401
+            impl = "fused"
+        except ImportError:
+            impl = "ops"
+
+    hp = HP.may_hparams(True)
+    K, Wm = args.steps, args.warmup
+    per_rank = K + Wm
+    seq = S.make_sequence(per_rank * world, args.size, args.size, hp)
+    sd = S.make_state_dict(hp, True)
+    model = RADNeRFTorso(hp)
+    if rank == 0:
+        model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    broadcast_model_(model, src=0)  # the only collective (RCCL): one flattened weight buffer
+    pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(Wm):
+            pipe.render_frame(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            pipe.render_frame(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+        roofline = None
+        if rank == 0:
+            roofline = measure_roofline(pipe, impl, Wm, min(args.profile_frames, K))
+
+    if rank == 0:
+        line = {
+            "metric": "rendered 512x512 fps (head+torso)", "value": world * K / dt, "unit": "frames/s", "n_gpus": world,
+            "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
+                                   f"(BASELINE.json configs[2]); frame-sharded over {world} GPU(s)",
+                       "impl": impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
+                       "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(hp, sd, seq, args.cpu_frames)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+def measure_roofline(pipe, impl, first, n_frames):
+    """Dominant-kernel roofline from live HIP-event timing of that kernel's launches (outside the fps region)."""
+    import torch
+    if impl == "fused":
+        from geneface_amd.fused import profile_frames
+        return profile_frames(pipe, first, n_frames, FLOP_PER_HEAD_SAMPLE, PEAK_F32_MFMA_TFLOPS)
+    # impl == "ops": the dominant kernel is whichever rocBLAS SGEMM torch dispatches; it is not ours to time per launch.
+    return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+            "note": "impl=ops runs the MLPs through rocBLAS; per-kernel roofline is reported for impl=fused only"}
+
+
+if __name__ == "__main__":
+    main()

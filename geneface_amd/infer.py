@@ -1,0 +1,107 @@
+"""Frame loop, frame sharding and weight broadcast of the RAD-NeRF inference path.
+
+Mirrors the data-parallel structure of inference/nerfs/base_nerf_infer.py in the reference:
+  * contiguous block partition of frames over ranks, last rank takes the remainder (:150-155),
+  * every rank holds a full replica; the only collective is a one-off weight broadcast (the DDP
+    constructor's implicit broadcast, :126,145) + barriers around the loop (:146,178),
+  * per frame: run_model(batch, infer=True) -> rgb*255 -> uint8 on the host (:95-97).
+One process per GPU (torchrun / torch.distributed, backend nccl == RCCL over xGMI); no per-frame
+communication.  Landmark post-processing lives in lm3d.py, model classes in radnerf*.py.
+"""
+import numpy as np
+import torch
+
+from . import utils
+
+
+def shard_range(num_frames: int, rank: int, world_size: int):
+    """[start, stop) of the frames `rank` renders (base_nerf_infer.py:150-155)."""
+    per = num_frames // world_size
+    start = rank * per
+    stop = (rank + 1) * per if rank != world_size - 1 else num_frames
+    return start, stop
+
+
+def broadcast_model_(model: torch.nn.Module, src: int = 0):
+    """Make every replica bit-identical to rank `src` with ONE collective per dtype: parameters and buffers are
+    flattened into a single contiguous buffer (~26 MB fp32 for head+torso), broadcast, and scattered back."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    tensors = [t for _, t in sorted(list(model.named_parameters()) + list(model.named_buffers()), key=lambda kv: kv[0])]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype in sorted(by_dtype, key=str):
+            group = by_dtype[dtype]
+            flat = torch.cat([t.detach().reshape(-1) for t in group])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+    return model
+
+
+class FramePipeline:
+    """Device-resident inputs of one rank's frame shard + the per-frame step.
+
+    `seq` is the host dict produced upstream (synthetic.make_sequence or the dataset/landmark loaders):
+    cond_wins [T,smo,win,C], poses [T,4,4] (ngp axes, already smoothed), intrinsics [4], bg_img [H*W,3], H, W.
+    """
+
+    def __init__(self, model, hp: dict, seq: dict, device, frames=None, impl: str = None, pinned_outputs: int = 2):
+        self.model, self.hp, self.device = model, hp, torch.device(device)
+        self.H, self.W = int(seq["H"]), int(seq["W"])
+        self.impl = impl or model.render_impl
+        idx = np.arange(len(seq["poses"])) if frames is None else np.arange(frames[0], frames[1])
+        self.frame_ids = idx
+        dev = self.device
+        self.cond_wins = torch.from_numpy(np.ascontiguousarray(seq["cond_wins"][idx])).float().to(dev)
+        self.poses = torch.from_numpy(np.ascontiguousarray(seq["poses"][idx])).float().to(dev)
+        self.pose6 = utils.convert_poses(self.poses)
+        self.intrinsics = [float(v) for v in seq["intrinsics"]]
+        self.bg = torch.from_numpy(np.ascontiguousarray(seq["bg_img"])).float().view(1, -1, 3).to(dev)
+        self.bg_coords = utils.get_bg_coords(self.H, self.W, dev)
+        self._pinned = [torch.empty(self.H, self.W, 3, dtype=torch.uint8).pin_memory() for _ in range(pinned_outputs)] \
+            if dev.type == "cuda" else [torch.empty(self.H, self.W, 3, dtype=torch.uint8)]
+        self._events = [None] * len(self._pinned)
+        self._slot = 0
+
+    def __len__(self):
+        return len(self.frame_ids)
+
+    def sample(self, i: int) -> dict:
+        """The `sample` dict tasks/radnerfs/radnerf.py:119-126 reads (rays materialised, like the reference's dataset)."""
+        rays = utils.get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
+        return {"cond_wins": self.cond_wins[i], "rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "bg_coords": self.bg_coords,
+                "pose": self.pose6[i:i + 1], "idx": int(self.frame_ids[i]), "bg_img": self.bg, "H": self.H, "W": self.W}
+
+    def run_model(self, sample: dict) -> dict:
+        """RADNeRF(Torso)Task.run_model(sample, infer=True) (tasks/radnerfs/radnerf.py:166-170, radnerf_torso.py:113-117)."""
+        bg = sample["bg_torso_img"] if ("bg_torso_img" in sample and not hasattr(self.model, "forward_torso")) else sample["bg_img"]
+        return self.model.render(sample["rays_o"], sample["rays_d"], sample["cond_wins"], sample["bg_coords"], sample["pose"],
+                                 index=sample["idx"], staged=False, bg_color=bg, perturb=False, force_all_rays=True,
+                                 render_impl=self.impl, **self.hp)
+
+    def render_frame(self, i: int) -> torch.Tensor:
+        """One step of the frame loop: returns the pinned-host uint8 [H,W,3] RGB frame (valid after `wait(slot)` /
+        a stream sync; double-buffered so the D2H copy of frame i overlaps the kernels of frame i+1)."""
+        if self.impl == "fused":
+            from .fused import render_frame_fused
+            rgb8 = render_frame_fused(self, i)
+        else:
+            out = self.run_model(self.sample(i))
+            rgb8 = (out["rgb_map"] * 255).view(self.H, self.W, 3).to(torch.uint8)
+        slot = self._slot
+        self._slot = (slot + 1) % len(self._pinned)
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()
+        self._pinned[slot].copy_(rgb8, non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[slot] = ev
+        return self._pinned[slot]

@@ -1,0 +1,171 @@
+"""-m gpu: every stand-alone HIP operator against the CPU oracle, called through the C ABI
+(geneface_amd.compat modules -> ctypes -> libgeneface_hip.so)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+from helpers import frame_inputs, model_fixture, sequence
+from oracle import kernels as K
+from oracle import radnerf_ref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return np.load(os.path.join(GOLD, "ops.npz"))
+
+
+def test_extension_is_loaded_and_sees_the_gpu(hip_lib):
+    assert hip_lib.gf_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libgeneface_hip.so" in maps
+
+
+@pytest.mark.parametrize("D,enc,interp", GI.GRID_CASES)
+def test_grid_encoder_vs_golden_and_oracle(ops, D, enc, interp):
+    from geneface_amd.encoders import get_encoder
+    tag, x, table, off = GI.grid_case(D, enc, interp)
+    m, out_dim = get_encoder(enc, input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16,
+                             desired_resolution=2048, interpolation=interp)
+    assert out_dim == 32 and np.array_equal(m.offsets.numpy(), off)
+    m.embeddings.data.copy_(torch.from_numpy(table))
+    m = m.to(DEV)
+    y = m(torch.from_numpy(x).to(DEV), bound=1).cpu().numpy()
+    gold = ops[tag + "_y"]
+    assert y.shape == gold.shape
+    assert np.abs(y - gold).max() < 2e-6, np.abs(y - gold).max()   # fp32, fma vs mul+add ordering only
+    assert np.array_equal(y == 0, gold == 0)                         # out-of-range rows are exact zeros
+
+
+def test_grid_encoder_large_random_vs_oracle():
+    """1 M random points through the seam layout [L,B,C] (3-D tiled, the head's position grid)."""
+    from geneface_amd.compat import _gridencoder
+    hp, sd = model_fixture(False)
+    B = 1 << 20
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, generator=g)
+    emb, off = sd["position_embedder.embeddings"], sd["position_embedder.offsets"]
+    S = float(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    out_ref = torch.empty(16, B, 2)
+    K.gridencoder.grid_encode_forward(x, emb, off, out_ref, B, 3, 2, 16, S, 16, None, 1, False, 0)
+    out = torch.empty(16, B, 2, device=DEV)
+    _gridencoder.grid_encode_forward(x.to(DEV), emb.to(DEV), off.to(DEV), out, B, 3, 2, 16, S, 16, None, 1, False, 0)
+    err = (out.cpu() - out_ref).abs().max().item()
+    assert err < 1e-5, err
+
+
+def test_grid_dy_dx_vs_oracle():
+    from geneface_amd.compat import _gridencoder
+    tag, x, table, off = GI.grid_case(3, "hashgrid", "smoothstep")
+    B = x.shape[0]
+    x01 = torch.from_numpy((x + 1) / 2)
+    S = float(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    o_ref, d_ref = torch.empty(16, B, 2), torch.empty(B, 16 * 3 * 2)
+    K.gridencoder.grid_encode_forward(x01, torch.from_numpy(table), torch.from_numpy(off), o_ref, B, 3, 2, 16, S, 16, d_ref, 0, False, 1)
+    o, d = torch.empty(16, B, 2, device=DEV), torch.empty(B, 96, device=DEV)
+    _gridencoder.grid_encode_forward(x01.to(DEV), torch.from_numpy(table).to(DEV), torch.from_numpy(off).to(DEV), o, B, 3, 2, 16, S, 16, d,
+                                     0, False, 1)
+    assert (o.cpu() - o_ref).abs().max() < 2e-6
+    scale = d_ref.abs().max().item()
+    assert (d.cpu() - d_ref).abs().max() < 1e-5 * max(scale, 1.0)
+
+
+def test_sh_and_freq_vs_golden(ops):
+    from geneface_amd.encoders import get_encoder
+    sh, n = get_encoder("spherical_harmonics")
+    y = sh(torch.from_numpy(GI.sh_dirs()).to(DEV)).cpu().numpy()
+    assert n == 16 and np.abs(y - ops["sh_y"]).max() < 1e-6
+    for dim, deg in ((6, 4), (2, 10)):
+        fe, c = get_encoder("frequency", input_dim=dim, multires=deg)
+        y = fe(torch.from_numpy(GI.freq_case(dim, deg)).to(DEV)).cpu().numpy()
+        assert c == dim + 2 * dim * deg
+        assert np.abs(y - ops[f"freq_{dim}_{deg}_y"]).max() < 2e-5  # |arg| up to 2^9: fp32 range reduction
+
+
+def test_unsupported_arguments_raise_like_the_reference():
+    from geneface_amd.compat import _gridencoder, _shencoder
+    x = torch.rand(8, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        _gridencoder.grid_encode_forward(x, torch.rand(64, 3, device=DEV), torch.tensor([0, 64], dtype=torch.int32, device=DEV),
+                                         torch.empty(1, 8, 3, device=DEV), 8, 3, 3, 1, 0.5, 16, None, 1, False, 0)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        _shencoder.sh_encode_forward(torch.rand(8, 3), torch.empty(8, 16, device=DEV), 8, 3, 4, None)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        _shencoder.sh_encode_forward(torch.rand(3, 8, device=DEV).t(), torch.empty(8, 16, device=DEV), 8, 3, 4, None)
+
+
+def test_near_far_march_composite_bit_exact(ops):
+    """Integer/discrete outputs of the marcher (which samples exist, their positions and t) must be identical."""
+    from geneface_amd import raymarching as rm
+    hp, sd = model_fixture(False)
+    ro, rd = torch.from_numpy(ops["rays_o"]).to(DEV), torch.from_numpy(ops["rays_d"]).to(DEV)
+    nears, fars = rm.near_far_from_aabb(ro, rd, sd["aabb_infer"].to(DEV), hp["min_near"])
+    assert np.array_equal(nears.cpu().numpy(), ops["march_nears"]) and np.array_equal(fars.cpu().numpy(), ops["march_fars"])
+    N = ro.shape[0]
+    alive = torch.arange(N, dtype=torch.int32, device=DEV)
+    rays_t = nears.clone()
+    bits = sd["density_bitfield"].to(DEV)
+    xyzs, dirs, deltas = rm.march_rays(N, 3, alive, rays_t, ro, rd, 1.0, bits, 1, 128, nears, fars, 128, False, hp["dt_gamma"], hp["max_steps"])
+    assert np.array_equal(xyzs.cpu().numpy(), ops["march_xyzs"])
+    assert np.array_equal(deltas.cpu().numpy(), ops["march_deltas"])
+    sig, rgb = (torch.from_numpy(a).to(DEV) for a in GI.composite_inputs(xyzs.shape[0]))
+    ws, dep, img = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV), torch.zeros(N, 3, device=DEV)
+    rm.composite_rays(N, 3, alive, rays_t, sig, rgb, deltas, ws, dep, img, 1e-4)
+    assert np.array_equal(alive.cpu().numpy(), ops["comp_alive"])            # who terminated: exact
+    assert np.array_equal(rays_t.cpu().numpy(), ops["comp_rays_t"])          # copied t values: exact
+    assert np.abs(ws.cpu().numpy() - ops["comp_ws"]).max() < 2e-6            # __expf vs expf
+    assert np.abs(dep.cpu().numpy() - ops["comp_depth"]).max() < 1e-5
+    assert np.abs(img.cpu().numpy() - ops["comp_image"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("size,n_step", [(64, 1), (128, 2), (512, 8)])
+def test_march_full_image_bit_exact(size, n_step):
+    from geneface_amd import raymarching as rm
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, size, size), 2)
+    ro, rd = fi["rays_o"].view(-1, 3), fi["rays_d"].view(-1, 3)
+    nears, fars = R.near_far_from_aabb(ro, rd, sd["aabb_infer"], hp["min_near"])
+    N = ro.shape[0]
+    alive = torch.arange(N, dtype=torch.int32)
+    xr, dr, der = R.march_rays(N, n_step, alive, nears.clone(), ro, rd, 1.0, sd["density_bitfield"], 1, 128, nears, fars, 128,
+                               hp["dt_gamma"], hp["max_steps"])
+    n_g, f_g = rm.near_far_from_aabb(ro.to(DEV), rd.to(DEV), sd["aabb_infer"].to(DEV), hp["min_near"])
+    assert torch.equal(n_g.cpu(), nears) and torch.equal(f_g.cpu(), fars)
+    xg, dg, deg = rm.march_rays(N, n_step, alive.to(DEV), n_g.clone(), ro.to(DEV), rd.to(DEV), 1.0, sd["density_bitfield"].to(DEV), 1, 128,
+                                n_g, f_g, 128, False, hp["dt_gamma"], hp["max_steps"])
+    assert torch.equal(xg.cpu(), xr) and torch.equal(deg.cpu(), der) and torch.equal(dg.cpu(), dr)
+    assert int((der[:, 0] > 0).sum()) > 0
+
+
+def test_grid_maintenance_ops_bit_exact():
+    from geneface_amd import raymarching as rm
+    g = torch.Generator().manual_seed(9)
+    coords = torch.randint(0, 128, (5000, 3), generator=g, dtype=torch.int32)
+    idx_ref = torch.empty(5000, dtype=torch.int32)
+    K.raymarching_face.morton3D(coords, 5000, idx_ref)
+    idx = rm.morton3D(coords.to(DEV))
+    assert torch.equal(idx.cpu(), idx_ref)
+    assert torch.equal(rm.morton3D_invert(idx).cpu(), coords)
+    grid = torch.rand(1, 64 ** 3, generator=g) * 20 - 1
+    bits_ref = torch.empty(64 ** 3 // 8, dtype=torch.uint8)
+    K.raymarching_face.packbits(grid, 64 ** 3 // 8, 10.0, bits_ref)
+    assert torch.equal(rm.packbits(grid.to(DEV), 10.0).cpu(), bits_ref)
+    dil_ref = torch.empty_like(grid)
+    K.raymarching_face.morton3D_dilation(grid, 1, 64, dil_ref)
+    assert torch.equal(rm.morton3D_dilation(grid.to(DEV)).cpu(), dil_ref)
+
+
+def test_empty_inputs_are_noops():
+    from geneface_amd import raymarching as rm
+    from geneface_amd.encoders import get_encoder
+    z = torch.zeros(0, 3, device=DEV)
+    n, f = rm.near_far_from_aabb(z, z, torch.tensor([-1, -.5, -1, 1, .5, 1.], device=DEV), 0.05)
+    assert n.numel() == 0 and f.numel() == 0
+    sh, _ = get_encoder("spherical_harmonics")
+    assert sh(z).shape == (0, 16)

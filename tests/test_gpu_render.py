@@ -1,0 +1,101 @@
+"""-m gpu: whole frames through the reference-compatible module API against the oracle and the golden frames."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import frame_inputs, model_fixture, psnr, sequence
+from oracle import radnerf_ref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+# fp32 everywhere; what differs from the oracle is summation order inside the MLPs (MFMA / rocBLAS vs
+# MKL) and __expf, amplified by exp(h) of the density head.  Strict tolerance of BASELINE.md section 4,
+# widened where the amplification is visible, plus a PSNR floor far above the 40 dB "fast" bar.
+RGB_ATOL = 5e-4
+PSNR_MIN = 65.0
+
+
+def build(torso, impl):
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd = model_fixture(torso)
+    m = (RADNeRFTorso if torso else RADNeRF)(hp)
+    m.load_state_dict(sd, strict=True)
+    m.render_impl = impl
+    return hp, sd, m.to(DEV).eval()
+
+
+def render_gpu(model, hp, fi):
+    to = lambda t: t.to(DEV)
+    return model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                        bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+
+
+def check(out, ref, torso):
+    rgb, rgb_ref = out["rgb_map"].cpu(), ref["rgb_map"] if torch.is_tensor(ref["rgb_map"]) else torch.from_numpy(ref["rgb_map"])
+    assert rgb.shape == rgb_ref.shape
+    err = (rgb - rgb_ref).abs().max().item()
+    assert err < RGB_ATOL, err
+    assert psnr(rgb, rgb_ref) > PSNR_MIN
+    u8 = (rgb * 255).to(torch.uint8).int() - (rgb_ref * 255).to(torch.uint8).int()
+    assert (u8.abs() <= 1).float().mean().item() > 0.999
+    dref = ref["depth_map"] if torch.is_tensor(ref["depth_map"]) else torch.from_numpy(ref["depth_map"])
+    assert (out["depth_map"].cpu() - dref).abs().max().item() < 2e-3
+    if torso:
+        for k, tol in (("torso_alpha_map", 2e-5), ("torso_rgb_map", 2e-5)):
+            r = ref[k] if torch.is_tensor(ref[k]) else torch.from_numpy(ref[k])
+            assert (out[k].cpu() - r).abs().max().item() < tol, k
+
+
+@pytest.mark.parametrize("impl", ["ops", "fused"])
+@pytest.mark.parametrize("torso", [False, True])
+@pytest.mark.parametrize("size,idx", [(64, 1), (96, 3)])
+def test_frame_vs_reference_golden(impl, torso, size, idx):
+    hp, sd, model = build(torso, impl)
+    fi = frame_inputs(sequence(4, size, size), idx)
+    out = render_gpu(model, hp, fi)
+    gold = np.load(os.path.join(GOLD, f"frame_{'torso' if torso else 'head'}_{size}.npz"))
+    check(out, gold, torso)
+
+
+@pytest.mark.parametrize("impl", ["ops", "fused"])
+def test_frame_256_vs_oracle(impl):
+    hp, sd, model = build(True, impl)
+    fi = frame_inputs(sequence(4, 256, 256), 0)
+    trace = []
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True, trace=trace)
+    out = render_gpu(model, hp, fi)
+    check(out, ref, True)
+    if hasattr(model, "last_schedule") and model.last_schedule:
+        assert [(a, s) for a, s in model.last_schedule] == [(t["n_alive"], t["n_step"]) for t in trace]  # the n_step schedule: exact
+
+
+def test_field_query_vs_oracle():
+    """RADNeRF.forward / density / cal_cond_feat / forward_torso as stand-alone calls (the GUI and the
+    density-grid update call them directly)."""
+    hp, sd, model = build(True, "ops")
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(5000, 3, generator=g) * 2 - 1) * torch.tensor([0.5, 0.3, 0.5])
+    d = torch.nn.functional.normalize(torch.randn(5000, 3, generator=g), dim=-1)
+    cond = torch.randn(5, 1, 204, generator=g)
+    cf_ref = R.cal_cond_feat(sd, hp, cond)
+    s_ref, c_ref, a_ref = R.head_field(sd, hp, x, d, cf_ref, sd["individual_embeddings"][0])
+    with torch.no_grad():
+        cf = model.cal_cond_feat(cond.to(DEV))
+        assert (cf.cpu() - cf_ref).abs().max() < 1e-5
+        s, c, a = model(x.to(DEV), d.to(DEV), cf_ref.to(DEV), model.individual_embeddings[0])
+        dd = model.density(x.to(DEV), cf_ref.to(DEV))
+    assert (a.cpu() - a_ref).abs().max() < 1e-5
+    assert ((s.cpu() - s_ref).abs() / s_ref.abs().clamp(min=1e-3)).max() < 2e-3   # exp() amplifies 1e-6-level logit noise
+    assert (c.cpu() - c_ref).abs().max() < 1e-4
+    assert torch.equal(dd["sigma"], s) and dd["geo_feat"].shape == (5000, 128)
+    xy = torch.rand(3000, 2, generator=g) * 2 - 1
+    p6 = torch.tensor([[0.1, -0.05, 0.02, 0.0, 3.3, 0.0]])
+    ta_ref, tc_ref, tdx_ref = R.torso_field(sd, hp, xy, p6, sd["torso_individual_codes"][0])
+    with torch.no_grad():
+        ta, tc, tdx = model.forward_torso(xy.to(DEV), p6.to(DEV), model.torso_individual_codes[0])
+    assert (ta.cpu() - ta_ref).abs().max() < 1e-4 and (tc.cpu() - tc_ref).abs().max() < 1e-4 and (tdx.cpu() - tdx_ref).abs().max() < 1e-4
