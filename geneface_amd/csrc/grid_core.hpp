@@ -89,7 +89,7 @@ __device__ __forceinline__ void grid_level_lookup(const float* __restrict__ tabl
     uint32_t pos_grid[D];
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        pos[d] = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pos[d] = __builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
         const float fl = floorf(pos[d]);
         pos_grid[d] = (uint32_t)fl;
         pos[d] -= fl;

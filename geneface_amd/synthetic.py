@@ -28,7 +28,7 @@ from .encoders.gridencoder import grid_offsets
 # log-density has mean ~3.3 / std ~1.2 inside the head (sigma ~ 1..1000: rays saturate after ~5-16 samples),
 # ambient coordinates have std ~0.25, colours and torso alpha are not constant.
 GAINS = {
-    "ambient_net.net.0.weight": 3.3, "ambient_net.net.1.weight": 3.3, "ambient_net.net.2.weight": 3.3,
+    "ambient_net.net.0.weight": 3.0, "ambient_net.net.1.weight": 3.0, "ambient_net.net.2.weight": 3.0,
     "sigma_net.net.0.weight": 2.0, "sigma_net.net.1.weight": 2.0, "sigma_net.net.2.weight": 2.0,
     "color_net.net.0.weight": 2.5, "color_net.net.1.weight": 5.0,
     "torso_deform_net.net.0.weight": 2.0, "torso_deform_net.net.1.weight": 2.0, "torso_deform_net.net.2.weight": 0.5,
@@ -99,8 +99,15 @@ def make_state_dict(hp: dict, torso: bool = True, seed: int = 0) -> "OrderedDict
         sd["cond_att_net.attentionNet.0.bias"] = _uniform("cond_att_net.attentionNet.0.bias", seed, (s,), 1 / math.sqrt(s))
 
     def grid(name, dim, desired):
+        # U(-a_l, a_l) per level with a_l = 2 * (16/res_l)^2: a band-limited signal (coarse levels carry the
+        # amplitude, fine levels only detail) like a trained table.  White noise at the 2048 level would turn 1e-7
+        # of fp32 rounding in a coordinate into 1e-2 of feature change and make every parity tolerance meaningless.
         off = grid_offsets(dim, 16, 16, hp["log2_hashmap_size"], desired)
-        sd[name + ".embeddings"] = _uniform(name + ".embeddings", seed, (int(off[-1]), 2), 0.5)
+        pls = np.exp2(np.log2(desired / 16) / 15)
+        table = _uniform(name + ".embeddings", seed, (int(off[-1]), 2), 2.0)
+        for l in range(16):
+            table[off[l]:off[l + 1]] *= np.float32((16.0 / np.ceil(16 * pls ** l)) ** 2)
+        sd[name + ".embeddings"] = table
         sd[name + ".offsets"] = off
 
     def mlp(name, din, dout, dh, nl):

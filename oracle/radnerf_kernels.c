@@ -20,9 +20,11 @@
  *
  * Floating point: compiled with -ffp-contract=off.  nvcc's default --fmad=true
  * fuses a*b+c; the only place where that can change a *discrete* decision is the
- * marcher's position  o + t*d  (it selects the occupancy voxel), so that one
- * expression is written as an explicit fmaf() here and in the HIP kernel.  All
- * other expressions are evaluated unfused, in the reference's association order.
+ * marcher's position  o + t*d  (it selects the occupancy voxel); the only place where
+ * it is visible above rounding noise is the grid encoder's  x*scale + 0.5  (a large
+ * intermediate).  Those two expressions are written as explicit fmaf() here and in the
+ * HIP kernels.  All other expressions are evaluated unfused, in the reference's
+ * association order.
  */
 #include <math.h>
 #include <stdint.h>
@@ -317,7 +319,9 @@ ORC_EXPORT int orc_grid_encode_forward(const float* inputs_, const float* embedd
             float pos[ORC_MAX_D], pos_deriv[ORC_MAX_D];
             uint32_t pos_grid[ORC_MAX_D];
             for (uint32_t d = 0; d < D; d++) {
-                pos[d] = inputs[d] * scale + (align_corners ? 0.0f : 0.5f);
+                /* nvcc --fmad=true fuses x*scale+0.5; pos reaches ~2^11 on the finest level, so fused and unfused
+                 * differ by one ulp(pos) ~ 1e-4 of a cell -- visible in the output.  Restated as the fused form. */
+                pos[d] = fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f);
                 pos_grid[d] = (uint32_t)floorf(pos[d]);
                 pos[d] -= (float)pos_grid[d];
                 if (interp == 1) {

@@ -71,7 +71,11 @@ def test_frame_256_vs_oracle(impl):
     out = render_gpu(model, hp, fi)
     check(out, ref, True)
     if hasattr(model, "last_schedule") and model.last_schedule:
-        assert [(a, s) for a, s in model.last_schedule] == [(t["n_alive"], t["n_step"]) for t in trace]  # the n_step schedule: exact
+        # the n_step schedule is a discrete function of the alive counts: it must be identical; the counts themselves may
+        # differ by the few rays whose transmittance sits within rounding of T_thresh when an iteration ends
+        assert [s for _, s in model.last_schedule] == [t["n_step"] for t in trace]
+        for (a, _), t in zip(model.last_schedule, trace):
+            assert abs(a - t["n_alive"]) <= max(3, 1e-3 * t["n_alive"]), (a, t["n_alive"])
 
 
 def test_field_query_vs_oracle():
