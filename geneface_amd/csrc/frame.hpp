@@ -1,0 +1,75 @@
+// Workspace carve-out and packed-weight layouts of the fused frame kernels (gf_frame_t itself is declared in
+// include/geneface_hip.h).
+#pragma once
+#include <stdint.h>
+
+#include "geneface_hip.h"  // gf_frame_t
+
+namespace gf {
+
+// ---------------- workspace carve-out (all offsets in bytes, 256-aligned) ----------------
+struct FrameWs {
+    float *nears, *fars, *rays_t, *weights_sum, *depth, *image, *rays_o, *rays_d;
+    int32_t *alive_a, *alive_b;
+    uint32_t* ctrl;  // [kCtrlWords]
+    size_t bytes;
+};
+constexpr uint32_t kMaxIters = 64;
+// ctrl layout: [0..kMaxIters] n_alive per iteration, [kMaxIters+1 .. 2*kMaxIters+1] cumulative step per iteration,
+// then statistics: valid samples per iteration.
+constexpr uint32_t kCtrlAlive = 0, kCtrlStep = kMaxIters + 1, kCtrlValid = 2 * (kMaxIters + 1), kCtrlWords = 3 * (kMaxIters + 1) + 8;
+
+inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
+    FrameWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return (char*)base + o; };
+    const size_t N = n_rays;
+    w.nears = (float*)take(N * 4);
+    w.fars = (float*)take(N * 4);
+    w.rays_t = (float*)take(N * 4);
+    w.weights_sum = (float*)take(N * 4);
+    w.depth = (float*)take(N * 4);
+    w.image = (float*)take(N * 12);
+    w.rays_o = (float*)take(N * 12);
+    w.rays_d = (float*)take(N * 12);
+    w.alive_a = (int32_t*)take(N * 4);
+    w.alive_b = (int32_t*)take(N * 4);
+    w.ctrl = (uint32_t*)take(kCtrlWords * 4);
+    w.bytes = off;
+    return w;
+}
+
+// ---------------- packed head weights (floats) ----------------
+// "big" chunks are MFMA A-operand streams: [out_block(4)][step/4][lane(64)][step%4], value =
+//   W[out_block*32 + (lane&31)][kmap(step, lane>>5)]   (see pack_head.cpp for every kmap)
+constexpr uint32_t kHidden = 128;
+constexpr uint32_t HP_AMB1 = 0;                         // K=32  (3-D grid features)      4*16*64
+constexpr uint32_t HP_AMB2 = HP_AMB1 + 4 * 16 * 64;     // K=128                          4*64*64
+constexpr uint32_t HP_SIG1 = HP_AMB2 + 4 * 64 * 64;     // K=64  (3-D | 2-D grid)         4*32*64
+constexpr uint32_t HP_SIG2 = HP_SIG1 + 4 * 32 * 64;     // K=128
+constexpr uint32_t HP_SIG3 = HP_SIG2 + 4 * 64 * 64;     // K=128 -> geo features (rows 1..128)
+constexpr uint32_t HP_COL1S = HP_SIG3 + 4 * 64 * 64;    // K=16  (SH part of colour L1)   4*8*64
+constexpr uint32_t HP_COL1G = HP_COL1S + 4 * 8 * 64;    // K=128 (geo part of colour L1)
+constexpr uint32_t HP_SMALL = HP_COL1G + 4 * 64 * 64;   // VALU layers + constant bias
+//   small block: rows in "C-layout order" [out_block(4)][half(2)][r(16)] = feature ob*32 + R0(r) + 4*half
+constexpr uint32_t HS_AMB3 = 0;        // [2][128]
+constexpr uint32_t HS_SIGROW = 256;    // [128]   density row (row 0 of sigma L3)
+constexpr uint32_t HS_COL2 = 384;      // [3][128]
+constexpr uint32_t HS_COLBIAS = 768;   // [128]   W_color0[:, 144:148] @ individual_code, C-layout order
+constexpr uint32_t HS_TOTAL = 896;
+constexpr uint32_t HP_TOTAL = HP_SMALL + HS_TOTAL;
+
+// ---------------- packed torso weights (floats) ----------------
+// MFMA streams as above with NOB out-blocks.  Frequency-encoded pixel coordinate enc(x) has 42 entries, padded to 48:
+// lane half h supplies enc index 24h + t (t < 24; indices >= 42 are zero on both sides).
+constexpr uint32_t TP_D1 = 0;                        // deform L1, enc(x) columns: NOB=2, 24 steps
+constexpr uint32_t TP_D2 = TP_D1 + 2 * 24 * 64;      // deform L2 (64->64): NOB=2, 32 steps
+constexpr uint32_t TP_C1 = TP_D2 + 2 * 32 * 64;      // canonical L1, [2-D grid 32 | enc(x) 48]: NOB=1, 16 + 24 steps
+constexpr uint32_t TP_C2 = TP_C1 + 1 * 40 * 64;      // canonical L2 (32->32): NOB=1, 16 steps
+constexpr uint32_t TP_D3 = TP_C2 + 1 * 16 * 64;      // VALU rows [2][64]  (accumulator-layout order)
+constexpr uint32_t TP_C3 = TP_D3 + 2 * 64;           // VALU rows [4][32]
+constexpr uint32_t TP_TOTAL = TP_C3 + 4 * 32;
+// per-frame torso bias vector: [64 deform L1 | 32 canonical L1], accumulator-layout order
+constexpr uint32_t TB_TOTAL = 96;
+
+}  // namespace gf

@@ -1,0 +1,195 @@
+// Torso pass + final composite of one RAD-NeRF frame (gfx950): per pixel, sample the 2-D torso occupancy, evaluate
+// the deformable 2-D torso field for the masked pixels on f32 MFMA, blend torso over background and the marched head
+// over that, clamp, normalise depth, optionally emit uint8.
+//
+// Replaces RADNeRFTorso.render's tail (/root/reference/modules/radnerfs/radnerf_torso.py:156-198) and forward_torso
+// (:51-84): grid_sample + boolean-mask gather/scatter (host sync on mask.any()), 2 freq encodes, 6 GEMMs, a grid
+// encode, cats/sigmoids and five elementwise blends -- ~25 launches -- become one kernel.
+// A 256-thread workgroup owns 256 consecutive pixels; masked ones are packed densely and processed as 32-pixel MFMA
+// tiles (same register-chained layer scheme as the head, mfma_mlp.hpp); all torso weights (44 KB) stay LDS-resident.
+#include "common.hpp"
+#include "frame.hpp"
+#include "grid_core.hpp"
+#include "mfma_mlp.hpp"
+
+namespace {
+
+using gf::floatx16;
+constexpr int kThreads = 256;
+
+struct TorsoArgs {
+    uint32_t N, G;
+    const float *image, *weights_sum, *depth, *nears, *fars;  // head accumulators (workspace)
+    const float *bg_coords, *bg, *occ;
+    float thresh, shrink;
+    const float *pack, *bias, *table; const int* offsets;
+    gf::GridLevels lv;
+    float *out_rgb, *out_depth, *out_alpha, *out_torso_rgb, *out_deform; uint8_t* out_rgb8;
+};
+
+// F.grid_sample(input[1,1,G,G], grid[..., (x,y)], bilinear, zeros padding, align_corners=True) at one location:
+// x indexes the last axis, y the one before it.
+__device__ __forceinline__ float sample_occ(const float* __restrict__ occ, int G, float x, float y) {
+    const float ix = ((x + 1.0f) / 2.0f) * (float)(G - 1), iy = ((y + 1.0f) / 2.0f) * (float)(G - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.0f) - ix, wy0 = (fy + 1.0f) - iy;
+    auto at = [&](int xx, int yy) { return (xx >= 0 && xx < G && yy >= 0 && yy < G) ? occ[yy * G + xx] : 0.0f; };
+    float out = at(x0, y0) * (wx0 * wy0);
+    out += at(x1, y0) * (wx1 * wy0);
+    out += at(x0, y1) * (wx0 * wy1);
+    out += at(x1, y1) * (wx1 * wy1);
+    return out;
+}
+
+// entry e (0..47) of the zero-padded frequency encoding of a 2-vector (42 real entries, freqencoder.cu:30-58 layout)
+__device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
+    if (e >= 42) return 0.0f;
+    if (e < 2) return e ? x1 : x0;
+    const int col = e / 2 - 1, d = e & 1, freq = col >> 1;
+    const float phase = (col & 1) ? (3.141592653589793f / 2) : 0.0f;
+    return sinf(scalbnf(d ? x1 : x0, freq) + phase);
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* pack = reinterpret_cast<float*>(smem_raw);   // [TP_TOTAL]
+    float* bias = pack + gf::TP_TOTAL;                  // [TB_TOTAL]
+    float* meta = bias + gf::TB_TOTAL;                  // [64]
+    float* o_a = meta + 64;                             // [256] per local pixel: alpha, r, g, b, dx0, dx1
+    float* o_r = o_a + kThreads; float* o_g = o_r + kThreads; float* o_b = o_g + kThreads;
+    float* o_dx = o_b + kThreads; float* o_dy = o_dx + kThreads;
+    uint32_t* d2p = reinterpret_cast<uint32_t*>(o_dy + kThreads);  // [256] dense -> local pixel
+    uint32_t* wcnt = d2p + kThreads;                               // [8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const uint32_t n = blockIdx.x * kThreads + tid;
+    const bool in_img = n < a.N;
+
+    float cx = 0.0f, cy = 0.0f;
+    bool masked = false;
+    if (in_img) {
+        cx = a.bg_coords[(size_t)n * 2];
+        cy = a.bg_coords[(size_t)n * 2 + 1];
+        masked = sample_occ(a.occ, (int)a.G, cx, cy) > a.thresh;
+    }
+    // dense packing of the masked pixels of this workgroup (pixel order preserved)
+    const unsigned long long bal = __ballot(masked);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+    o_a[tid] = 0.0f; o_r[tid] = 0.0f; o_g[tid] = 0.0f; o_b[tid] = 0.0f;
+    __syncthreads();
+    uint32_t wbase = 0, Mt = 0;
+    for (int w = 0; w < kThreads / 64; w++) { const uint32_t c = wcnt[w]; if (w < wave) wbase += c; Mt += c; }
+    if (masked) d2p[wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)tid;
+
+    if (Mt > 0) {  // workgroup-uniform
+        for (int i = tid; i < (int)gf::TP_TOTAL / 4; i += kThreads) reinterpret_cast<float4*>(pack)[i] = reinterpret_cast<const float4*>(a.pack)[i];
+        if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
+        if (tid < 16) {
+            meta[tid * 4 + 0] = a.lv.scale[tid];
+            meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
+            meta[tid * 4 + 2] = __uint_as_float((uint32_t)a.offsets[tid]);
+            meta[tid * 4 + 3] = __uint_as_float((uint32_t)(a.offsets[tid + 1] - a.offsets[tid]));
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < Mt; base += 128) {
+            const uint32_t tile0 = base + wave * 32;
+            if (tile0 >= Mt) continue;  // wave-uniform; no barriers inside the tile body
+            const uint32_t j = tile0 + (lane & 31);
+            const bool valid = j < Mt;
+            const uint32_t p = valid ? d2p[j] : d2p[tile0];
+            const uint32_t pix = blockIdx.x * kThreads + p;
+            const float x0 = a.bg_coords[(size_t)pix * 2] * a.shrink, x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
+
+            float enc[24];
+#pragma unroll
+            for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
+
+            floatx16 h2[2];
+            float act2[32];
+            gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+            gf::unpack<2>(h2, act2);
+            gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
+            gf::unpack<2>(h2, act2);
+            float dx[2];
+            gf::valu_rows<2, 2>(pack + gf::TP_D3, half, act2, dx);
+
+            const float xc[2] = {(fminf(fmaxf(x0 + dx[0], -1.0f), 1.0f) + 1.0f) / 2.0f, (fminf(fmaxf(x1 + dx[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
+            float in[40];
+            {
+                float g[16];
+                gf::encode_half<2>(a.table, meta, half, 1u /*tiled*/, 0u /*linear*/, xc, g);
+#pragma unroll
+                for (int t = 0; t < 16; t++) in[t] = g[t];
+#pragma unroll
+                for (int t = 0; t < 24; t++) in[16 + t] = enc[t];
+            }
+            floatx16 h1[1];
+            float act1[16];
+            gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+            gf::unpack<1>(h1, act1);
+            gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
+            gf::unpack<1>(h1, act1);
+            float o4[4];
+            gf::valu_rows<4, 1>(pack + gf::TP_C3, half, act1, o4);
+            if (valid && half == 0) {
+                o_a[p] = 1.0f / (1.0f + __expf(-o4[0]));
+                o_r[p] = 1.0f / (1.0f + __expf(-o4[1]));
+                o_g[p] = 1.0f / (1.0f + __expf(-o4[2]));
+                o_b[p] = 1.0f / (1.0f + __expf(-o4[3]));
+                o_dx[p] = dx[0];
+                o_dy[p] = dx[1];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!in_img) return;
+    // radnerf_torso.py:186-193: torso over background, head over that, clamp, depth normalisation
+    const float alpha = o_a[tid];
+    const float tc[3] = {o_r[tid], o_g[tid], o_b[tid]};
+    const float ws = a.weights_sum[n];
+    if (a.out_alpha) a.out_alpha[n] = alpha;
+    if (a.out_deform && masked) { a.out_deform[(size_t)n * 2] = o_dx[tid]; a.out_deform[(size_t)n * 2 + 1] = o_dy[tid]; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float bgc = tc[c] * alpha + a.bg[(size_t)n * 3 + c] * (1 - alpha);
+        if (a.out_torso_rgb) a.out_torso_rgb[(size_t)n * 3 + c] = bgc;
+        float v = a.image[(size_t)n * 3 + c] + (1 - ws) * bgc;
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        a.out_rgb[(size_t)n * 3 + c] = v;
+        if (a.out_rgb8) a.out_rgb8[(size_t)n * 3 + c] = (uint8_t)(v * 255.0f);
+    }
+    a.out_depth[n] = fmaxf(a.depth[n] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+}
+
+constexpr size_t kTorsoSmem = (gf::TP_TOTAL + gf::TB_TOTAL + 64 + 6 * kThreads + kThreads + 8) * sizeof(float);
+
+}  // namespace
+
+// Torso pass + final blend.  Requires gf_render_head(f, stream) to have been enqueued before on the same stream
+// (it reads the head accumulators from the workspace).
+GF_EXPORT int gf_render_torso(const gf_frame_t* f, void* stream) {
+    if (!f || !f->workspace) return gf_set_error(GF_ERR_INVALID, "torso: null descriptor / workspace");
+    if (!f->torso_pack || !f->torso_bias || !f->torso_table || !f->torso_offsets || !f->torso_occ || !f->bg_coords || !f->bg_color ||
+        !f->out_rgb || !f->out_depth)
+        return gf_set_error(GF_ERR_INVALID, "torso: null pointer in the torso description");
+    const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
+    TorsoArgs a;
+    a.N = f->n_rays; a.G = f->grid_size;
+    a.image = w.image; a.weights_sum = w.weights_sum; a.depth = w.depth; a.nears = w.nears; a.fars = w.fars;
+    a.bg_coords = f->bg_coords; a.bg = f->bg_color; a.occ = f->torso_occ;
+    a.thresh = f->torso_thresh; a.shrink = f->torso_shrink;
+    a.pack = f->torso_pack; a.bias = f->torso_bias; a.table = f->torso_table; a.offsets = f->torso_offsets;
+    if (gf::fill_grid_levels(a.lv, 16, f->torso_S, f->base_res)) return gf_set_error(GF_ERR_INVALID, "torso: bad grid levels");
+    a.out_rgb = f->out_rgb; a.out_depth = f->out_depth; a.out_alpha = f->out_torso_alpha; a.out_torso_rgb = f->out_torso_rgb;
+    a.out_deform = f->out_deform; a.out_rgb8 = f->out_rgb8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_torso_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTorsoSmem) != hipSuccess)
+            return gf_set_error(GF_ERR_HIP, "torso: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_torso_finish, dim3(gf_div_up(f->n_rays, (uint32_t)kThreads)), dim3(kThreads), kTorsoSmem, gf_stream(stream), a);
+    return gf_check_launch("render_torso");
+}

@@ -146,4 +146,24 @@ __device__ __forceinline__ void grid_level_lookup(const float* __restrict__ tabl
     }
 }
 
+// Fused-kernel form: the two 32-lane halves of a wave split a 16-level grid; this lane evaluates levels 8*half .. 8*half+7
+// at point x (already mapped to [0,1]) -> f[16] = [level][channel].  meta = LDS table of float4 {scale, resolution, row offset,
+// rows} per level (the integer fields bit-cast).
+template <uint32_t D>
+__device__ __forceinline__ void encode_half(const float* __restrict__ table, const float* __restrict__ meta, int half,
+                                            uint32_t gridtype, uint32_t interp, const float (&x)[D], float (&f)[16]) {
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const float4 m = reinterpret_cast<const float4*>(meta)[half * 8 + l];
+        float o[2];
+        grid_level_lookup<D, 2>(table + (size_t)__float_as_uint(m.z) * 2, __float_as_uint(m.w), m.x, __float_as_uint(m.y),
+                                    gridtype, false, interp, x, o, nullptr);
+        f[l * 2 + 0] = oob ? 0.0f : o[0];
+        f[l * 2 + 1] = oob ? 0.0f : o[1];
+    }
+}
+
 }  // namespace gf

@@ -1,0 +1,115 @@
+// Host-side weight packing for the fused field kernels: turns the reference's nn.Linear weights
+// (row-major [out][in], modules/radnerfs/cond_encoder.py:92-111; layer shapes radnerf.py:44,53,59 and
+// radnerf_torso.py:48-49) into the streams frame_head.hip / frame_torso.hip consume.  Pure host code.
+#include "common.hpp"
+#include "frame.hpp"
+#include <string.h>
+
+namespace {
+
+// MFMA 32x32 accumulator row held by (register r, lane half h): the "C-layout" feature order
+inline uint32_t c_row(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
+
+// Emit one A-operand stream: for out_block ob, step t, lane l  ->  W[ob*32 + (l&31)][col(t, l>>5)]
+template <typename ColFn>
+void emit_stream(float* dst, const float* W, uint32_t ld, uint32_t row0, uint32_t nsteps, ColFn col) {
+    for (uint32_t ob = 0; ob < 4; ob++)
+        for (uint32_t t = 0; t < nsteps; t++)
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t row = row0 + ob * 32 + (l & 31u);
+                dst[((ob * (nsteps / 4) + t / 4) * 64 + l) * 4 + (t & 3u)] = W[(size_t)row * ld + col(t, l >> 5)];
+            }
+}
+
+// hidden -> hidden: step t = ob_in*16 + r consumes C-layout feature ob_in*32 + c_row(r, half)
+inline uint32_t hidden_col(uint32_t t, uint32_t h) { return (t / 16) * 32 + c_row(t % 16, h); }
+
+void emit_valu_rows(float* dst, const float* W, uint32_t ld, uint32_t row, uint32_t col0) {
+    for (uint32_t ob = 0; ob < 4; ob++)
+        for (uint32_t h = 0; h < 2; h++)
+            for (uint32_t r = 0; r < 16; r++) dst[ob * 32 + h * 16 + r] = W[(size_t)row * ld + col0 + ob * 32 + c_row(r, h)];
+}
+
+}  // namespace
+
+GF_EXPORT uint32_t gf_head_pack_floats(void) { return gf::HP_TOTAL; }
+GF_EXPORT uint32_t gf_torso_pack_floats(void) { return gf::TP_TOTAL; }
+
+// perm[i] (i = ob*32 + half*16 + r) = feature index ob*32 + c_row(r, half): the order in which per-frame bias
+// vectors (amb_bias) must be handed to the kernels.
+GF_EXPORT int gf_clayout_perm(uint32_t* perm128_host) {
+    for (uint32_t ob = 0; ob < 4; ob++)
+        for (uint32_t h = 0; h < 2; h++)
+            for (uint32_t r = 0; r < 16; r++) perm128_host[ob * 32 + h * 16 + r] = ob * 32 + c_row(r, h);
+    return GF_OK;
+}
+
+// All pointers are HOST pointers.  Shapes (May config, asserted by the Python side):
+//   amb0 [128,96] amb1 [128,128] amb2 [2,128] | sig0 [128,64] sig1 [128,128] sig2 [129,128] | col0 [128,148] col1 [3,128]
+//   ind_code [4] or NULL.   out [gf_head_pack_floats()]
+GF_EXPORT int gf_head_pack(const float* amb0, const float* amb1, const float* amb2, const float* sig0, const float* sig1,
+                           const float* sig2, const float* col0, const float* col1, const float* ind_code, float* out) {
+    using namespace gf;
+    if (!amb0 || !amb1 || !amb2 || !sig0 || !sig1 || !sig2 || !col0 || !col1 || !out) return gf_set_error(GF_ERR_INVALID, "head_pack: null pointer");
+    memset(out, 0, sizeof(float) * HP_TOTAL);
+    // ambient L1: only the 32 grid columns go through MFMA (the 64 cond columns fold into amb_bias per frame).
+    // step t: lane half h supplies grid feature 16h + t  (levels 8h .. 8h+7, two channels each)
+    emit_stream(out + HP_AMB1, amb0, 96, 0, 16, [](uint32_t t, uint32_t h) { return 16 * h + t; });
+    emit_stream(out + HP_AMB2, amb1, 128, 0, 64, hidden_col);
+    // density L1: input = [3-D grid (32) | 2-D grid (32)]
+    emit_stream(out + HP_SIG1, sig0, 64, 0, 32, [](uint32_t t, uint32_t h) { return t < 16 ? 16 * h + t : 32 + 16 * h + (t - 16); });
+    emit_stream(out + HP_SIG2, sig1, 128, 0, 64, hidden_col);
+    // density L3: rows 1..128 are the geometry feature (row 0 = log-density goes to the VALU block)
+    emit_stream(out + HP_SIG3, sig2, 128, 1, 64, hidden_col);
+    // colour L1: columns [SH 0..15 | geo 16..143 | id 144..147]
+    emit_stream(out + HP_COL1S, col0, 148, 0, 8, [](uint32_t t, uint32_t h) { return 8 * h + t; });
+    emit_stream(out + HP_COL1G, col0, 148, 0, 64, [](uint32_t t, uint32_t h) { return 16 + hidden_col(t, h); });
+    float* s = out + HP_SMALL;
+    for (uint32_t c = 0; c < 2; c++) emit_valu_rows(s + HS_AMB3 + c * 128, amb2, 128, c, 0);
+    emit_valu_rows(s + HS_SIGROW, sig2, 128, 0, 0);
+    for (uint32_t c = 0; c < 3; c++) emit_valu_rows(s + HS_COL2 + c * 128, col1, 128, c, 0);
+    for (uint32_t ob = 0; ob < 4; ob++)
+        for (uint32_t h = 0; h < 2; h++)
+            for (uint32_t r = 0; r < 16; r++) {
+                const uint32_t row = ob * 32 + c_row(r, h);
+                float b = 0.0f;
+                if (ind_code) for (uint32_t k = 0; k < 4; k++) b += col0[(size_t)row * 148 + 144 + k] * ind_code[k];
+                s[HS_COLBIAS + ob * 32 + h * 16 + r] = b;
+            }
+    return GF_OK;
+}
+
+//   d0 [64,104] d1 [64,64] d2 [2,64] | c0 [32,136] c1 [32,32] c2 [4,32].  out [gf_torso_pack_floats()]
+// d0 columns: [enc(x) 0..41 | enc(pose) 42..95 | code 96..103]; c0 columns: [grid 0..31 | enc(x) 32..73 | enc(pose)+code 74..135].
+// The pose/code columns are per-frame constants: the host folds them into torso_bias.
+GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, const float* c0, const float* c1, const float* c2,
+                            float* out) {
+    using namespace gf;
+    if (!d0 || !d1 || !d2 || !c0 || !c1 || !c2 || !out) return gf_set_error(GF_ERR_INVALID, "torso_pack: null pointer");
+    memset(out, 0, sizeof(float) * TP_TOTAL);
+    auto stream = [&](float* dst, const float* W, uint32_t ld, uint32_t nob, uint32_t nsteps, auto col) {
+        for (uint32_t ob = 0; ob < nob; ob++)
+            for (uint32_t t = 0; t < nsteps; t++)
+                for (uint32_t l = 0; l < 64; l++) {
+                    const int c = col(t, l >> 5);
+                    dst[((ob * (nsteps / 4) + t / 4) * 64 + l) * 4 + (t & 3u)] = c < 0 ? 0.0f : W[(size_t)(ob * 32 + (l & 31u)) * ld + c];
+                }
+    };
+    auto enc_col = [](uint32_t t, uint32_t h) { const uint32_t e = 24 * h + t; return e < 42 ? (int)e : -1; };
+    stream(out + TP_D1, d0, 104, 2, 24, enc_col);
+    stream(out + TP_D2, d1, 64, 2, 32, [](uint32_t t, uint32_t h) { return (int)hidden_col(t, h); });
+    stream(out + TP_C1, c0, 136, 1, 40, [&](uint32_t t, uint32_t h) {
+        if (t < 16) return (int)(16 * h + t);            // 2-D grid features: levels 8h..8h+7
+        const int e = enc_col(t - 16, h);
+        return e < 0 ? -1 : 32 + e;
+    });
+    stream(out + TP_C2, c1, 32, 1, 16, [](uint32_t t, uint32_t h) { return (int)hidden_col(t, h); });
+    for (uint32_t c = 0; c < 2; c++)
+        for (uint32_t ob = 0; ob < 2; ob++)
+            for (uint32_t h = 0; h < 2; h++)
+                for (uint32_t r = 0; r < 16; r++) out[TP_D3 + c * 64 + ob * 32 + h * 16 + r] = d2[(size_t)c * 64 + ob * 32 + c_row(r, h)];
+    for (uint32_t c = 0; c < 4; c++)
+        for (uint32_t h = 0; h < 2; h++)
+            for (uint32_t r = 0; r < 16; r++) out[TP_C3 + c * 32 + h * 16 + r] = c2[(size_t)c * 32 + c_row(r, h)];
+    return GF_OK;
+}

@@ -1,0 +1,351 @@
+"""Host side of the fused frame path (gf_render_head / gf_render_torso of include/geneface_hip.h).
+
+`render_head_fused` / `render_torso_fused` are what `NeRFRenderer.render` / `RADNeRFTorso.render` dispatch to for
+`render_impl="fused"`: same inputs, same result dict, but a frame is a handful of kernel launches on the current
+stream with no host synchronisation (the reference's loop, renderer.py:316-351, syncs once per march iteration).
+`render_frame_fused` is the frame-loop step used by FramePipeline (rays generated in-kernel from the pose, uint8 out).
+
+Per-model state (packed weights, fold matrices, workspace) is built once and cached on the module.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .lib import check, current_stream, lib, ptr
+
+_u32, _f32, _vp = C.c_uint32, C.c_float, C.c_void_p
+
+
+class GfFrame(C.Structure):
+    """ctypes mirror of gf_frame_t (include/geneface_hip.h); size is checked against gf_frame_sizeof()."""
+    _fields_ = [
+        ("n_rays", _u32), ("img_h", _u32), ("img_w", _u32), ("_pad0", _u32),
+        ("rays_o", _vp), ("rays_d", _vp),
+        ("pose", _f32 * 12), ("intrinsics", _f32 * 4),
+        ("aabb", _vp), ("bitfield", _vp),
+        ("min_near", _f32), ("bound", _f32), ("dt_gamma", _f32), ("T_thresh", _f32),
+        ("max_steps", _u32), ("cascade", _u32), ("grid_size", _u32), ("_pad1", _u32),
+        ("pos_table", _vp), ("pos_offsets", _vp), ("amb_table", _vp), ("amb_offsets", _vp),
+        ("pos_S", _f32), ("amb_S", _f32),
+        ("base_res", _u32), ("gridtype", _u32), ("interp", _u32), ("_pad2", _u32),
+        ("head_pack", _vp), ("amb_bias", _vp),
+        ("torso_pack", _vp), ("torso_bias", _vp), ("torso_table", _vp), ("torso_offsets", _vp), ("torso_occ", _vp), ("bg_coords", _vp),
+        ("torso_S", _f32), ("torso_thresh", _f32), ("torso_shrink", _f32), ("_pad3", _f32),
+        ("bg_color", _vp), ("out_rgb", _vp), ("out_depth", _vp), ("out_rgb8", _vp), ("out_torso_alpha", _vp),
+        ("out_torso_rgb", _vp), ("out_deform", _vp),
+        ("workspace", _vp),
+    ]
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().float().cpu().numpy())
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FusedState:
+    """Everything the kernels need that depends only on the model (built once, device resident)."""
+
+    def __init__(self, model):
+        L = lib()
+        assert C.sizeof(GfFrame) == L.gf_frame_sizeof(), "gf_frame_t layout mismatch between fused.py and geneface_hip.h"
+        self.check_architecture(model)
+        dev = model.density_bitfield.device
+        if dev.type != "cuda":
+            raise RuntimeError("the fused render path needs the model on a HIP device (there is no CPU path)")
+        self.device = dev
+        self.has_torso = hasattr(model, "torso_deform_net")
+
+        perm = (C.c_uint32 * 128)()
+        check(L.gf_clayout_perm(perm))
+        self.perm = torch.tensor(list(perm), dtype=torch.long)
+
+        a, s, c = model.ambient_net.net, model.sigma_net.net, model.color_net.net
+        ind = _np(model.individual_embeddings[0]) if model.individual_embedding_dim > 0 else None
+        pack = np.empty(L.gf_head_pack_floats(), dtype=np.float32)
+        check(L.gf_head_pack(_hp(_np(a[0].weight)), _hp(_np(a[1].weight)), _hp(_np(a[2].weight)), _hp(_np(s[0].weight)),
+                             _hp(_np(s[1].weight)), _hp(_np(s[2].weight)), _hp(_np(c[0].weight)), _hp(_np(c[1].weight)),
+                             _hp(ind) if ind is not None else None, _hp(pack)))
+        self.head_pack = torch.from_numpy(pack).to(dev)
+        # ambient L1's cond_feat columns, rows in accumulator-layout order: amb_bias = W_cond @ cond_feat per frame
+        self.W_cond = a[0].weight.detach()[self.perm.to(dev), 32:].contiguous()
+
+        pe, ae = model.position_embedder, model.ambient_embedder
+        self.pos_S, self.amb_S = float(np.log2(pe.per_level_scale)), float(np.log2(ae.per_level_scale))
+        self.gridtype, self.interp, self.base_res = pe.gridtype_id, pe.interp_id, int(pe.base_resolution)
+
+        if self.has_torso:
+            d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
+            tpack = np.empty(L.gf_torso_pack_floats(), dtype=np.float32)
+            check(L.gf_torso_pack(_hp(_np(d[0].weight)), _hp(_np(d[1].weight)), _hp(_np(d[2].weight)), _hp(_np(cn[0].weight)),
+                                  _hp(_np(cn[1].weight)), _hp(_np(cn[2].weight)), _hp(tpack)))
+            self.torso_pack = torch.from_numpy(tpack).to(dev)
+            p64, p32 = self.perm[:64].to(dev), self.perm[:32].to(dev)
+            # per-frame constants [enc(pose) 54 | code 8] fold into the first-layer biases
+            self.W_tconst = torch.cat([d[0].weight.detach()[p64, 42:], cn[0].weight.detach()[p32, 74:]], dim=0).contiguous()  # [96, 62]
+            self.torso_S = float(np.log2(model.torso_embedder.per_level_scale))
+        self._ws = {}
+
+    @staticmethod
+    def check_architecture(model):
+        """The fused kernels are specialised for the GeneFace RAD-NeRF architecture (base.yaml:85-102)."""
+        want = {"position_embedder.embeddings": 2, "ambient_embedder.embeddings": 2}
+        sd = dict(model.named_parameters())
+        for k, cdim in want.items():
+            if sd[k].shape[1] != cdim:
+                raise NotImplementedError(f"fused path: {k} must have level_dim {cdim}")
+        shapes = {"ambient_net.net.0.weight": (128, 96), "ambient_net.net.1.weight": (128, 128), "ambient_net.net.2.weight": (2, 128),
+                  "sigma_net.net.0.weight": (128, 64), "sigma_net.net.1.weight": (128, 128), "sigma_net.net.2.weight": (129, 128),
+                  "color_net.net.1.weight": (3, 128)}
+        for k, shp in shapes.items():
+            if k not in sd or tuple(sd[k].shape) != shp:
+                raise NotImplementedError(f"fused path: {k} must have shape {shp} (use render_impl='ops' for other architectures)")
+        if sd["color_net.net.0.weight"].shape != (128, 144 + model.individual_embedding_dim) or model.individual_embedding_dim not in (0, 4):
+            raise NotImplementedError("fused path: color_net.net.0 must be [128, 16+128+4]")
+        if model.position_embedder.num_levels != 16 or model.ambient_embedder.num_levels != 16:
+            raise NotImplementedError("fused path: grids must have 16 levels")
+        if hasattr(model, "torso_deform_net"):
+            tshapes = {"torso_deform_net.net.0.weight": (64, 104), "torso_deform_net.net.1.weight": (64, 64), "torso_deform_net.net.2.weight": (2, 64),
+                       "torso_canonicial_net.net.0.weight": (32, 136), "torso_canonicial_net.net.1.weight": (32, 32),
+                       "torso_canonicial_net.net.2.weight": (4, 32)}
+            for k, shp in tshapes.items():
+                if tuple(sd[k].shape) != shp:
+                    raise NotImplementedError(f"fused path: {k} must have shape {shp}")
+
+    def workspace(self, n_rays):
+        if n_rays not in self._ws:
+            nbytes = lib().gf_frame_workspace_bytes(n_rays)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            off = lib().gf_frame_ctrl_offset(n_rays)
+            ctrl = buf[off:off + 4 * lib().gf_frame_ctrl_words()].view(torch.int32)
+            self._ws[n_rays] = (buf, ctrl)
+        return self._ws[n_rays]
+
+
+def get_state(model) -> FusedState:
+    st = getattr(model, "_fused_state", None)
+    if st is None or st.device != model.density_bitfield.device:
+        st = FusedState(model)
+        object.__setattr__(model, "_fused_state", st)
+    return st
+
+
+def invalidate(model):
+    """Call after changing weights (the packed copies are rebuilt on the next render)."""
+    if hasattr(model, "_fused_state"):
+        object.__delattr__(model, "_fused_state")
+
+
+def _bg_tensor(bg_color, N, device):
+    if bg_color is None:
+        bg_color = 1
+    if not torch.is_tensor(bg_color):
+        return torch.full((N, 3), float(bg_color), dtype=torch.float32, device=device)
+    bg = bg_color.to(device=device, dtype=torch.float32)
+    if bg.numel() == 3:
+        bg = bg.reshape(1, 3).expand(N, 3)
+    return bg.reshape(N, 3).contiguous()
+
+
+def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth, out_rgb8=None):
+    f.n_rays = N
+    f.aabb, f.bitfield = ptr(model.aabb_infer, torch.float32), ptr(model.density_bitfield, torch.uint8)
+    f.min_near, f.bound, f.dt_gamma, f.T_thresh = float(model.min_near), float(model.bound), float(dt_gamma), float(T_thresh)
+    f.max_steps, f.cascade, f.grid_size = int(max_steps), int(model.cascade), int(model.grid_size)
+    pe, ae = model.position_embedder, model.ambient_embedder
+    f.pos_table, f.pos_offsets = ptr(pe.embeddings, torch.float32), ptr(pe.offsets, torch.int32)
+    f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+    f.pos_S, f.amb_S = st.pos_S, st.amb_S
+    f.base_res, f.gridtype, f.interp = st.base_res, st.gridtype, st.interp
+    f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
+    f.bg_color = ptr(bg, torch.float32)
+    f.out_rgb, f.out_depth = ptr(out_rgb), ptr(out_depth)
+    f.out_rgb8 = ptr(out_rgb8, torch.uint8) if out_rgb8 is not None else None
+    f.workspace = st.workspace(N)[0].data_ptr()
+
+
+def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_alpha, out_trgb, out_deform):
+    te = model.torso_embedder
+    f.torso_pack, f.torso_bias = ptr(st.torso_pack), ptr(torso_bias, torch.float32)
+    f.torso_table, f.torso_offsets = ptr(te.embeddings, torch.float32), ptr(te.offsets, torch.int32)
+    f.torso_occ, f.bg_coords = ptr(model.density_grid_torso, torch.float32), ptr(bg_coords, torch.float32)
+    f.torso_S = st.torso_S
+    f.torso_thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
+    f.torso_shrink = float(model.torso_shrink)
+    f.out_torso_alpha = ptr(out_alpha) if out_alpha is not None else None
+    f.out_torso_rgb = ptr(out_trgb) if out_trgb is not None else None
+    f.out_deform = ptr(out_deform) if out_deform is not None else None
+
+
+def _per_frame_vectors(model, st, cond, poses6=None):
+    """cond encoder + the per-frame bias folds (tiny torch ops on the current stream)."""
+    cond_feat = model.cal_cond_feat(cond).reshape(-1).float()
+    amb_bias = torch.mv(st.W_cond, cond_feat)
+    torso_bias = None
+    if poses6 is not None:
+        v = [model.torso_pose_embedder(poses6.reshape(1, 6).float()).reshape(-1)]
+        if model.torso_individual_embedding_dim > 0:
+            v.append(model.torso_individual_codes[0].detach())
+        torso_bias = torch.mv(st.W_tconst, torch.cat(v))
+    return cond_feat, amb_bias, torso_bias
+
+
+def _check_args(perturb, max_steps):
+    if perturb:
+        raise NotImplementedError("fused render path: perturb=True (training / GUI jitter) is only available with render_impl='ops'")
+    if max_steps > 64:
+        raise NotImplementedError("fused render path: max_steps > 64 is only available with render_impl='ops'")
+
+
+def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh):
+    """NeRFRenderer.render (renderer.py:263-367, inference) on the fused path."""
+    _check_args(perturb, max_steps)
+    with torch.no_grad():
+        st = get_state(model)
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        _, amb_bias, _ = _per_frame_vectors(model, st, cond)
+        bg = _bg_tensor(bg_color, N, dev)
+        out_rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        out_depth = torch.empty(N, dtype=torch.float32, device=dev)
+        f = GfFrame()
+        _fill_common(f, model, st, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth)
+        f.rays_o, f.rays_d = ptr(rays_o), ptr(rays_d)
+        check(lib().gf_render_head(C.byref(f), current_stream(dev)))
+        model.last_ctrl = st.workspace(N)[1]
+        return {"depth_map": out_depth.view(*prefix), "rgb_map": out_rgb.view(*prefix, 3)}
+
+
+def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh,
+                       return_deform=True):
+    """RADNeRFTorso.render (radnerf_torso.py:86-198, inference) on the fused path."""
+    _check_args(perturb, max_steps)
+    with torch.no_grad():
+        st = get_state(model)
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        bg_coords = bg_coords.contiguous().view(-1, 2).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        _, amb_bias, torso_bias = _per_frame_vectors(model, st, cond, poses)
+        bg = _bg_tensor(bg_color, N, dev)
+        out_rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        out_depth = torch.empty(N, dtype=torch.float32, device=dev)
+        out_alpha = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        out_trgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        out_deform = torch.zeros(N, 2, dtype=torch.float32, device=dev) if return_deform else None
+        f = GfFrame()
+        _fill_common(f, model, st, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth)
+        f.rays_o, f.rays_d = ptr(rays_o), ptr(rays_d)
+        _fill_torso(f, model, st, bg_coords, torso_bias, out_alpha, out_trgb, out_deform)
+        s = current_stream(dev)
+        check(lib().gf_render_head(C.byref(f), s))
+        check(lib().gf_render_torso(C.byref(f), s))
+        model.last_ctrl = st.workspace(N)[1]
+        results = {"torso_alpha_map": out_alpha, "torso_rgb_map": out_trgb.view(*prefix, 3) if len(prefix) > 1 else out_trgb,
+                   "rgb_map": out_rgb.view(*prefix, 3), "depth_map": out_depth.view(*prefix)}
+        if return_deform:
+            mask = out_alpha.view(-1) > 0  # sigmoid() > 0 on every masked pixel, exactly 0 elsewhere
+            if bool(mask.any()):
+                results["deform"] = out_deform[mask]
+        return results
+
+
+def schedule_from_ctrl(ctrl: torch.Tensor, N: int, max_steps: int):
+    """[(n_alive, n_step, n_valid_samples)] of the last frame, decoded from the device control block (forces a sync)."""
+    c = ctrl.cpu().numpy().astype(np.int64)
+    K = 65
+    out, step = [], 0
+    for it in range(64):
+        n_alive = int(c[it])
+        if n_alive <= 0 or step >= max_steps:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        out.append((n_alive, n_step, int(c[2 * K + it])))
+        step += n_step
+    return out
+
+
+# --------------------------------------------------------------------------------------------- frame-loop step
+class _PipeBuffers:
+    def __init__(self, pipe):
+        dev, N = pipe.device, pipe.H * pipe.W
+        self.rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        self.depth = torch.empty(N, dtype=torch.float32, device=dev)
+        self.rgb8 = [torch.empty(pipe.H, pipe.W, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.k = 0
+        self.bg = pipe.bg.reshape(N, 3).contiguous()
+        self.bg_coords = pipe.bg_coords.reshape(N, 2).contiguous()
+        self.poses_host = pipe.poses.cpu().numpy()
+
+
+def _fill_pose_frame(pipe, i, f, rgb8):
+    """Describe frame i of the pipeline: rays come from pose + intrinsics inside the kernel."""
+    model, hp = pipe.model, pipe.hp
+    st = get_state(model)
+    bufs = getattr(pipe, "_fused_bufs", None)
+    if bufs is None:
+        bufs = pipe._fused_bufs = _PipeBuffers(pipe)
+    N = pipe.H * pipe.W
+    torso = st.has_torso
+    _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
+    _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], 1e-4, amb_bias, bufs.bg, bufs.rgb, bufs.depth, rgb8)
+    f.img_h, f.img_w = pipe.H, pipe.W
+    f.rays_o = f.rays_d = None
+    p = bufs.poses_host[i]
+    for r in range(3):
+        for c in range(4):
+            f.pose[r * 4 + c] = float(p[r, c])
+    for k in range(4):
+        f.intrinsics[k] = float(pipe.intrinsics[k])
+    if torso:
+        _fill_torso(f, model, st, bufs.bg_coords, torso_bias, None, None, None)
+    return st, bufs, (amb_bias, torso_bias)
+
+
+def render_frame_fused(pipe, i):
+    """One frame of FramePipeline on the fused path -> device uint8 [H,W,3] (two buffers alternate, so the async
+    D2H copy of frame i may still be reading one while frame i+1 is rendered into the other)."""
+    with torch.no_grad():
+        f = GfFrame()
+        st, bufs, keep = _fill_pose_frame(pipe, i, f, None)
+        rgb8 = bufs.rgb8[bufs.k]
+        bufs.k = 1 - bufs.k
+        f.out_rgb8 = rgb8.data_ptr()
+        s = current_stream(pipe.device)
+        check(lib().gf_render_head(C.byref(f), s))
+        if st.has_torso:
+            check(lib().gf_render_torso(C.byref(f), s))
+        return rgb8
+
+
+def profile_frames(pipe, first, n_frames, flop_per_sample, peak_tflops):
+    """bench.py roofline leg: time every launch of the dominant kernel (the per-iteration head kernel) with HIP events
+    on the stream it runs on, and divide the algorithmic FLOPs of the samples it evaluated by that time."""
+    iter_ms = (C.c_float * 64)()
+    n_it = C.c_uint32(0)
+    tot_ms, tot_samples, launches, per_frame = 0.0, 0, 0, []
+    N = pipe.H * pipe.W
+    with torch.no_grad():
+        for i in range(first, first + n_frames):
+            f = GfFrame()
+            st, bufs, keep = _fill_pose_frame(pipe, i, f, None)
+            check(lib().gf_render_head_timed(C.byref(f), current_stream(pipe.device), iter_ms, C.byref(n_it)))
+            sched = schedule_from_ctrl(st.workspace(N)[1], N, pipe.hp["max_steps"])
+            ms = sum(iter_ms[k] for k in range(len(sched)))
+            samples = sum(v for _, _, v in sched)
+            tot_ms += ms
+            tot_samples += samples
+            launches += len(sched)
+            per_frame.append({"iters": len(sched), "samples": samples, "n_step": [s for _, s, _ in sched], "kernel_ms": round(ms, 4)})
+    achieved = tot_samples * flop_per_sample / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved / peak_tflops,
+            "traffic": None, "kernel": "k_head_iter (march + field + composite, one launch per march iteration)",
+            "launches": launches, "avg_launch_ms": tot_ms / max(launches, 1), "samples_per_frame": tot_samples / max(n_frames, 1),
+            "flop_per_sample": flop_per_sample, "frames_profiled": n_frames, "example_frame": per_frame[0] if per_frame else None}

@@ -84,6 +84,72 @@ int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32
 /* freq_encode_forward (kernel freqencoder.cu:30-58).  inputs [B,D], outputs [B,C], C = D + 2*D*deg. */
 int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused frame path.  One call enqueues a whole head (and torso) pass of
+ *   NeRFRenderer.render    modules/radnerfs/renderer.py:263-367 (inference branch :314-367)
+ *   RADNeRF.forward        modules/radnerfs/radnerf.py:73-105   (evaluated inside the march iterations)
+ *   RADNeRFTorso.render    modules/radnerfs/radnerf_torso.py:86-198, forward_torso :51-84
+ * with no host synchronisation: the alive list, n_alive and the n_step schedule (renderer.py:338) stay on the device.
+ * Weights are handed over once in the packed layouts produced by gf_head_pack / gf_torso_pack (HOST functions).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gf_frame_t {
+    /* rays: explicit tensors, or generated from pose + intrinsics when rays_o == NULL (utils.py:282-363, N = -1 branch) */
+    uint32_t n_rays, img_h, img_w, _pad0;
+    const float* rays_o;        /* [N,3] or NULL */
+    const float* rays_d;        /* [N,3] or NULL */
+    float pose[12];             /* row-major 3x4 cam2world, ngp axes */
+    float intrinsics[4];        /* fx, fy, cx, cy */
+    /* marcher state (renderer.py:65-99) */
+    const float* aabb;          /* [6] aabb_infer */
+    const uint8_t* bitfield;    /* density_bitfield [cascade*grid^3/8] */
+    float min_near, bound, dt_gamma, T_thresh;
+    uint32_t max_steps, cascade, grid_size, _pad1;
+    /* head field (radnerf.py:41-59) */
+    const float* pos_table;  const int32_t* pos_offsets;   /* position_embedder.embeddings / offsets (3-D, 16x2) */
+    const float* amb_table;  const int32_t* amb_offsets;   /* ambient_embedder.embeddings / offsets  (2-D, 16x2) */
+    float pos_S, amb_S;         /* log2(per_level_scale) of each grid */
+    uint32_t base_res, gridtype, interp, _pad2;
+    const float* head_pack;     /* device copy of gf_head_pack() output */
+    const float* amb_bias;      /* [128] ambient_net.net.0.weight[:, 32:96] @ cond_feat, rows permuted by gf_clayout_perm */
+    /* torso field (radnerf_torso.py:20-49); torso_pack == NULL renders the head only */
+    const float* torso_pack;    /* device copy of gf_torso_pack() output */
+    const float* torso_bias;    /* [96] folded per-frame constants (deform L1 64 | canonical L1 32), permuted rows */
+    const float* torso_table; const int32_t* torso_offsets;
+    const float* torso_occ;     /* density_grid_torso [grid*grid] */
+    const float* bg_coords;     /* [N,2] */
+    float torso_S, torso_thresh, torso_shrink, _pad3;
+    /* compositing */
+    const float* bg_color;      /* [N,3] */
+    float* out_rgb;             /* [N,3] rgb_map */
+    float* out_depth;           /* [N]   depth_map */
+    uint8_t* out_rgb8;          /* [N,3] or NULL: (rgb*255) truncated, base_nerf_infer.py:96-97 */
+    float* out_torso_alpha;     /* [N]   or NULL: torso_alpha_map */
+    float* out_torso_rgb;       /* [N,3] or NULL: torso_rgb_map */
+    float* out_deform;          /* [N,2] or NULL: dx of the masked pixels (others untouched) */
+    void* workspace;            /* gf_frame_workspace_bytes(n_rays) bytes, 256-byte aligned */
+} gf_frame_t;
+
+uint64_t gf_frame_sizeof(void);
+uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
+uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */
+uint32_t gf_frame_ctrl_words(void);               /* [0..64] n_alive per iteration | [65..129] cumulative step | [130..194] valid samples */
+uint32_t gf_head_pack_floats(void);
+uint32_t gf_torso_pack_floats(void);
+int gf_clayout_perm(uint32_t* perm128_host);
+/* HOST pointers: nn.Linear weights [out,in] of ambient_net / sigma_net / color_net (cond_encoder.py:92-111), individual code or NULL */
+int gf_head_pack(const float* amb0_host, const float* amb1_host, const float* amb2_host, const float* sig0_host,
+                 const float* sig1_host, const float* sig2_host, const float* col0_host, const float* col1_host,
+                 const float* ind_code_host, float* out_host);
+/* HOST pointers: torso_deform_net / torso_canonicial_net weights */
+int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_host, const float* c0_host,
+                  const float* c1_host, const float* c2_host, float* out_host);
+/* head pass; with torso_pack == NULL also the head-only tail (renderer.py:354-364) so outputs are final */
+int gf_render_head(const gf_frame_t* frame, void* stream);
+/* torso pass + final blend (radnerf_torso.py:156-198); gf_render_head must precede it on the same stream */
+int gf_render_torso(const gf_frame_t* frame, void* stream);
+/* measurement only: gf_render_head's march iterations bracketed by HIP events on `stream`; synchronises */
+int gf_render_head_timed(const gf_frame_t* frame, void* stream, float* iter_ms_host, uint32_t* n_iters_host);
+
 #ifdef __cplusplus
 }
 #endif
