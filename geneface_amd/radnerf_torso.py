@@ -66,7 +66,7 @@ class RADNeRFTorso(RADNeRF):
                force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         if self.training:
             raise NotImplementedError("RADNeRFTorso.render: the training branch is outside this round's scope (SURVEY.md 8f-2)")
-        impl = kwargs.get("render_impl", self.render_impl)
+        impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_torso_fused
             return render_torso_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh)

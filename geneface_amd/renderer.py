@@ -21,8 +21,10 @@ from . import raymarching
 
 
 class NeRFRenderer(nn.Module):
-    #: default execution strategy of render(); "fused" falls back to nothing -- it raises if unavailable
-    render_impl = "ops"
+    #: execution strategy of render(): "fused", "ops", or "auto" = fused whenever the call is inside what the fused
+    #: kernels cover (no perturbation, max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
+    #: the GPU through libgeneface_hip.so; neither has a CPU fallback.
+    render_impl = "auto"
 
     def __init__(self, hparams):
         super().__init__()
@@ -78,6 +80,22 @@ class NeRFRenderer(nn.Module):
     def update_extra_state(self, decay=0.95, S=128):
         raise NotImplementedError("density-grid maintenance is the next scope row (SURVEY.md 8f-1)")
 
+    def _pick_impl(self, impl, perturb, max_steps):
+        if impl != "auto":
+            return impl
+        if perturb or max_steps > 64:
+            return "ops"
+        ok = getattr(self, "_fused_arch_ok", None)
+        if ok is None:
+            from .fused import FusedState
+            try:
+                FusedState.check_architecture(self)
+                ok = True
+            except NotImplementedError:
+                ok = False
+            object.__setattr__(self, "_fused_arch_ok", ok)
+        return "fused" if ok else "ops"
+
     # --- shared pieces of render() ---
     def _ind_code(self):
         return self.individual_embeddings[0] if self.individual_embedding_dim > 0 else None
@@ -112,7 +130,7 @@ class NeRFRenderer(nn.Module):
                force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         if self.training:
             raise NotImplementedError("NeRFRenderer.render: the training branch is outside this round's scope (SURVEY.md 8f-2)")
-        impl = kwargs.get("render_impl", self.render_impl)
+        impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_head_fused
             return render_head_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh)
