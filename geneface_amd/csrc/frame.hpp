@@ -10,14 +10,22 @@ namespace gf {
 // ---------------- workspace carve-out (all offsets in bytes, 256-aligned) ----------------
 struct FrameWs {
     float *nears, *fars, *rays_t, *weights_sum, *depth, *image, *rays_o, *rays_d;
-    int32_t *alive_a, *alive_b;
+    int32_t *alive_a, *alive_b;  // survivor list / hit list
     uint32_t* ctrl;  // [kCtrlWords]
     size_t bytes;
 };
-constexpr uint32_t kMaxIters = 64;
-// ctrl layout: [0..kMaxIters] n_alive per iteration, [kMaxIters+1 .. 2*kMaxIters+1] cumulative step per iteration,
-// then statistics: valid samples per iteration.
-constexpr uint32_t kCtrlAlive = 0, kCtrlStep = kMaxIters + 1, kCtrlValid = 2 * (kMaxIters + 1), kCtrlWords = 3 * (kMaxIters + 1) + 8;
+constexpr uint32_t kMaxSteps = 64;  // largest max_steps the fused path accepts
+// Control block (uint32 words), zeroed by a memset node at the head of every frame:
+constexpr uint32_t kCtrlQHead0 = 0;    // phase 0: next unclaimed entry of the hit list
+constexpr uint32_t kCtrlNHit = 1;      // rays with >= 1 sample (length of the hit list, alive_b)
+constexpr uint32_t kCtrlNSurv = 2;     // rays still alive after max_steps samples (length of the survivor list, alive_a)
+constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list
+constexpr uint32_t kCtrlSamples = 4;   // [2] field evaluations per phase
+constexpr uint32_t kCtrlRounds = 6;    // [2] workgroup rounds per phase
+constexpr uint32_t kCtrlTiles = 8;     // [2] 32-sample MFMA tiles executed per phase
+constexpr uint32_t kCtrlBudget = 10;   // total per-ray sample budget B the reference's n_step schedule arrives at
+constexpr uint32_t kCtrlHist = 16;     // [kMaxSteps + 2] rays that terminate at cumulative sample index d (d = 1 .. max_steps)
+constexpr uint32_t kCtrlWords = 128;
 
 inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
     FrameWs w;

@@ -1,23 +1,34 @@
-// Fused head pass of one RAD-NeRF frame for gfx950: ray setup, then one kernel per march iteration that
-// marches, evaluates the whole field (3-D grid -> ambient MLP -> tanh -> 2-D grid -> density MLP -> exp; SH + geometry
-// feature -> colour MLP -> sigmoid) on f32 MFMA and composites -- with the alive list, n_alive and n_step kept on the
-// device, so a frame is enqueued without a single host synchronisation.
+// Fused head pass of one RAD-NeRF frame for gfx950.
 //
-// What it replaces, per iteration, in the reference (paths relative to /root/reference/modules/radnerfs):
-//   renderer.py:316-351 loop body = raymarching.cu:828-929 (march) + radnerf.py:73-105 (~40 launches: 2 grid encodes,
-//   8 GEMMs, SH, cats, activations) + raymarching.cu:943-1029 (composite) + `rays_alive[rays_alive >= 0]` (host sync).
+// Replaces, in the reference (paths relative to /root/reference/modules/radnerfs), the whole inference loop of
+// renderer.py:316-351: per iteration raymarching.cu:828-929 (march) + radnerf.py:73-105 (~40 launches: 2 grid encodes,
+// 8 GEMMs, SH, cats, activations) + raymarching.cu:943-1029 (composite) + `rays_alive[rays_alive >= 0]` (a host sync),
+// repeated up to 16 times -- by three launches and no host synchronisation.
 //
-// Work decomposition: a 256-thread workgroup (4 waves) takes `kPass` = 128 sample slots per pass = 128/n_step rays.
-//   A. march   : one lane per ray writes its samples to LDS; a wave-scan packs the valid ones densely
-//   B. field   : each wave owns one 32-sample tile.  Activations live in registers in the MFMA accumulator layout,
-//                which is exactly the B-operand layout of the next layer's v_mfma_f32_32x32x2_f32 (feature pairs
-//                (row, row+4) split over the two 32-lane halves), so layers chain with no data movement; weights
-//                stream L2 -> LDS one layer at a time (64 KB buffer, 2 workgroups per CU so one's loads overlap
-//                the other's MFMAs); the three skinny output layers (->2, ->1, ->3) run on the VALU
-//   C. composite: one lane per ray consumes its samples in order, updates the ray, survivors are appended to the
-//                next alive list with one atomic per wave.
-// Exactness: the n_step schedule is a function of global alive counts (renderer.py:338); it is reproduced exactly
-// because every iteration is its own launch and reads the count its predecessor accumulated.
+// EXACT TWO-PHASE SCHEDULING.  The reference gives every still-alive ray n_step = clamp(N // n_alive, 1, 8) more samples
+// per iteration until the cumulative count c reaches max_steps (renderer.py:338,351).  Two facts make the global
+// iteration barrier unnecessary:
+//   (1) what a ray accumulates depends only on its TOTAL sample budget, not on how the budget is cut into chunks (the
+//       marcher resumes from the t it stopped at; the compositor's termination tests are per sample);
+//   (2) the total budget B = last c is a function of alive(c) for c < max_steps only (the loop stops once c >= max_steps),
+//       and alive(c) = N - #{rays whose terminal sample index d <= c}, d = the sample at which T dropped below T_thresh,
+//       or (number of samples the ray has) + 1.
+// So: phase 0 gives every ray its first max_steps samples (or fewer, if it terminates) and histograms d; phase 1 replays
+// the reference's schedule from the histogram, obtains B exactly, and gives the rays still alive the remaining
+// B - max_steps samples.  tests/test_gpu_render.py checks B, the alive counts and the sample totals against the oracle's
+// iteration trace.
+//
+// WORK DECOMPOSITION.  k_frame_init: one lane per ray -- ray generation, slab test, and the march through empty space up to
+// the first occupied sample (a latency-bound, high-occupancy kernel; rays that never hit anything are finished here).
+// k_head_phase: persistent 256-thread workgroups (2 per CU) each keep a pool of up to 128 live rays in LDS, refilled from
+// a global queue, and loop over rounds of <= 128 samples:
+//   A. march    : one lane per pooled ray, samples to LDS, wave-scan packs the valid ones densely
+//   B. field    : each of the 4 waves owns a 32-sample MFMA tile.  Activations stay in registers in the accumulator
+//                 layout of v_mfma_f32_32x32x2_f32, which is also a legal B-operand layout for the next layer, so layers
+//                 chain with no data movement; weights stream L2 -> LDS by asynchronous LDS-DMA in half-layer chunks
+//                 (two 32 KB buffers: chunk k+1 lands while chunk k feeds the MFMAs); the three skinny output layers
+//                 (->2, ->1, ->3) run on the VALU; grid lookups are split across the two 32-lane halves of the wave
+//   C. composite: the owning lane consumes its samples in order; finished rays write their accumulators once.
 #include "common.hpp"
 #include "frame.hpp"
 #include "march_core.hpp"
@@ -30,9 +41,11 @@ namespace {
 using gf::floatx16;
 
 constexpr int kThreads = 256;
-constexpr int kPass = 128;       // sample slots per workgroup pass (4 waves x 32-column MFMA tiles)
-constexpr int kWFloats = 16384;  // 64 KB weight buffer
-constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 128 /*level meta: 2 grids x 16 x {scale,res,off,size}*/;
+constexpr int kPass = 128;            // sample slots per round (4 waves x 32-column MFMA tiles)
+constexpr int kPool = 128;            // live rays per workgroup
+constexpr int kBufFloats = 8192;      // one 32 KB weight buffer
+constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 128 /*level meta: 2 grids x 16 x {scale,res,off,rows}*/;
+constexpr int kHistBins = gf::kMaxSteps + 2;
 
 struct HeadArgs {
     gf::MarchParams mp;
@@ -42,62 +55,89 @@ struct HeadArgs {
     const float* head_pack; const float* amb_bias;
     const float* rays_o; const float* rays_d; const float* fars;
     float* rays_t; float* weights_sum; float* depth; float* image;
-    const int* alive_in; int* alive_out; uint32_t* ctrl;
-    uint32_t N, iter, max_steps, gridtype, interp;
+    const int* queue;   // phase 0: hit list, phase 1: survivor list
+    int* survivors;     // phase 0 output
+    uint32_t* ctrl;
+    uint32_t N, phase, max_steps, gridtype, interp;
     float T_thresh, bound;
 };
 
 // ---------------------------------------------------------------------------------------------------- LDS carve
 struct Smem {
-    float* W;      // [kWFloats] current layer's A-operand stream
-    float* P;      // [kPFloats] VALU-layer rows, colour bias, ambient bias, per-level grid meta
-    float *sx, *sy, *sz, *sdt, *st;  // [kPass] raw sample slots (slot = ray_local * n_step + s)
-    float *osig, *orr, *og, *ob;     // [kPass] field outputs per raw slot
-    float *rdx, *rdy, *rdz;          // [kPass] per-ray direction
-    uint32_t *d2r, *rcnt, *rbase;    // [kPass] dense->raw map, per-ray sample count / dense base
-    uint32_t* misc;                  // [8]
+    float* buf[2];   // weight chunk double buffer
+    float* P;        // VALU-layer rows, colour bias, ambient bias, per-level grid meta
+    // ray pool (slot = owner thread)
+    int* p_ray; float *p_ox, *p_oy, *p_oz, *p_dx, *p_dy, *p_dz, *p_t, *p_far, *p_ws, *p_dep, *p_r, *p_g, *p_b; uint32_t* p_done;
+    // per-round sample staging (raw slot = rank * n + s); outputs alias the positions
+    float *sx, *sy, *sz, *sdt, *st, *ob;
+    uint8_t *d2r, *rcnt, *rbase, *rrank;
+    uint32_t* hist;  // [kHistBins]
+    uint32_t* misc;  // [16]
 };
-constexpr int kSmemFloats = kWFloats + kPFloats + kPass * (5 + 4 + 3 + 3) + 8;
+constexpr int kSmemBytes = (2 * kBufFloats + kPFloats + 15 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
+static_assert(2 * kSmemBytes <= 160 * 1024, "two workgroups per CU");
+
 __device__ __forceinline__ Smem carve(char* base) {
     Smem s;
     float* f = reinterpret_cast<float*>(base);
-    s.W = f; f += kWFloats;
+    s.buf[0] = f; f += kBufFloats;
+    s.buf[1] = f; f += kBufFloats;
     s.P = f; f += kPFloats;
-    s.sx = f; f += kPass; s.sy = f; f += kPass; s.sz = f; f += kPass; s.sdt = f; f += kPass; s.st = f; f += kPass;
-    s.osig = f; f += kPass; s.orr = f; f += kPass; s.og = f; f += kPass; s.ob = f; f += kPass;
-    s.rdx = f; f += kPass; s.rdy = f; f += kPass; s.rdz = f; f += kPass;
-    s.d2r = reinterpret_cast<uint32_t*>(f); f += kPass;
-    s.rcnt = reinterpret_cast<uint32_t*>(f); f += kPass;
-    s.rbase = reinterpret_cast<uint32_t*>(f); f += kPass;
-    s.misc = reinterpret_cast<uint32_t*>(f);
+    s.p_ray = reinterpret_cast<int*>(f); f += kPool;
+    s.p_ox = f; f += kPool; s.p_oy = f; f += kPool; s.p_oz = f; f += kPool;
+    s.p_dx = f; f += kPool; s.p_dy = f; f += kPool; s.p_dz = f; f += kPool;
+    s.p_t = f; f += kPool; s.p_far = f; f += kPool;
+    s.p_ws = f; f += kPool; s.p_dep = f; f += kPool; s.p_r = f; f += kPool; s.p_g = f; f += kPool; s.p_b = f; f += kPool;
+    s.p_done = reinterpret_cast<uint32_t*>(f); f += kPool;
+    s.sx = f; f += kPass; s.sy = f; f += kPass; s.sz = f; f += kPass; s.sdt = f; f += kPass; s.st = f; f += kPass; s.ob = f; f += kPass;
+    s.hist = reinterpret_cast<uint32_t*>(f); f += kHistBins;
+    s.misc = reinterpret_cast<uint32_t*>(f); f += 16;
+    uint8_t* b = reinterpret_cast<uint8_t*>(f);
+    s.d2r = b; s.rcnt = b + kPass; s.rbase = b + 2 * kPass; s.rrank = b + 3 * kPass;
     return s;
 }
-// P layout
 constexpr int P_SMALL = 0, P_AMBBIAS = gf::HS_TOTAL, P_META = gf::HS_TOTAL + 128;
-// meta: grid g (0 = 3-D, 1 = 2-D), level l: P[P_META + g*64 + l*4 + {0 scale, 1 resolution, 2 row offset, 3 rows}]
 
-__device__ __forceinline__ void stage_weights(float* __restrict__ W, const float* __restrict__ src, int nfloats) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    float4* d4 = reinterpret_cast<float4*>(W);
-    for (int i = threadIdx.x; i < nfloats / 4; i += kThreads) d4[i] = s4[i];
+// The reference's schedule replayed from the terminal-index histogram: returns the total budget B.
+__device__ uint32_t replay_budget(const uint32_t* __restrict__ hist, uint32_t N, uint32_t max_steps) {
+    uint32_t c = 0, dead = 0, d = 0;
+    while (c < max_steps) {
+        while (d < c) { d++; dead += hist[d]; }  // dead = #{rays with terminal index <= c}
+        const uint32_t n_alive = N - dead;
+        if (n_alive == 0) break;
+        uint32_t n = N / n_alive;
+        n = n > 8u ? 8u : (n < 1u ? 1u : n);
+        c += n;
+    }
+    return c;
 }
 
-__global__ void __launch_bounds__(kThreads, 2) k_head_iter(const HeadArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const bool owner = tid < kPool;
 
-    const uint32_t n_alive = a.ctrl[gf::kCtrlAlive + a.iter];
-    const uint32_t step0 = a.ctrl[gf::kCtrlStep + a.iter];
-    if (n_alive == 0 || step0 >= a.max_steps) return;
-    uint32_t n_step = a.N / n_alive;
-    n_step = n_step > 8u ? 8u : (n_step < 1u ? 1u : n_step);  // renderer.py:338
-    if (blockIdx.x == 0 && tid == 0) a.ctrl[gf::kCtrlStep + a.iter + 1] = step0 + n_step;
-    const uint32_t R = kPass / n_step;  // rays per pass
-    const uint32_t n_groups = (n_alive + R - 1) / R;
-    if (blockIdx.x >= n_groups) return;
+    // ---- phase set-up (uniform) ----
+    uint32_t budget, limit;
+    const uint32_t qhead = a.phase ? gf::kCtrlQHead1 : gf::kCtrlQHead0;
+    if (a.phase == 0) {
+        budget = a.max_steps;
+        limit = a.ctrl[gf::kCtrlNHit];
+    } else {
+        if (tid == 0) {
+            const uint32_t B = replay_budget(a.ctrl + gf::kCtrlHist, a.N, a.max_steps);
+            s.misc[8] = B;
+            if (blockIdx.x == 0) a.ctrl[gf::kCtrlBudget] = B;
+        }
+        __syncthreads();
+        const uint32_t B = s.misc[8];
+        budget = B > a.max_steps ? B - a.max_steps : 0u;
+        limit = a.ctrl[gf::kCtrlNSurv];
+    }
+    if (budget == 0 || limit == 0) return;
+    if ((uint32_t)blockIdx.x * kPool >= limit) return;  // not even one refill's worth of work for this workgroup
 
-    // persistent small data: VALU rows + colour bias, this frame's ambient bias, per-level grid meta
     for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
     if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
     if (tid < 32) {
@@ -110,32 +150,78 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_iter(const HeadArgs a) {
         m[2] = __uint_as_float((uint32_t)off[l]);
         m[3] = __uint_as_float((uint32_t)(off[l + 1] - off[l]));
     }
+    if (tid < kHistBins) s.hist[tid] = 0;
+    if (owner) s.p_ray[tid] = -1;
     const float* pack = a.head_pack;
+    uint32_t par = 0;               // which weight buffer the next chunk goes to
+    uint32_t st_samples = 0, st_rounds = 0, st_tiles = 0;  // statistics (thread 0)
+    bool queue_open = true;         // uniform
 
-    for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
-        __syncthreads();  // previous pass fully consumed (staging + weight buffer)
-        // ------------------------------------------------------------------ A. march
-        const uint32_t slot = group * R + tid;
-        const bool has_ray = (uint32_t)tid < R && slot < n_alive;
-        int ray = -1;
-        float t_ray = 0.0f;
-        uint32_t cnt = 0;
-        if (has_ray) {
-            ray = a.alive_in[slot];
-            const float* o = a.rays_o + (size_t)ray * 3;
-            const float* d = a.rays_d + (size_t)ray * 3;
-            const float dx = d[0], dy = d[1], dz = d[2];
-            t_ray = a.rays_t[ray];
-            const uint32_t base = tid * n_step;
-            cnt = gf::march_ray(a.mp, o[0], o[1], o[2], dx, dy, dz, a.fars[ray], 0.0f, n_step, t_ray,
-                                [&](uint32_t st, float x, float y, float z, float dt, float t_after) {
-                                    s.sx[base + st] = x; s.sy[base + st] = y; s.sz[base + st] = z;
-                                    s.sdt[base + st] = dt; s.st[base + st] = t_after;
-                                });
-            s.rdx[tid] = dx; s.rdy[tid] = dy; s.rdz[tid] = dz;
+    for (;;) {
+        __syncthreads();  // previous round fully retired (pool, staging)
+        // ------------------------------------------------------------------ refill empty pool slots from the queue
+        int ray = owner ? s.p_ray[tid] : -1;
+        if (queue_open && wave < 2) {  // wave-uniform branch
+            const bool want = ray < 0;
+            const unsigned long long m = __ballot(want);
+            const uint32_t nw = (uint32_t)__popcll(m);
+            uint32_t base = 0;
+            if (lane == 0 && nw) base = atomicAdd(&a.ctrl[qhead], nw);
+            base = __shfl(base, 0);
+            if (want) {
+                const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (idx < limit) {
+                    ray = a.queue[idx];
+                    const float* o = a.rays_o + (size_t)ray * 3;
+                    const float* d = a.rays_d + (size_t)ray * 3;
+                    s.p_ox[tid] = o[0]; s.p_oy[tid] = o[1]; s.p_oz[tid] = o[2];
+                    s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
+                    s.p_t[tid] = a.rays_t[ray];
+                    s.p_far[tid] = a.fars[ray];
+                    if (a.phase == 0) {
+                        s.p_ws[tid] = 0.0f; s.p_dep[tid] = 0.0f; s.p_r[tid] = 0.0f; s.p_g[tid] = 0.0f; s.p_b[tid] = 0.0f;
+                    } else {
+                        s.p_ws[tid] = a.weights_sum[ray]; s.p_dep[tid] = a.depth[ray];
+                        s.p_r[tid] = a.image[(size_t)ray * 3]; s.p_g[tid] = a.image[(size_t)ray * 3 + 1]; s.p_b[tid] = a.image[(size_t)ray * 3 + 2];
+                    }
+                    s.p_done[tid] = 0;
+                    s.p_ray[tid] = ray;
+                }
+            }
+            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= limit) ? 1u : 0u;  // this wave saw the end of the queue
         }
-        if (tid < kPass) s.rcnt[tid] = cnt;
-        stage_weights(s.W, pack + gf::HP_AMB1, 4 * 16 * 64);  // first layer's weights ride the same barrier
+        // ------------------------------------------------------------------ pool census
+        const bool alive = ray >= 0;
+        unsigned long long amask = 0;
+        if (wave < 2) {
+            amask = __ballot(alive);
+            if (lane == 0) s.misc[wave] = (uint32_t)__popcll(amask);
+        }
+        __syncthreads();
+        const uint32_t n_pool = s.misc[0] + s.misc[1];
+        if (queue_open && (s.misc[4] | s.misc[5])) queue_open = false;
+        if (n_pool == 0) {
+            if (!queue_open) break;   // nothing alive, nothing left to fetch
+            continue;                 // the queue still has entries: fetch again
+        }
+        uint32_t n = kPass / n_pool;
+        n = n > 8u ? 8u : n;          // >= 1 since n_pool <= 128
+        // ------------------------------------------------------------------ A. march
+        uint32_t cnt = 0, req = 0, rank = 0;
+        float t_ray = 0.0f;
+        if (alive) {
+            rank = (wave ? s.misc[0] : 0u) + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+            const uint32_t left = budget - s.p_done[tid];
+            req = n < left ? n : left;
+            t_ray = s.p_t[tid];
+            const uint32_t base = rank * n;
+            cnt = gf::march_ray(a.mp, s.p_ox[tid], s.p_oy[tid], s.p_oz[tid], s.p_dx[tid], s.p_dy[tid], s.p_dz[tid], s.p_far[tid], 0.0f, req, t_ray,
+                                [&](uint32_t q, float x, float y, float z, float dt, float t_after, float) {
+                                    s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
+                                    s.sdt[base + q] = dt; s.st[base + q] = t_after;
+                                });
+        }
+        if (owner) s.rcnt[tid] = (uint8_t)cnt;
         __syncthreads();
         if (wave == 0) {  // exclusive scan of 128 counts, two per lane
             const uint32_t c0 = s.rcnt[2 * lane], c1 = s.rcnt[2 * lane + 1];
@@ -146,187 +232,234 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_iter(const HeadArgs a) {
                 if (lane >= d) incl += up;
             }
             const uint32_t excl = incl - (c0 + c1);
-            s.rbase[2 * lane] = excl;
-            s.rbase[2 * lane + 1] = excl + c0;
-            if (lane == 63) s.misc[0] = incl;
+            s.rbase[2 * lane] = (uint8_t)excl;
+            s.rbase[2 * lane + 1] = (uint8_t)(excl + c0);
+            if (lane == 63) s.misc[2] = incl;
         }
         __syncthreads();
-        const uint32_t Mv = s.misc[0];
-        if (tid < kPass) {
-            const uint32_t c = s.rcnt[tid], b = s.rbase[tid];
-            for (uint32_t q = 0; q < c; q++) s.d2r[b + q] = tid * n_step + q;
+        const uint32_t Mv = s.misc[2];
+        if (alive) {
+            const uint32_t b = s.rbase[tid];
+            for (uint32_t q = 0; q < cnt; q++) { s.d2r[b + q] = (uint8_t)(rank * n + q); s.rrank[b + q] = (uint8_t)tid; }
         }
-        if (tid == 0 && Mv) atomicAdd(&a.ctrl[gf::kCtrlValid + a.iter], Mv);
-        __syncthreads();
+        if (tid == 0) { st_samples += Mv; st_rounds++; st_tiles += (Mv + 31) / 32; }
 
         // ------------------------------------------------------------------ B. field on this wave's tile
         if (Mv > 0) {  // uniform over the workgroup
-            const uint32_t j = wave * 32 + (lane & 31);  // dense sample index
+            // chunk 0 (ambient L1) starts streaming now; the d2r table is published by the first barrier below
+            gf::dma_to_lds(s.buf[par], pack + gf::HP_AMB1, 4 * 16 * 64, wave, lane);
+            __syncthreads();
+            const uint32_t j = wave * 32 + (lane & 31);      // dense sample index
             const bool active = (uint32_t)(wave * 32) < Mv;  // wave-uniform
             const bool valid = j < Mv;
-            const uint32_t raw = valid ? s.d2r[j] : 0u;
-            const uint32_t rloc = raw / n_step;
+            const uint32_t jj = valid ? j : (active ? (uint32_t)(wave * 32) : 0u);
+            const uint32_t raw = s.d2r[jj];
+            const uint32_t slot = s.rrank[jj];
 
             float pf[16], af[16], act[64];
             floatx16 h[4];
-            float ambient[2] = {0.0f, 0.0f};
+            float sigma = 0.0f;
+            const float* cur;
+#define GF_NEXT_CHUNK(SRC, NFLOATS)                                   \
+            __syncthreads(); /* chunk landed; previous chunk's readers are done */ \
+            cur = s.buf[par]; par ^= 1u;                               \
+            gf::dma_to_lds(s.buf[par], pack + (SRC), (NFLOATS), wave, lane);
+#define GF_LAST_CHUNK()                                               \
+            __syncthreads();                                          \
+            cur = s.buf[par]; par ^= 1u;
 
             if (active) {
                 const float b2 = 2 * a.bound;
                 const float x3[3] = {(s.sx[raw] + a.bound) / b2, (s.sy[raw] + a.bound) / b2, (s.sz[raw] + a.bound) / b2};
                 gf::encode_half<3>(a.pos_table, s.P + P_META, half, a.gridtype, a.interp, x3, pf);
-                // ambient L1 (3-D grid features; the cond_feat columns are folded into the bias)
-                gf::mfma_layer<4, 16, true, false>(s.W, lane, pf, s.P + P_AMBBIAS, h);
+            }
+            GF_NEXT_CHUNK(gf::HP_AMB2, 2 * 64 * 64)                       // -> ambient L2, out-blocks 0-1
+            if (active) {
+                gf::mfma_layer<4, 16, true, false>(cur, lane, pf, s.P + P_AMBBIAS, h);   // ambient L1 (cond_feat folded into the bias)
                 gf::unpack<4>(h, act);
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_AMB2, 4 * 64 * 64);
-            __syncthreads();
+            GF_NEXT_CHUNK(gf::HP_AMB2 + 2 * 64 * 64, 2 * 64 * 64)         // -> ambient L2, out-blocks 2-3
+            if (active) gf::mfma_part<4, 0, 2, 64, true, false>(cur, lane, act, nullptr, h);
+            GF_NEXT_CHUNK(gf::HP_SIG1, 4 * 32 * 64)                       // -> density L1
             if (active) {
-                gf::mfma_layer<4, 64, true, false>(s.W, lane, act, nullptr, h);
+                gf::mfma_part<4, 2, 2, 64, true, false>(cur, lane, act, nullptr, h);
                 gf::unpack<4>(h, act);
+                float ambient[2];
                 gf::valu_rows<2, 4>(s.P + P_SMALL + gf::HS_AMB3, half, act, ambient);
-                ambient[0] = tanhf(ambient[0]);
-                ambient[1] = tanhf(ambient[1]);
-                const float x2[2] = {(ambient[0] + 1.0f) / 2.0f, (ambient[1] + 1.0f) / 2.0f};
+                const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
                 gf::encode_half<2>(a.amb_table, s.P + P_META + 64, half, a.gridtype, a.interp, x2, af);
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_SIG1, 4 * 32 * 64);
-            __syncthreads();
+            GF_NEXT_CHUNK(gf::HP_SIG2, 2 * 64 * 64)                       // -> density L2, 0-1
             if (active) {
                 float in[32];
 #pragma unroll
                 for (int t = 0; t < 16; t++) { in[t] = pf[t]; in[16 + t] = af[t]; }
-                gf::mfma_layer<4, 32, true, false>(s.W, lane, in, nullptr, h);
+                gf::mfma_layer<4, 32, true, false>(cur, lane, in, nullptr, h);
                 gf::unpack<4>(h, act);
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_SIG2, 4 * 64 * 64);
-            __syncthreads();
-            float sigma = 0.0f;
+            GF_NEXT_CHUNK(gf::HP_SIG2 + 2 * 64 * 64, 2 * 64 * 64)         // -> density L2, 2-3
+            if (active) gf::mfma_part<4, 0, 2, 64, true, false>(cur, lane, act, nullptr, h);
+            GF_NEXT_CHUNK(gf::HP_SIG3, 2 * 64 * 64)                       // -> density L3 (geo), 0-1
             if (active) {
-                gf::mfma_layer<4, 64, true, false>(s.W, lane, act, nullptr, h);
+                gf::mfma_part<4, 2, 2, 64, true, false>(cur, lane, act, nullptr, h);
                 gf::unpack<4>(h, act);
                 float h0[1];
                 gf::valu_rows<1, 4>(s.P + P_SMALL + gf::HS_SIGROW, half, act, h0);
                 sigma = expf(h0[0]);  // trunc_exp forward: plain exp, no clamp (utils.py:41)
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_SIG3, 4 * 64 * 64);
-            __syncthreads();
+            GF_NEXT_CHUNK(gf::HP_SIG3 + 2 * 64 * 64, 2 * 64 * 64)         // -> density L3 (geo), 2-3
+            if (active) gf::mfma_part<4, 0, 2, 64, false, false>(cur, lane, act, nullptr, h);  // geometry feature: no activation
+            GF_NEXT_CHUNK(gf::HP_COL1S, 4 * 8 * 64)                       // -> colour L1, SH columns
             if (active) {
-                gf::mfma_layer<4, 64, false, false>(s.W, lane, act, nullptr, h);  // geometry feature: no activation
+                gf::mfma_part<4, 2, 2, 64, false, false>(cur, lane, act, nullptr, h);
                 gf::unpack<4>(h, act);
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_COL1S, 4 * 8 * 64);
-            __syncthreads();
+            GF_NEXT_CHUNK(gf::HP_COL1G, 2 * 64 * 64)                      // -> colour L1, geo columns, 0-1
             if (active) {
                 float sh[16], shh[8];
-                gf::sh4(s.rdx[rloc], s.rdy[rloc], s.rdz[rloc], sh);
+                gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
 #pragma unroll
                 for (int t = 0; t < 8; t++) shh[t] = half ? sh[8 + t] : sh[t];
-                gf::mfma_layer<4, 8, false, false>(s.W, lane, shh, s.P + P_SMALL + gf::HS_COLBIAS, h);  // bias = identity-code columns
+                gf::mfma_layer<4, 8, false, false>(cur, lane, shh, s.P + P_SMALL + gf::HS_COLBIAS, h);  // bias = identity-code columns
             }
-            __syncthreads();
-            stage_weights(s.W, pack + gf::HP_COL1G, 4 * 64 * 64);
-            __syncthreads();
+            GF_NEXT_CHUNK(gf::HP_COL1G + 2 * 64 * 64, 2 * 64 * 64)        // -> colour L1, geo columns, 2-3
+            if (active) gf::mfma_part<4, 0, 2, 64, true, true>(cur, lane, act, nullptr, h);
+            GF_LAST_CHUNK()
             if (active) {
-                gf::mfma_layer<4, 64, true, true>(s.W, lane, act, nullptr, h);
+                gf::mfma_part<4, 2, 2, 64, true, true>(cur, lane, act, nullptr, h);
                 gf::unpack<4>(h, act);
                 float c[3];
                 gf::valu_rows<3, 4>(s.P + P_SMALL + gf::HS_COL2, half, act, c);
-                if (valid && half == 0) {
-                    s.osig[raw] = sigma;
-                    s.orr[raw] = 1.0f / (1.0f + __expf(-c[0]));
-                    s.og[raw] = 1.0f / (1.0f + __expf(-c[1]));
+                if (valid && half == 0) {  // outputs reuse the position slots (every wave read its positions 11 barriers ago)
+                    s.sx[raw] = sigma;
+                    s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
+                    s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
                     s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
                 }
             }
+#undef GF_NEXT_CHUNK
+#undef GF_LAST_CHUNK
             __syncthreads();
         }
 
-        // ------------------------------------------------------------------ C. composite + survivor compaction
-        bool survive = false;
-        if (has_ray) {
+        // ------------------------------------------------------------------ C. composite, retire
+        bool survivor = false;
+        if (alive) {
             gf::RayAcc acc;
             acc.t = t_ray;
-            acc.weight_sum = a.weights_sum[ray];
-            acc.depth = a.depth[ray];
-            acc.r = a.image[(size_t)ray * 3 + 0];
-            acc.g = a.image[(size_t)ray * 3 + 1];
-            acc.b = a.image[(size_t)ray * 3 + 2];
-            const uint32_t base = tid * n_step;
-            uint32_t st = 0;
-            while (st < n_step) {
-                if (st >= cnt) break;  // the marcher produced no further sample (delta == 0 in the reference)
-                if (!gf::composite_sample(acc, s.osig[base + st], s.orr[base + st], s.og[base + st], s.ob[base + st], s.sdt[base + st],
-                                          s.st[base + st], a.T_thresh))
+            acc.weight_sum = s.p_ws[tid]; acc.depth = s.p_dep[tid];
+            acc.r = s.p_r[tid]; acc.g = s.p_g[tid]; acc.b = s.p_b[tid];
+            uint32_t done = s.p_done[tid];
+            const uint32_t base = rank * n;
+            bool died = false;
+            uint32_t d = 0;
+            for (uint32_t q = 0; q < cnt; q++) {
+                done++;
+                if (!gf::composite_sample(acc, s.sx[base + q], s.sy[base + q], s.sz[base + q], s.ob[base + q], s.sdt[base + q], s.st[base + q], a.T_thresh)) {
+                    died = true;  // T < T_thresh: terminates at this sample (raymarching.cu:1004)
+                    d = done;
                     break;
-                st++;
+                }
             }
-            survive = (st == n_step);
-            if (survive) a.rays_t[ray] = acc.t;
-            a.weights_sum[ray] = acc.weight_sum;
-            a.depth[ray] = acc.depth;
-            a.image[(size_t)ray * 3 + 0] = acc.r;
-            a.image[(size_t)ray * 3 + 1] = acc.g;
-            a.image[(size_t)ray * 3 + 2] = acc.b;
+            if (!died && cnt < req) {  // the marcher ran out: the next request finds nothing (raymarching.cu:977)
+                died = true;
+                d = done + 1;
+            }
+            const bool finished = !died && done == budget;
+            if (died || finished) {
+                a.weights_sum[ray] = acc.weight_sum;
+                a.depth[ray] = acc.depth;
+                a.image[(size_t)ray * 3 + 0] = acc.r; a.image[(size_t)ray * 3 + 1] = acc.g; a.image[(size_t)ray * 3 + 2] = acc.b;
+                if (finished) a.rays_t[ray] = t_ray;
+                if (died && a.phase == 0) atomicAdd(&s.hist[d], 1u);
+                survivor = finished && a.phase == 0;
+                s.p_ray[tid] = -1;
+            } else {
+                s.p_ws[tid] = acc.weight_sum; s.p_dep[tid] = acc.depth; s.p_r[tid] = acc.r; s.p_g[tid] = acc.g; s.p_b[tid] = acc.b;
+                s.p_t[tid] = t_ray;
+                s.p_done[tid] = done;
+            }
         }
-        if (wave < 2) {  // rays only live in the first 128 threads
-            const unsigned long long mask = __ballot(survive);
-            const uint32_t n = (uint32_t)__popcll(mask);
+        if (a.phase == 0 && wave < 2) {
+            const unsigned long long m = __ballot(survivor);
+            const uint32_t ns = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (lane == 0 && n) base = atomicAdd(&a.ctrl[gf::kCtrlAlive + a.iter + 1], n);
+            if (lane == 0 && ns) base = atomicAdd(&a.ctrl[gf::kCtrlNSurv], ns);
             base = __shfl(base, 0);
-            if (survive) a.alive_out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ray;
+            if (survivor) a.survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ray;
         }
+    }
+
+    __syncthreads();
+    if (a.phase == 0 && tid >= 1 && tid <= (int)a.max_steps) {
+        const uint32_t v = s.hist[tid];
+        if (v) atomicAdd(&a.ctrl[gf::kCtrlHist + tid], v);
+    }
+    if (tid == 0) {
+        atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], st_samples);
+        atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], st_rounds);
+        atomicAdd(&a.ctrl[gf::kCtrlTiles + a.phase], st_tiles);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- frame setup
 struct InitArgs {
+    gf::MarchParams mp;
     const float* rays_o_in; const float* rays_d_in;  // explicit rays, or NULL
     float pose[12]; float fx, fy, cx, cy; uint32_t img_w;
     const float* aabb; float min_near;
     float *rays_o, *rays_d, *nears, *fars, *rays_t, *weights_sum, *depth, *image;
-    int* alive; uint32_t* ctrl; uint32_t N;
+    int* hit_list; uint32_t* ctrl; uint32_t N;
 };
 
 __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < gf::kCtrlWords; i += 256) a.ctrl[i] = (i == gf::kCtrlAlive) ? a.N : 0u;
-    }
-    if (n >= a.N) return;
-    float ox, oy, oz, dx, dy, dz;
-    if (a.rays_o_in) {
-        ox = a.rays_o_in[(size_t)n * 3]; oy = a.rays_o_in[(size_t)n * 3 + 1]; oz = a.rays_o_in[(size_t)n * 3 + 2];
-        dx = a.rays_d_in[(size_t)n * 3]; dy = a.rays_d_in[(size_t)n * 3 + 1]; dz = a.rays_d_in[(size_t)n * 3 + 2];
-    } else {
-        // pinhole rays, pixel centres at +0.5, row-major pixels (utils.py:296-363): same operation order as the torch code
+    const int lane = threadIdx.x & 63;
+    bool hit = false, miss = false;
+    if (n < a.N) {
+        float ox, oy, oz, dx, dy, dz;
+        if (a.rays_o_in) {
+            ox = a.rays_o_in[(size_t)n * 3]; oy = a.rays_o_in[(size_t)n * 3 + 1]; oz = a.rays_o_in[(size_t)n * 3 + 2];
+            dx = a.rays_d_in[(size_t)n * 3]; dy = a.rays_d_in[(size_t)n * 3 + 1]; dz = a.rays_d_in[(size_t)n * 3 + 2];
+        } else {
+            // pinhole rays, pixel centres at +0.5, row-major pixels (utils.py:296-363), same operation order as the torch code
 #pragma clang fp contract(off)
-        const uint32_t row = n / a.img_w, col = n - row * a.img_w;
-        const float xs = ((float)col + 0.5f - a.cx) / a.fx, ys = ((float)row + 0.5f - a.cy) / a.fy, zs = 1.0f;
-        const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
-        const float ux = xs / nrm, uy = ys / nrm, uz = zs / nrm;
-        dx = ux * a.pose[0] + uy * a.pose[1] + uz * a.pose[2];
-        dy = ux * a.pose[4] + uy * a.pose[5] + uz * a.pose[6];
-        dz = ux * a.pose[8] + uy * a.pose[9] + uz * a.pose[10];
-        ox = a.pose[3]; oy = a.pose[7]; oz = a.pose[11];
+            const uint32_t row = n / a.img_w, col = n - row * a.img_w;
+            const float xs = ((float)col + 0.5f - a.cx) / a.fx, ys = ((float)row + 0.5f - a.cy) / a.fy, zs = 1.0f;
+            const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+            const float ux = xs / nrm, uy = ys / nrm, uz = zs / nrm;
+            dx = ux * a.pose[0] + uy * a.pose[1] + uz * a.pose[2];
+            dy = ux * a.pose[4] + uy * a.pose[5] + uz * a.pose[6];
+            dz = ux * a.pose[8] + uy * a.pose[9] + uz * a.pose[10];
+            ox = a.pose[3]; oy = a.pose[7]; oz = a.pose[11];
+        }
+        a.rays_o[(size_t)n * 3] = ox; a.rays_o[(size_t)n * 3 + 1] = oy; a.rays_o[(size_t)n * 3 + 2] = oz;
+        a.rays_d[(size_t)n * 3] = dx; a.rays_d[(size_t)n * 3 + 1] = dy; a.rays_d[(size_t)n * 3 + 2] = dz;
+        float near, far;
+        gf::near_far_from_aabb_1(ox, oy, oz, dx, dy, dz, a.aabb, a.min_near, near, far);
+        a.nears[n] = near;
+        a.fars[n] = far;
+        a.weights_sum[n] = 0.0f;
+        a.depth[n] = 0.0f;
+        a.image[(size_t)n * 3] = 0.0f; a.image[(size_t)n * 3 + 1] = 0.0f; a.image[(size_t)n * 3 + 2] = 0.0f;
+        // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there
+        float t = near, t_first = near;
+        const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far, 0.0f, 1u, t,
+                                           [&](uint32_t, float, float, float, float, float, float t_at) { t_first = t_at; });
+        a.rays_t[n] = t_first;
+        hit = got > 0;
+        miss = !hit;
     }
-    a.rays_o[(size_t)n * 3] = ox; a.rays_o[(size_t)n * 3 + 1] = oy; a.rays_o[(size_t)n * 3 + 2] = oz;
-    a.rays_d[(size_t)n * 3] = dx; a.rays_d[(size_t)n * 3 + 1] = dy; a.rays_d[(size_t)n * 3 + 2] = dz;
-    float near, far;
-    gf::near_far_from_aabb_1(ox, oy, oz, dx, dy, dz, a.aabb, a.min_near, near, far);
-    a.nears[n] = near;
-    a.fars[n] = far;
-    a.rays_t[n] = near;
-    a.weights_sum[n] = 0.0f;
-    a.depth[n] = 0.0f;
-    a.image[(size_t)n * 3] = 0.0f; a.image[(size_t)n * 3 + 1] = 0.0f; a.image[(size_t)n * 3 + 2] = 0.0f;
-    a.alive[n] = (int)n;
+    // rays with a sample -> hit list (order is irrelevant: rays are independent); rays without one terminate at index 1
+    const unsigned long long hm = __ballot(hit), mm = __ballot(miss);
+    const uint32_t nh = (uint32_t)__popcll(hm), nm = (uint32_t)__popcll(mm);
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (nh) base = atomicAdd(&a.ctrl[gf::kCtrlNHit], nh);
+        if (nm) atomicAdd(&a.ctrl[gf::kCtrlHist + 1], nm);
+    }
+    base = __shfl(base, 0);
+    if (hit) a.hit_list[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (int)n;
 }
 
 // head-only tail of NeRFRenderer.render (renderer.py:354-364): background blend, clamp, depth normalisation
@@ -357,8 +490,56 @@ int check_frame(const gf_frame_t* f) {
     if ((f->rays_o == nullptr) != (f->rays_d == nullptr)) return gf_set_error(GF_ERR_INVALID, "frame: rays_o and rays_d must both be given or both NULL");
     if (!f->rays_o && (uint64_t)f->img_h * f->img_w != f->n_rays) return gf_set_error(GF_ERR_INVALID, "frame: img_h*img_w != n_rays");
     if (f->max_steps == 0 || f->cascade == 0 || f->grid_size == 0 || f->grid_size > 1024) return gf_set_error(GF_ERR_INVALID, "frame: bad marcher configuration");
+    if (f->max_steps > gf::kMaxSteps) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u needs the op-by-op path", gf::kMaxSteps);
     if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "frame: gridtype/interp must be 0 or 1");
     return GF_OK;
+}
+
+int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 4 events around the two phase kernels */) {
+    const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
+    const uint32_t N = f->n_rays;
+    if (hipMemsetAsync(w.ctrl, 0, gf::kCtrlWords * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "frame: hipMemsetAsync failed");
+
+    InitArgs ia;
+    gf::fill_march_params(ia.mp, f->bitfield, f->bound, f->dt_gamma, f->max_steps, f->cascade, f->grid_size);
+    ia.rays_o_in = f->rays_o; ia.rays_d_in = f->rays_d;
+    for (int i = 0; i < 12; i++) ia.pose[i] = f->pose[i];
+    ia.fx = f->intrinsics[0]; ia.fy = f->intrinsics[1]; ia.cx = f->intrinsics[2]; ia.cy = f->intrinsics[3];
+    ia.img_w = f->img_w ? f->img_w : 1;
+    ia.aabb = f->aabb; ia.min_near = f->min_near;
+    ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.rays_t = w.rays_t;
+    ia.weights_sum = w.weights_sum; ia.depth = w.depth; ia.image = w.image; ia.hit_list = w.alive_b; ia.ctrl = w.ctrl; ia.N = N;
+    hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, 256u)), dim3(256), 0, s, ia);
+
+    HeadArgs ha;
+    ha.mp = ia.mp;
+    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
+        return gf_set_error(GF_ERR_INVALID, "frame: bad grid levels");
+    ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
+    ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
+    ha.rays_o = w.rays_o; ha.rays_d = w.rays_d; ha.fars = w.fars;
+    ha.rays_t = w.rays_t; ha.weights_sum = w.weights_sum; ha.depth = w.depth; ha.image = w.image;
+    ha.survivors = w.alive_a;
+    ha.ctrl = w.ctrl; ha.N = N; ha.max_steps = f->max_steps; ha.gridtype = f->gridtype; ha.interp = f->interp;
+    ha.T_thresh = f->T_thresh; ha.bound = f->bound;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_phase), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+            return gf_set_error(GF_ERR_HIP, "frame: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
+        attr_set = true;
+    }
+    // persistent grid: 2 workgroups per CU x 256 CUs, never more workgroups than pools' worth of rays
+    const uint32_t pools = gf_div_up(N, (uint32_t)kPool);
+    const uint32_t grid = pools < 512u ? pools : 512u;
+    for (uint32_t phase = 0; phase < 2; phase++) {
+        ha.phase = phase;
+        ha.queue = phase ? w.alive_a : w.alive_b;
+        if (ev) (void)hipEventRecord(ev[2 * phase], s);
+        hipLaunchKernelGGL(k_head_phase, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        if (ev) (void)hipEventRecord(ev[2 * phase + 1], s);
+    }
+    return gf_check_launch("render_head");
 }
 
 }  // namespace
@@ -367,7 +548,7 @@ GF_EXPORT uint64_t gf_frame_workspace_bytes(uint32_t n_rays) { return gf::carve_
 
 GF_EXPORT uint32_t gf_frame_ctrl_words(void) { return gf::kCtrlWords; }
 
-// Byte offset of the control block inside the workspace (n_alive / cumulative step / valid samples per iteration).
+// Byte offset of the control block inside the workspace (see frame.hpp for the word layout).
 GF_EXPORT uint64_t gf_frame_ctrl_offset(uint32_t n_rays) {
     char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);
     const gf::FrameWs w = gf::carve_workspace(base, n_rays);
@@ -376,66 +557,13 @@ GF_EXPORT uint64_t gf_frame_ctrl_offset(uint32_t n_rays) {
 
 GF_EXPORT uint64_t gf_frame_sizeof(void) { return sizeof(gf_frame_t); }
 
-namespace {
-
-int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 2*(iters)+... */, uint32_t* n_iters_out) {
-    const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
-    const uint32_t N = f->n_rays;
-    InitArgs ia;
-    ia.rays_o_in = f->rays_o; ia.rays_d_in = f->rays_d;
-    for (int i = 0; i < 12; i++) ia.pose[i] = f->pose[i];
-    ia.fx = f->intrinsics[0]; ia.fy = f->intrinsics[1]; ia.cx = f->intrinsics[2]; ia.cy = f->intrinsics[3];
-    ia.img_w = f->img_w ? f->img_w : 1;
-    ia.aabb = f->aabb; ia.min_near = f->min_near;
-    ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.rays_t = w.rays_t;
-    ia.weights_sum = w.weights_sum; ia.depth = w.depth; ia.image = w.image; ia.alive = w.alive_a; ia.ctrl = w.ctrl; ia.N = N;
-    hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, 256u)), dim3(256), 0, s, ia);
-
-    HeadArgs ha;
-    gf::fill_march_params(ha.mp, f->bitfield, f->bound, f->dt_gamma, f->max_steps, f->cascade, f->grid_size);
-    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
-        return gf_set_error(GF_ERR_INVALID, "frame: bad grid levels");
-    ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
-    ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
-    ha.rays_o = w.rays_o; ha.rays_d = w.rays_d; ha.fars = w.fars;
-    ha.rays_t = w.rays_t; ha.weights_sum = w.weights_sum; ha.depth = w.depth; ha.image = w.image;
-    ha.ctrl = w.ctrl; ha.N = N; ha.max_steps = f->max_steps; ha.gridtype = f->gridtype; ha.interp = f->interp;
-    ha.T_thresh = f->T_thresh; ha.bound = f->bound;
-
-    // the n_step schedule needs at most max_steps iterations (n_step >= 1); every launch past the last live one exits at once
-    const uint32_t iters = f->max_steps < gf::kMaxIters ? f->max_steps : gf::kMaxIters;
-    const size_t smem = (size_t)kSmemFloats * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_iter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "frame: cannot raise the dynamic LDS limit to %zu bytes", smem);
-        attr_set = true;
-    }
-    // persistent grid: 2 workgroups per CU x 256 CUs, capped by the number of ray groups in the busiest iteration
-    const uint32_t max_groups = gf_div_up(N, (uint32_t)(kPass / 8)) ;  // upper bound over every n_step (n_alive*n_step <= N)
-    const uint32_t grid = max_groups < 512u ? max_groups : 512u;
-    for (uint32_t it = 0; it < iters; it++) {
-        ha.iter = it;
-        ha.alive_in = (it & 1) ? w.alive_b : w.alive_a;
-        ha.alive_out = (it & 1) ? w.alive_a : w.alive_b;
-        if (ev) (void)hipEventRecord(ev[2 * it], s);
-        hipLaunchKernelGGL(k_head_iter, dim3(grid), dim3(kThreads), smem, s, ha);
-        if (ev) (void)hipEventRecord(ev[2 * it + 1], s);
-    }
-    if (n_iters_out) *n_iters_out = iters;
-    return gf_check_launch("render_head");
-}
-
-}  // namespace
-
 // Head pass (NeRFRenderer.render inference branch up to the background blend): fills the workspace accumulators.
 // When f->torso_pack == NULL the head-only tail (bg blend, clamp, depth) is also enqueued and the outputs are final.
 GF_EXPORT int gf_render_head(const gf_frame_t* f, void* stream) {
     int rc = check_frame(f);
     if (rc) return rc;
-    if (f->max_steps > gf::kMaxIters) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u needs the op-by-op path", gf::kMaxIters);
     hipStream_t s = gf_stream(stream);
-    rc = launch_head(f, s, nullptr, nullptr);
+    rc = launch_head(f, s, nullptr);
     if (rc) return rc;
     if (!f->torso_pack) {
         if (!f->bg_color || !f->out_rgb || !f->out_depth) return gf_set_error(GF_ERR_INVALID, "frame: null output / background pointer");
@@ -447,28 +575,26 @@ GF_EXPORT int gf_render_head(const gf_frame_t* f, void* stream) {
     return GF_OK;
 }
 
-// Same work as gf_render_head's march iterations, bracketed by HIP events on `stream`; synchronises, then reports each
-// iteration kernel's duration (ms).  iter_ms_host must hold kMaxIters floats.  For measurement only (bench.py roofline).
-GF_EXPORT int gf_render_head_timed(const gf_frame_t* f, void* stream, float* iter_ms_host, uint32_t* n_iters_host) {
+// Same work as gf_render_head's two field kernels, bracketed by HIP events on `stream`; synchronises, then reports
+// their durations (ms): phase_ms_host[0] = first max_steps samples, [1] = the remaining B - max_steps.  Measurement only.
+GF_EXPORT int gf_render_head_timed(const gf_frame_t* f, void* stream, float* phase_ms_host, uint32_t* n_phases_host) {
     int rc = check_frame(f);
     if (rc) return rc;
-    if (f->max_steps > gf::kMaxIters) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u", gf::kMaxIters);
-    static hipEvent_t ev[2 * gf::kMaxIters];
+    static hipEvent_t ev[4];
     static bool made = false;
     if (!made) {
         for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return gf_set_error(GF_ERR_HIP, "hipEventCreate failed");
         made = true;
     }
     hipStream_t s = gf_stream(stream);
-    uint32_t iters = 0;
-    rc = launch_head(f, s, ev, &iters);
+    rc = launch_head(f, s, ev);
     if (rc) return rc;
     if (hipStreamSynchronize(s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "hipStreamSynchronize failed");
-    for (uint32_t i = 0; i < iters; i++) {
+    for (uint32_t i = 0; i < 2; i++) {
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
-        iter_ms_host[i] = ms;
+        phase_ms_host[i] = ms;
     }
-    *n_iters_host = iters;
+    *n_phases_host = 2;
     return GF_OK;
 }

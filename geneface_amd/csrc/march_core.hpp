@@ -84,7 +84,9 @@ __device__ __forceinline__ int mip_from_dt(float dt, float Hf, float max_cascade
 }
 
 // March one ray from t (updated in place) for at most n_step occupied samples.
-// emit(step, x, y, z, dt, t_after) is called once per sample, in order.  Returns the sample count.
+// emit(step, x, y, z, dt, t_after, t_at) is called once per sample, in order (t_at = the ray parameter the sample was
+// taken at: restarting the march from t_at with noise 0 reproduces this sample and everything after it bit for bit).
+// Returns the sample count.
 template <typename Emit>
 __device__ __forceinline__ uint32_t march_ray(const MarchParams& p, float ox, float oy, float oz, float dx, float dy,
                                               float dz, float far, float noise, uint32_t n_step, float& t, Emit&& emit) {
@@ -114,8 +116,9 @@ __device__ __forceinline__ uint32_t march_ray(const MarchParams& p, float ox, fl
         const bool occ = p.grid[idx >> 3] & (1u << (idx & 7u));
 
         if (occ) {
+            const float t_at = t;
             t += dt;
-            emit(step, x, y, z, dt, t);
+            emit(step, x, y, z, dt, t, t_at);
             step++;
         } else {
             const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * p.rH * 2 - 1) * mip_bound - x) * rdx;

@@ -13,15 +13,20 @@ namespace gf {
 
 using floatx16 = __attribute__((ext_vector_type(16))) float;
 
-// bin[t] = this lane's B operand for step t.  bias = LDS vector in accumulator-layout order [ob][half][16], or nullptr.
-template <int NOB, int NSTEPS, bool RELU, bool ACCUM>
-__device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, int lane, const float (&bin)[NSTEPS],
-                                           const float* __restrict__ bias, floatx16 (&out)[NOB]) {
+// Out-blocks [OB0, OB0+NOBP) of a layer whose accumulator array has NOB blocks.  Wl points at the LDS stream of exactly these
+// NOBP blocks ([block][step/4][lane][step%4]).  bin[t] = this lane's B operand for step t.  bias = LDS vector of the WHOLE layer
+// in accumulator-layout order [ob][half][16], or nullptr.  ACCUM continues accumulating into out[] (used when a layer's K
+// range is split over two weight streams).
+template <int NOB, int OB0, int NOBP, int NSTEPS, bool RELU, bool ACCUM>
+__device__ __forceinline__ void mfma_part(const float* __restrict__ Wl, int lane, const float (&bin)[NSTEPS],
+                                          const float* __restrict__ bias, floatx16 (&out)[NOB]) {
     static_assert(NSTEPS % 4 == 0, "steps come in groups of four (one 16-byte LDS read)");
+    static_assert(OB0 + NOBP <= NOB, "block range");
     const float4* W4 = reinterpret_cast<const float4*>(Wl);
     const int half = lane >> 5;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ob++) {
+    for (int o = 0; o < NOBP; o++) {
+        const int ob = OB0 + o;
         floatx16 acc;
         if (ACCUM) {
             acc = out[ob];
@@ -38,7 +43,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, int lan
         }
 #pragma unroll
         for (int t4 = 0; t4 < NSTEPS / 4; t4++) {
-            const float4 w = W4[(ob * (NSTEPS / 4) + t4) * 64 + lane];
+            const float4 w = W4[(o * (NSTEPS / 4) + t4) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, bin[t4 * 4 + 0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, bin[t4 * 4 + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, bin[t4 * 4 + 2], acc, 0, 0, 0);
@@ -49,6 +54,25 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, int lan
             for (int r = 0; r < 16; r++) acc[r] = fmaxf(acc[r], 0.0f);
         }
         out[ob] = acc;
+    }
+}
+
+// whole layer from one stream
+template <int NOB, int NSTEPS, bool RELU, bool ACCUM>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, int lane, const float (&bin)[NSTEPS],
+                                           const float* __restrict__ bias, floatx16 (&out)[NOB]) {
+    mfma_part<NOB, 0, NOB, NSTEPS, RELU, ACCUM>(Wl, lane, bin, bias, out);
+}
+
+// Asynchronous L2/HBM -> LDS copy of `nfloats` (multiple of 256) contiguous floats by the whole 256-thread workgroup:
+// each wave-instruction moves 1 KiB (64 lanes x 16 B) without touching VGPRs; completion = this wave's vmcnt reaching 0
+// (a following __syncthreads() waits for it).  Destination is lane-linear, which is exactly the stream layout above.
+__device__ __forceinline__ void dma_to_lds(float* lds_dst, const float* __restrict__ gsrc, int nfloats, int wave, int lane) {
+    using gptr_t = __attribute__((address_space(1))) void*;
+    using lptr_t = __attribute__((address_space(3))) void*;
+    const int n_inst = nfloats >> 8;
+    for (int k = wave; k < n_inst; k += 4) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)k * 256 + lane * 4), (lptr_t)(lds_dst + k * 256), 16, 0, 0);
     }
 }
 

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(gf::MarchParams p, uint32
     float* dout = dirs + (size_t)n * n_step * 3;
     float* de = deltas + (size_t)n * n_step * 2;
     gf::march_ray(p, o[0], o[1], o[2], dx, dy, dz, fars[index], noises[n], n_step, t,
-                  [&](uint32_t s, float x, float y, float z, float dt, float t_after) {
+                  [&](uint32_t s, float x, float y, float z, float dt, float t_after, float) {
                       xo[s * 3 + 0] = x; xo[s * 3 + 1] = y; xo[s * 3 + 2] = z;
                       dout[s * 3 + 0] = dx; dout[s * 3 + 1] = dy; dout[s * 3 + 2] = dz;
                       de[s * 2 + 0] = dt; de[s * 2 + 1] = t_after;

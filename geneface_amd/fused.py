@@ -257,19 +257,25 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
         return results
 
 
-def schedule_from_ctrl(ctrl: torch.Tensor, N: int, max_steps: int):
-    """[(n_alive, n_step, n_valid_samples)] of the last frame, decoded from the device control block (forces a sync)."""
+def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
+    """Decode the device control block of the last frame (forces a sync).  `schedule` is the reference's per-iteration
+    (n_alive, n_step) list (renderer.py:330-351) replayed from the terminal-index histogram, `budget` the total number of
+    samples a never-terminating ray receives; `budget_device` is the same number as the phase-1 kernel computed it."""
     c = ctrl.cpu().numpy().astype(np.int64)
-    K = 65
-    out, step = [], 0
-    for it in range(64):
-        n_alive = int(c[it])
-        if n_alive <= 0 or step >= max_steps:
+    hist = c[16:16 + max_steps + 2]
+    sched, cum, dead, d = [], 0, 0, 0
+    while cum < max_steps:
+        while d < cum:
+            d += 1
+            dead += int(hist[d])
+        n_alive = N - dead
+        if n_alive <= 0:
             break
         n_step = max(min(N // n_alive, 8), 1)
-        out.append((n_alive, n_step, int(c[2 * K + it])))
-        step += n_step
-    return out
+        sched.append((n_alive, n_step))
+        cum += n_step
+    return {"schedule": sched, "budget": cum, "budget_device": int(c[10]), "n_hit": int(c[1]), "n_survivors": int(c[2]),
+            "samples": (int(c[4]), int(c[5])), "rounds": (int(c[6]), int(c[7])), "tiles": (int(c[8]), int(c[9]))}
 
 
 # --------------------------------------------------------------------------------------------- frame-loop step
@@ -326,26 +332,31 @@ def render_frame_fused(pipe, i):
 
 
 def profile_frames(pipe, first, n_frames, flop_per_sample, peak_tflops):
-    """bench.py roofline leg: time every launch of the dominant kernel (the per-iteration head kernel) with HIP events
-    on the stream it runs on, and divide the algorithmic FLOPs of the samples it evaluated by that time."""
-    iter_ms = (C.c_float * 64)()
-    n_it = C.c_uint32(0)
+    """bench.py roofline leg: time every launch of the dominant kernel (k_head_phase: march + field + composite; two launches
+    per frame) with HIP events on the stream it runs on, and divide the algorithmic FLOPs of the samples it evaluated by
+    that time."""
+    phase_ms = (C.c_float * 4)()
+    n_ph = C.c_uint32(0)
     tot_ms, tot_samples, launches, per_frame = 0.0, 0, 0, []
     N = pipe.H * pipe.W
     with torch.no_grad():
         for i in range(first, first + n_frames):
             f = GfFrame()
             st, bufs, keep = _fill_pose_frame(pipe, i, f, None)
-            check(lib().gf_render_head_timed(C.byref(f), current_stream(pipe.device), iter_ms, C.byref(n_it)))
-            sched = schedule_from_ctrl(st.workspace(N)[1], N, pipe.hp["max_steps"])
-            ms = sum(iter_ms[k] for k in range(len(sched)))
-            samples = sum(v for _, _, v in sched)
+            check(lib().gf_render_head_timed(C.byref(f), current_stream(pipe.device), phase_ms, C.byref(n_ph)))
+            fs = frame_stats(st.workspace(N)[1], N, pipe.hp["max_steps"])
+            ms = phase_ms[0] + phase_ms[1]
+            samples = fs["samples"][0] + fs["samples"][1]
             tot_ms += ms
             tot_samples += samples
-            launches += len(sched)
-            per_frame.append({"iters": len(sched), "samples": samples, "n_step": [s for _, s, _ in sched], "kernel_ms": round(ms, 4)})
+            launches += 2
+            per_frame.append({"phase_ms": [round(phase_ms[0], 4), round(phase_ms[1], 4)], "samples": list(fs["samples"]),
+                              "tiles": list(fs["tiles"]), "rounds": list(fs["rounds"]), "budget": fs["budget_device"],
+                              "reference_schedule": fs["schedule"], "n_hit": fs["n_hit"], "n_survivors": fs["n_survivors"]})
     achieved = tot_samples * flop_per_sample / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    tiles = sum(sum(p["tiles"]) for p in per_frame)
     return {"bound": "mfma", "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved / peak_tflops,
-            "traffic": None, "kernel": "k_head_iter (march + field + composite, one launch per march iteration)",
-            "launches": launches, "avg_launch_ms": tot_ms / max(launches, 1), "samples_per_frame": tot_samples / max(n_frames, 1),
+            "traffic": None, "kernel": "k_head_phase (march + field + composite; 2 launches per frame)",
+            "launches": launches, "avg_launch_ms": tot_ms / max(launches, 1), "kernel_ms_per_frame": tot_ms / max(n_frames, 1),
+            "samples_per_frame": tot_samples / max(n_frames, 1), "tile_fill": tot_samples / max(32 * tiles, 1),
             "flop_per_sample": flop_per_sample, "frames_profiled": n_frames, "example_frame": per_frame[0] if per_frame else None}
