@@ -30,12 +30,12 @@ def headers():
     return sorted(glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")))
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
+    obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
     newest = max(os.path.getmtime(p) for p in [src, __file__, *headers()])
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC, *COMMON, "-x", "hip", "-c", src, "-o", obj, "-I", HERE, "-I", os.path.join(HERE, "..", "..", "include")]
+    cmd = [HIPCC, *COMMON, *extra, "-x", "hip", "-c", src, "-o", obj, "-I", HERE, "-I", os.path.join(HERE, "..", "..", "include")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -44,20 +44,25 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, trace: bool = False) -> str:
+    """trace=True builds the instrumented variant (-DGF_TRACE: per-round s_memtime timeline of the head kernel, read by
+    tools/trace_head.py) into libgeneface_hip_trace.so; the product library never contains the instrumentation."""
+    obj_dir = OBJ_DIR + ("_trace" if trace else "")
+    out = OUT.replace(".so", "_trace.so") if trace else OUT
+    extra = ("-DGF_TRACE",) if trace else ()
+    os.makedirs(obj_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), sources()))
+        results = list(ex.map(lambda s: _compile(s, force, extra, obj_dir), sources()))
     objs = [o for o, _ in results]
-    if force or any(ch for _, ch in results) or not os.path.exists(OUT):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+    if force or any(ch for _, ch in results) or not os.path.exists(out):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print("linked", OUT)
-    return OUT
+            print("linked", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv))

@@ -47,6 +47,20 @@ constexpr int kBufFloats = 8192;      // one 32 KB weight buffer
 constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 128 /*level meta: 2 grids x 16 x {scale,res,off,rows}*/;
 constexpr int kHistBins = gf::kMaxSteps + 2;
 
+// ---- optional per-round timeline (built only with -DGF_TRACE into libgeneface_hip_trace.so; see tools/trace_head.py) ----
+#ifdef GF_TRACE
+constexpr int kTraceSlots = 40, kTraceRounds = 48, kTraceWGs = 16;
+static uint32_t* g_trace_buf = nullptr;
+#define GF_STAMP(i)                                                              \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        if (tid == 0) s.tr[(i)] = (uint32_t)__builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define GF_STAMP(i) do { } while (0)
+#endif
+
 struct HeadArgs {
     gf::MarchParams mp;
     gf::GridLevels lv3, lv2;
@@ -60,6 +74,9 @@ struct HeadArgs {
     uint32_t* ctrl;
     uint32_t N, phase, max_steps, gridtype, interp;
     float T_thresh, bound;
+#ifdef GF_TRACE
+    uint32_t* trace;
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------------- LDS carve
@@ -73,8 +90,15 @@ struct Smem {
     uint8_t *d2r, *rcnt, *rbase, *rrank;
     uint32_t* hist;  // [kHistBins]
     uint32_t* misc;  // [16]
+#ifdef GF_TRACE
+    uint32_t* tr;    // [kTraceSlots]
+#endif
 };
+#ifdef GF_TRACE
+constexpr int kSmemBytes = (2 * kBufFloats + kPFloats + 15 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass + 4 * kTraceSlots;
+#else
 constexpr int kSmemBytes = (2 * kBufFloats + kPFloats + 15 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
+#endif
 static_assert(2 * kSmemBytes <= 160 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ Smem carve(char* base) {
@@ -94,6 +118,9 @@ __device__ __forceinline__ Smem carve(char* base) {
     s.misc = reinterpret_cast<uint32_t*>(f); f += 16;
     uint8_t* b = reinterpret_cast<uint8_t*>(f);
     s.d2r = b; s.rcnt = b + kPass; s.rbase = b + 2 * kPass; s.rrank = b + 3 * kPass;
+#ifdef GF_TRACE
+    s.tr = reinterpret_cast<uint32_t*>(b + 4 * kPass);
+#endif
     return s;
 }
 constexpr int P_SMALL = 0, P_AMBBIAS = gf::HS_TOTAL, P_META = gf::HS_TOTAL + 128;
@@ -136,7 +163,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         limit = a.ctrl[gf::kCtrlNSurv];
     }
     if (budget == 0 || limit == 0) return;
-    if ((uint32_t)blockIdx.x * kPool >= limit) return;  // not even one refill's worth of work for this workgroup
+    // Rays per pool: a full pool (128 rays, 1 sample per ray and round) when there is plenty of work, but when the queue is short
+    // (phase 1: a few thousand survivors that each need B - max_steps more samples) spread it over the whole grid and give
+    // every ray up to 8 samples per round instead of walking 128 rays through B - max_steps rounds on a handful of CUs.
+    uint32_t pool_cap = (limit + gridDim.x - 1) / gridDim.x;
+    pool_cap = pool_cap < 16u ? 16u : (pool_cap > (uint32_t)kPool ? (uint32_t)kPool : pool_cap);
+    if ((uint32_t)blockIdx.x * pool_cap >= limit) return;  // not even one refill's worth of work for this workgroup
 
     for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
     if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
@@ -157,12 +189,16 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     uint32_t st_samples = 0, st_rounds = 0, st_tiles = 0;  // statistics (thread 0)
     bool queue_open = true;         // uniform
 
+#ifdef GF_TRACE
+    uint32_t tr_round = 0;
+#endif
     for (;;) {
         __syncthreads();  // previous round fully retired (pool, staging)
+        GF_STAMP(0);
         // ------------------------------------------------------------------ refill empty pool slots from the queue
         int ray = owner ? s.p_ray[tid] : -1;
         if (queue_open && wave < 2) {  // wave-uniform branch
-            const bool want = ray < 0;
+            const bool want = ray < 0 && (uint32_t)tid < pool_cap;
             const unsigned long long m = __ballot(want);
             const uint32_t nw = (uint32_t)__popcll(m);
             uint32_t base = 0;
@@ -190,6 +226,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             }
             if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= limit) ? 1u : 0u;  // this wave saw the end of the queue
         }
+        GF_STAMP(1);
         // ------------------------------------------------------------------ pool census
         const bool alive = ray >= 0;
         unsigned long long amask = 0;
@@ -198,6 +235,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             if (lane == 0) s.misc[wave] = (uint32_t)__popcll(amask);
         }
         __syncthreads();
+        GF_STAMP(2);
         const uint32_t n_pool = s.misc[0] + s.misc[1];
         if (queue_open && (s.misc[4] | s.misc[5])) queue_open = false;
         if (n_pool == 0) {
@@ -221,8 +259,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                                     s.sdt[base + q] = dt; s.st[base + q] = t_after;
                                 });
         }
+        GF_STAMP(3);
         if (owner) s.rcnt[tid] = (uint8_t)cnt;
         __syncthreads();
+        GF_STAMP(4);
         if (wave == 0) {  // exclusive scan of 128 counts, two per lane
             const uint32_t c0 = s.rcnt[2 * lane], c1 = s.rcnt[2 * lane + 1];
             uint32_t incl = c0 + c1;
@@ -243,12 +283,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             for (uint32_t q = 0; q < cnt; q++) { s.d2r[b + q] = (uint8_t)(rank * n + q); s.rrank[b + q] = (uint8_t)tid; }
         }
         if (tid == 0) { st_samples += Mv; st_rounds++; st_tiles += (Mv + 31) / 32; }
+        GF_STAMP(5);
 
         // ------------------------------------------------------------------ B. field on this wave's tile
         if (Mv > 0) {  // uniform over the workgroup
             // chunk 0 (ambient L1) starts streaming now; the d2r table is published by the first barrier below
             gf::dma_to_lds(s.buf[par], pack + gf::HP_AMB1, 4 * 16 * 64, wave, lane);
             __syncthreads();
+            GF_STAMP(6);
             const uint32_t j = wave * 32 + (lane & 31);      // dense sample index
             const bool active = (uint32_t)(wave * 32) < Mv;  // wave-uniform
             const bool valid = j < Mv;
@@ -260,12 +302,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             floatx16 h[4];
             float sigma = 0.0f;
             const float* cur;
+            [[maybe_unused]] int tr_i = 7;
 #define GF_NEXT_CHUNK(SRC, NFLOATS)                                   \
+            GF_STAMP(tr_i); tr_i++;                                    \
             __syncthreads(); /* chunk landed; previous chunk's readers are done */ \
+            GF_STAMP(tr_i); tr_i++;                                    \
             cur = s.buf[par]; par ^= 1u;                               \
             gf::dma_to_lds(s.buf[par], pack + (SRC), (NFLOATS), wave, lane);
 #define GF_LAST_CHUNK()                                               \
+            GF_STAMP(tr_i); tr_i++;                                    \
             __syncthreads();                                          \
+            GF_STAMP(tr_i); tr_i++;                                    \
             cur = s.buf[par]; par ^= 1u;
 
             if (active) {
@@ -339,8 +386,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             }
 #undef GF_NEXT_CHUNK
 #undef GF_LAST_CHUNK
+            GF_STAMP(31);
             __syncthreads();
         }
+        GF_STAMP(32);
 
         // ------------------------------------------------------------------ C. composite, retire
         bool survivor = false;
@@ -388,6 +437,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             base = __shfl(base, 0);
             if (survivor) a.survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ray;
         }
+        GF_STAMP(33);
+#ifdef GF_TRACE
+        if (tid == 0) { s.tr[34] = Mv; s.tr[35] = n_pool; s.tr[36] = n; s.tr[37] = __builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */); }
+        __syncthreads();
+        if (a.trace && blockIdx.x < kTraceWGs && tr_round < kTraceRounds && tid < kTraceSlots)
+            a.trace[((a.phase * kTraceWGs + blockIdx.x) * kTraceRounds + tr_round) * kTraceSlots + tid] = s.tr[tid];
+        tr_round++;
+#endif
     }
 
     __syncthreads();
@@ -522,6 +579,9 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.survivors = w.alive_a;
     ha.ctrl = w.ctrl; ha.N = N; ha.max_steps = f->max_steps; ha.gridtype = f->gridtype; ha.interp = f->interp;
     ha.T_thresh = f->T_thresh; ha.bound = f->bound;
+#ifdef GF_TRACE
+    ha.trace = g_trace_buf;
+#endif
 
     static bool attr_set = false;
     if (!attr_set) {
@@ -543,6 +603,12 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
 }
 
 }  // namespace
+
+#ifdef GF_TRACE
+// trace build only: device buffer of 2 * kTraceWGs * kTraceRounds * kTraceSlots uint32 (phase, workgroup, round, slot)
+GF_EXPORT void gf_trace_set(void* dev_buf) { g_trace_buf = reinterpret_cast<uint32_t*>(dev_buf); }
+GF_EXPORT uint32_t gf_trace_dims(uint32_t which) { return which == 0 ? kTraceWGs : which == 1 ? kTraceRounds : kTraceSlots; }
+#endif
 
 GF_EXPORT uint64_t gf_frame_workspace_bytes(uint32_t n_rays) { return gf::carve_workspace(reinterpret_cast<void*>(uintptr_t(1) << 20), n_rays).bytes; }
 

@@ -11,7 +11,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgeneface_hip.so")
+# GF_HIP_LIB selects another build of the same library (tools/trace_head.py points it at the instrumented one)
+LIB_PATH = os.environ.get("GF_HIP_LIB") or os.path.join(_HERE, "csrc", "libgeneface_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "geneface_hip.h")
 
 _lock = threading.Lock()

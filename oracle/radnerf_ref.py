@@ -147,6 +147,22 @@ def torso_field(sd, hp, x, poses6, code):
 
 
 # ----------------------------------------------------------------------------- frame
+def _count_composited(n_alive, n_step, T_thresh, ws0, sigmas, deltas):
+    """How many of an iteration's marched samples the compositor actually consumes (it stops at the first empty slot and
+    after the sample at which T < T_thresh, raymarching.cu:977,1004) -- the lower bound on field evaluations any
+    schedule needs; `n_valid` (everything marched) is what the reference's schedule evaluates."""
+    M = n_alive * n_step
+    s, dt = sigmas[:M].view(n_alive, n_step), deltas[:M, 0].view(n_alive, n_step)
+    ws, live, cnt = ws0.clone(), torch.ones(n_alive, dtype=torch.bool), 0
+    for k in range(n_step):
+        valid = live & (dt[:, k] != 0)
+        T = 1 - ws
+        ws = torch.where(valid, ws + (1 - torch.exp(-s[:, k] * dt[:, k])) * T, ws)
+        cnt += int(valid.sum())
+        live = valid & ~(T < T_thresh)
+    return cnt
+
+
 def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace=None):
     N = rays_o.shape[0]
     cascade = 1 + math.ceil(math.log2(hp["bound"]))
@@ -165,7 +181,8 @@ def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh,
                                         cascade, hp["grid_size"], nears, fars, 128, dt_gamma, max_steps)
         sigmas, rgbs, _ = head_field(sd, hp, xyzs, dirs, cond_feat, ind_code)
         if trace is not None:
-            trace.append({"n_alive": n_alive, "n_step": n_step, "n_valid": int((deltas[:, 0] > 0).sum())})
+            trace.append({"n_alive": n_alive, "n_step": n_step, "n_valid": int((deltas[:, 0] > 0).sum()),
+                          "n_composited": _count_composited(n_alive, n_step, T_thresh, weights_sum[rays_alive.long()], sigmas, deltas)})
         RM.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(), deltas, weights_sum,
                           depth, image)
         rays_alive = rays_alive[rays_alive >= 0].contiguous()

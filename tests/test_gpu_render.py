@@ -79,8 +79,10 @@ def test_frame_256_vs_oracle(impl):
         assert fs["budget"] == fs["budget_device"] == sum(t["n_step"] for t in trace)
         for (a, _), t in zip(fs["schedule"], trace):
             assert abs(a - t["n_alive"]) <= max(3, 1e-3 * t["n_alive"]), (a, t["n_alive"])
-        total, want = sum(fs["samples"]), sum(t["n_valid"] for t in trace)
-        assert abs(total - want) <= max(16, 1e-3 * want), (total, want)   # field evaluations actually performed
+        # field evaluations actually performed: at least every sample the reference composites, at most every sample the
+        # reference marches (its iterations evaluate a dying ray's whole n_step chunk; the pool rounds waste fewer)
+        total, hi, lo = sum(fs["samples"]), sum(t["n_valid"] for t in trace), sum(t["n_composited"] for t in trace)
+        assert lo - max(16, 1e-3 * lo) <= total <= hi + max(16, 1e-3 * hi), (lo, total, hi)
         assert fs["n_hit"] == trace[1]["n_alive"] or abs(fs["n_hit"] - trace[0]["n_valid"]) == 0
     elif hasattr(model, "last_schedule") and model.last_schedule:
         # the n_step schedule is a discrete function of the alive counts: it must be identical; the counts themselves may

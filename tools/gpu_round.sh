@@ -1,0 +1,22 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench line, head-kernel timeline, rocprofv3 kernel stats, PMC passes.
+# usage: tools/gpu_round.sh <tag> [steps...]   (steps: test bench trace prof pmc; default all)
+set -u
+TAG=${1:-r1}; shift || true
+STEPS=${*:-test bench trace prof pmc}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for s in $STEPS; do
+  case $s in
+    test)  timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest.log; tail -3 $OUT/pytest.log ;;
+    bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
+    trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
+    prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160 ;;
+    pmc)   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmc_sq -o sq --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 > $OUT/pmc_sq.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 > $OUT/pmc_fetch.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o w --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 > $OUT/pmc_write.log 2>&1)
+           python tools/pmc_summary.py $OUT ;;
+  esac
+done

@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Per-round timeline of the head kernel (k_head_phase) from the instrumented build.
+
+    python -m geneface_amd.csrc.build --trace          # builds libgeneface_hip_trace.so (-DGF_TRACE)
+    python tools/trace_head.py [--size 512] [--frame 10]
+
+Thread 0 of the first 16 workgroups stamps s_memtime at every segment boundary of every round (frame_head.hip, GF_STAMP);
+this script renders one frame with that build and prints, per segment, the mean / p50 / p90 shader cycles over the traced
+rounds, so the share of a round spent in refill, march, scan, every weight-chunk barrier and every MFMA segment is
+visible.  Measurement tooling only: the product library carries no instrumentation.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["GF_HIP_LIB"] = os.path.join(ROOT, "geneface_amd", "csrc", "libgeneface_hip_trace.so")
+
+NAMES = {
+    (0, 1): "refill (queue atomic + ray loads)", (1, 2): "census barrier", (2, 3): "march", (3, 4): "barrier after march",
+    (4, 5): "scan + dense map", (5, 6): "dma chunk0 issue + barrier", (6, 7): "encode 3-D grid",
+    (7, 8): "BARRIER amb1", (8, 9): "mfma amb L1 (K=32)",
+    (9, 10): "BARRIER amb2a", (10, 11): "mfma amb L2 blocks 0-1",
+    (11, 12): "BARRIER amb2b", (12, 13): "mfma amb L2 blocks 2-3 + rows + tanh + encode 2-D",
+    (13, 14): "BARRIER sig1", (14, 15): "mfma sig L1 (K=64)",
+    (15, 16): "BARRIER sig2a", (16, 17): "mfma sig L2 blocks 0-1",
+    (17, 18): "BARRIER sig2b", (18, 19): "mfma sig L2 blocks 2-3 + sigma row + exp",
+    (19, 20): "BARRIER sig3a", (20, 21): "mfma sig L3 blocks 0-1",
+    (21, 22): "BARRIER sig3b", (22, 23): "mfma sig L3 blocks 2-3",
+    (23, 24): "BARRIER col1s", (24, 25): "SH + mfma col L1 SH part (K=16)",
+    (25, 26): "BARRIER col1g a", (26, 27): "mfma col L1 geo blocks 0-1",
+    (27, 28): "BARRIER col1g b (last)", (28, 31): "mfma col L1 geo blocks 2-3 + rgb rows + sigmoid",
+    (31, 32): "barrier end of field", (32, 33): "composite + retire",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--frame", type=int, default=10)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.fused import GfFrame, _fill_pose_frame, frame_stats
+    from geneface_amd.infer import FramePipeline
+    from geneface_amd.lib import check, current_stream, lib
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+
+    dev = torch.device("cuda", 0)
+    hp = HP.may_hparams(True)
+    seq = S.make_sequence(args.frame + 1, args.size, args.size, hp)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True), strict=True)
+    model = model.to(dev).eval()
+    pipe = FramePipeline(model, hp, seq, dev, impl="fused")
+    L = lib()
+    L.gf_trace_dims.restype = C.c_uint32
+    nwg, nrounds, nslots = (L.gf_trace_dims(C.c_uint32(i)) for i in range(3))
+    buf = torch.zeros(2 * nwg * nrounds * nslots, dtype=torch.int32, device=dev)
+    L.gf_trace_set.argtypes = [C.c_void_p]
+    for warm in range(3):
+        pipe.render_frame(args.frame)
+    torch.cuda.synchronize()
+    L.gf_trace_set(C.c_void_p(buf.data_ptr()))
+    buf.zero_()
+    with torch.no_grad():
+        f = GfFrame()
+        st, bufs, keep = _fill_pose_frame(pipe, args.frame, f, None)
+        ms = (C.c_float * 4)()
+        nph = C.c_uint32(0)
+        check(L.gf_render_head_timed(C.byref(f), current_stream(dev), ms, C.byref(nph)))
+    torch.cuda.synchronize()
+    N = args.size * args.size
+    fs = frame_stats(st.workspace(N)[1], N, hp["max_steps"])
+    t = buf.cpu().numpy().astype(np.int64).reshape(2, nwg, nrounds, nslots) & 0xFFFFFFFF
+    print(f"frame {args.frame} {args.size}x{args.size}: phase ms = {ms[0]:.3f} {ms[1]:.3f}; stats = {json.dumps(fs)}")
+    report = {"phase_ms": [ms[0], ms[1]], "stats": fs, "phases": []}
+    for ph in range(2):
+        tp = t[ph]
+        used = tp[:, :, 33] != 0
+        if not used.any():
+            continue
+        full = used & (tp[:, :, 34] >= 96)   # rounds with >= 3 full tiles of samples: the steady state
+        sel = full if full.any() else used
+        rounds = tp[sel]
+        total = (rounds[:, 33] - rounds[:, 0]) & 0xFFFFFFFF
+        print(f"\n== phase {ph}: {int(used.sum())} traced rounds over {nwg} workgroups, {int(sel.sum())} selected "
+              f"(Mv>=96: {bool(full.any())}); round = {total.mean():.0f} cycles mean, p50 {np.median(total):.0f}, p90 {np.percentile(total, 90):.0f}; "
+              f"Mv mean {rounds[:, 34].mean():.1f}, n_pool mean {rounds[:, 35].mean():.1f}, n mean {rounds[:, 36].mean():.2f}")
+        rows = []
+        for (a, b), name in NAMES.items():
+            d = (rounds[:, b] - rounds[:, a]) & 0xFFFFFFFF
+            ok = (rounds[:, a] != 0) & (rounds[:, b] != 0) & (d < (1 << 30))
+            if not ok.any():
+                continue
+            d = d[ok]
+            rows.append((name, float(d.mean()), float(np.median(d)), float(np.percentile(d, 90)), float(d.mean() / total.mean())))
+        for name, mean, p50, p90, share in rows:
+            print(f"  {name:58s} mean {mean:9.0f}  p50 {p50:9.0f}  p90 {p90:9.0f}  {100 * share:5.1f}%")
+        bar = sum(r[1] for r in rows if r[0].startswith("BARRIER"))
+        mf = sum(r[1] for r in rows if r[0].startswith("mfma") or r[0].startswith("SH"))
+        print(f"  -> weight-chunk barriers {100 * bar / total.mean():.1f}%  mfma segments {100 * mf / total.mean():.1f}% of the round")
+        # rounds per workgroup and the span of each workgroup's activity
+        per_wg = used.sum(axis=1)
+        print(f"  rounds per traced workgroup: {per_wg.tolist()}")
+        report["phases"].append({"phase": ph, "round_cycles_mean": float(total.mean()), "segments": rows})
+    if args.json:
+        with open(args.json, "w") as fh:
+            json.dump(report, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
