@@ -10,6 +10,7 @@ namespace gf {
 // ---------------- workspace carve-out (all offsets in bytes, 256-aligned) ----------------
 struct FrameWs {
     float *nears, *fars, *rays_t, *weights_sum, *depth, *image, *rays_o, *rays_d;
+    float* far_occ;  // min(far, exit of the occupancy bounding box): where marching may stop (no sample can lie beyond it)
     int32_t *alive_a, *alive_b;  // survivor list / hit list
     uint32_t* ctrl;  // [kCtrlWords]
     size_t bytes;
@@ -40,6 +41,7 @@ inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
     w.image = (float*)take(N * 12);
     w.rays_o = (float*)take(N * 12);
     w.rays_d = (float*)take(N * 12);
+    w.far_occ = (float*)take(N * 4);
     w.alive_a = (int32_t*)take(N * 4);
     w.alive_b = (int32_t*)take(N * 4);
     w.ctrl = (uint32_t*)take(kCtrlWords * 4);
@@ -48,22 +50,27 @@ inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
 }
 
 // ---------------- packed head weights (floats) ----------------
-// "big" chunks are MFMA A-operand streams: [out_block(4)][step/4][lane(64)][step%4], value =
-//   W[out_block*32 + (lane&31)][kmap(step, lane>>5)]   (see pack_head.cpp for every kmap)
+// Wave w of a head workgroup owns output features [32w, 32w+32) of every 128-wide layer.  Its weights are ONE contiguous
+// stream of MFMA A operands in consumption order, read straight from L2 into registers:
+//   stream[w][g][lane][i]  (g = 4-step group, i = step within the group)  =  W[row0 + 32w + (lane&31)][col0 + 8u + 4*(lane>>5) + i]
+// with u = g - (first group of the layer): step 4u+i of a layer consumes input features (8u+i, 8u+4+i), lane half h
+// supplying 8u+4h+i -- which are 4 consecutive floats of a sample's activation row in LDS (one ds_read_b128 per group).
 constexpr uint32_t kHidden = 128;
-constexpr uint32_t HP_AMB1 = 0;                         // K=32  (3-D grid features)      4*16*64
-constexpr uint32_t HP_AMB2 = HP_AMB1 + 4 * 16 * 64;     // K=128                          4*64*64
-constexpr uint32_t HP_SIG1 = HP_AMB2 + 4 * 64 * 64;     // K=64  (3-D | 2-D grid)         4*32*64
-constexpr uint32_t HP_SIG2 = HP_SIG1 + 4 * 32 * 64;     // K=128
-constexpr uint32_t HP_SIG3 = HP_SIG2 + 4 * 64 * 64;     // K=128 -> geo features (rows 1..128)
-constexpr uint32_t HP_COL1S = HP_SIG3 + 4 * 64 * 64;    // K=16  (SH part of colour L1)   4*8*64
-constexpr uint32_t HP_COL1G = HP_COL1S + 4 * 8 * 64;    // K=128 (geo part of colour L1)
-constexpr uint32_t HP_SMALL = HP_COL1G + 4 * 64 * 64;   // VALU layers + constant bias
-//   small block: rows in "C-layout order" [out_block(4)][half(2)][r(16)] = feature ob*32 + R0(r) + 4*half
-constexpr uint32_t HS_AMB3 = 0;        // [2][128]
-constexpr uint32_t HS_SIGROW = 256;    // [128]   density row (row 0 of sigma L3)
-constexpr uint32_t HS_COL2 = 384;      // [3][128]
-constexpr uint32_t HS_COLBIAS = 768;   // [128]   W_color0[:, 144:148] @ individual_code, C-layout order
+constexpr uint32_t G_AMB1 = 0;              // ambient L1, 3-D grid columns 0..31 (cond columns fold into amb_bias)     4 groups
+constexpr uint32_t G_SIG1A = G_AMB1 + 4;    // density L1, 3-D grid columns 0..31 (runs beside ambient L1)                4
+constexpr uint32_t G_AMB2 = G_SIG1A + 4;    // ambient L2                                                                 16
+constexpr uint32_t G_SIG1B = G_AMB2 + 16;   // density L1, 2-D grid columns 32..63                                        4
+constexpr uint32_t G_SIG2 = G_SIG1B + 4;    // density L2                                                                 16
+constexpr uint32_t G_SIG3 = G_SIG2 + 16;    // density L3 rows 1..128 (geometry feature)                                  16
+constexpr uint32_t G_COL1S = G_SIG3 + 16;   // colour L1, SH columns 0..15                                                2
+constexpr uint32_t G_COL1G = G_COL1S + 2;   // colour L1, geometry columns 16..143                                        16
+constexpr uint32_t G_TOTAL = G_COL1G + 16;  // 78 groups = 78 KiB per wave and round
+constexpr uint32_t HP_STREAM = 0;                                  // [4][G_TOTAL][64][4]
+constexpr uint32_t HP_SMALL = HP_STREAM + 4 * G_TOTAL * 256;       // VALU layers + constant bias
+constexpr uint32_t HS_AMB3 = 0;        // [2][128]  ambient L3 rows, natural feature order
+constexpr uint32_t HS_SIGROW = 256;    // [128]     density row (row 0 of density L3)
+constexpr uint32_t HS_COL2 = 384;      // [3][128]  colour L2 rows
+constexpr uint32_t HS_COLBIAS = 768;   // [128]     W_color0[:, 144:148] @ individual_code, accumulator-layout order [ob][half][16]
 constexpr uint32_t HS_TOTAL = 896;
 constexpr uint32_t HP_TOTAL = HP_SMALL + HS_TOTAL;
 

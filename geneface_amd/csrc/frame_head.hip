@@ -18,16 +18,20 @@
 // B - max_steps samples.  tests/test_gpu_render.py checks B, the alive counts and the sample totals against the oracle's
 // iteration trace.
 //
-// WORK DECOMPOSITION.  k_frame_init: one lane per ray -- ray generation, slab test, and the march through empty space up to
-// the first occupied sample (a latency-bound, high-occupancy kernel; rays that never hit anything are finished here).
-// k_head_phase: persistent 256-thread workgroups (2 per CU) each keep a pool of up to 128 live rays in LDS, refilled from
-// a global queue, and loop over rounds of <= 128 samples:
-//   A. march    : one lane per pooled ray, samples to LDS, wave-scan packs the valid ones densely
-//   B. field    : each of the 4 waves owns a 32-sample MFMA tile.  Activations stay in registers in the accumulator
-//                 layout of v_mfma_f32_32x32x2_f32, which is also a legal B-operand layout for the next layer, so layers
-//                 chain with no data movement; weights stream L2 -> LDS by asynchronous LDS-DMA in half-layer chunks
-//                 (two 32 KB buffers: chunk k+1 lands while chunk k feeds the MFMAs); the three skinny output layers
-//                 (->2, ->1, ->3) run on the VALU; grid lookups are split across the two 32-lane halves of the wave
+// WORK DECOMPOSITION.  k_frame_init: one lane per ray -- ray generation, slab test against aabb_infer and against the box
+// around the occupied cells (beyond which no sample can exist), and the march through empty space up to the first occupied
+// sample (a latency-bound, high-occupancy kernel; rays that never hit anything are finished here).
+// k_head_phase: persistent 256-thread workgroups (2 per CU) each keep a pool of up to 128 live rays -- state in the owning
+// lane's registers -- refilled from a global queue, and loop over rounds of <= 128 samples:
+//   A. march    : one lane per pooled ray (bounded slice of the traversal), samples to LDS, a wave scan packs them densely
+//   B. field    : the 128 samples' activations live in ONE LDS buffer H[128][128]; each wave OWNS 32 output features of
+//                 every 128-wide layer and computes them for all (up to four) 32-sample tiles on v_mfma_f32_32x32x2_f32:
+//                 A operand = its slice of the weights, streamed L2 -> registers (78 KiB per wave and round, consumption
+//                 order, one 1-KiB global_load_dwordx4 per 16 MFMAs, reused by the four tiles), B operand = activations, one
+//                 ds_read_b128 per tile and 4 MFMAs.  A layer ends with barrier / in-place write-back of the accumulators /
+//                 barrier.  No weight ever touches LDS, no activation ever leaves the CU, accumulators are the only large
+//                 register arrays (no spills); the three skinny layers (->2, ->1, ->3) and both grid lookups run on the
+//                 VALU with one lane pair per sample
 //   C. composite: the owning lane consumes its samples in order; finished rays write their accumulators once.
 #include "common.hpp"
 #include "frame.hpp"
@@ -35,26 +39,28 @@
 #include "grid_core.hpp"
 #include "sh_core.hpp"
 #include "mfma_mlp.hpp"
+#include <type_traits>
 
 namespace {
 
 using gf::floatx16;
 
 constexpr int kThreads = 256;
-constexpr int kPass = 128;            // sample slots per round (4 waves x 32-column MFMA tiles)
+constexpr int kPass = 128;            // sample slots per round (four 32-column MFMA tiles)
 constexpr int kPool = 128;            // live rays per workgroup
-constexpr int kBufFloats = 8192;      // one 32 KB weight buffer
-constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 128 /*level meta: 2 grids x 16 x {scale,res,off,rows}*/;
+constexpr int kHS = 132;              // floats per activation row (128 + 4: rows 16 B apart in bank space -> conflict-free b128)
+constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 2 * 16 * 8 /*level meta*/;
 constexpr int kHistBins = gf::kMaxSteps + 2;
+constexpr uint32_t kMarchSlack = 3;   // empty-space skips a ray may add to its requested samples per round
 
 // ---- optional per-round timeline (built only with -DGF_TRACE into libgeneface_hip_trace.so; see tools/trace_head.py) ----
 #ifdef GF_TRACE
-constexpr int kTraceSlots = 40, kTraceRounds = 48, kTraceWGs = 16;
+constexpr int kTraceSlots = 48, kTraceRounds = 48, kTraceWGs = 16;
 static uint32_t* g_trace_buf = nullptr;
 #define GF_STAMP(i)                                                              \
     do {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                       \
-        if (tid == 0) s.tr[(i)] = (uint32_t)__builtin_amdgcn_s_memtime();        \
+        if (threadIdx.x == 0) s.tr[(i)] = (uint32_t)__builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                       \
     } while (0)
 #else
@@ -67,7 +73,7 @@ struct HeadArgs {
     const float* pos_table; const int* pos_offsets;
     const float* amb_table; const int* amb_offsets;
     const float* head_pack; const float* amb_bias;
-    const float* rays_o; const float* rays_d; const float* fars;
+    const float* rays_o; const float* rays_d; const float* far_occ;
     float* rays_t; float* weights_sum; float* depth; float* image;
     const int* queue;   // phase 0: hit list, phase 1: survivor list
     int* survivors;     // phase 0 output
@@ -81,11 +87,10 @@ struct HeadArgs {
 
 // ---------------------------------------------------------------------------------------------------- LDS carve
 struct Smem {
-    float* buf[2];   // weight chunk double buffer
+    float* H;        // [kPass][kHS] activations of the round's samples
     float* P;        // VALU-layer rows, colour bias, ambient bias, per-level grid meta
-    // ray pool (slot = owner thread)
-    int* p_ray; float *p_ox, *p_oy, *p_oz, *p_dx, *p_dy, *p_dz, *p_t, *p_far, *p_ws, *p_dep, *p_r, *p_g, *p_b; uint32_t* p_done;
-    // per-round sample staging (raw slot = rank * n + s); outputs alias the positions
+    float *p_dx, *p_dy, *p_dz;   // [kPool] ray directions by pool slot (read by the SH evaluation of the slot's samples)
+    // per-round sample staging (raw slot = rank * n + s); field outputs alias the positions
     float *sx, *sy, *sz, *sdt, *st, *ob;
     uint8_t *d2r, *rcnt, *rbase, *rrank;
     uint32_t* hist;  // [kHistBins]
@@ -94,25 +99,20 @@ struct Smem {
     uint32_t* tr;    // [kTraceSlots]
 #endif
 };
+constexpr int kSmemBase = (kPass * kHS + kPFloats + 3 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
 #ifdef GF_TRACE
-constexpr int kSmemBytes = (2 * kBufFloats + kPFloats + 15 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass + 4 * kTraceSlots;
+constexpr int kSmemBytes = kSmemBase + 4 * kTraceSlots;
 #else
-constexpr int kSmemBytes = (2 * kBufFloats + kPFloats + 15 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
+constexpr int kSmemBytes = kSmemBase;
 #endif
 static_assert(2 * kSmemBytes <= 160 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ Smem carve(char* base) {
     Smem s;
     float* f = reinterpret_cast<float*>(base);
-    s.buf[0] = f; f += kBufFloats;
-    s.buf[1] = f; f += kBufFloats;
+    s.H = f; f += kPass * kHS;
     s.P = f; f += kPFloats;
-    s.p_ray = reinterpret_cast<int*>(f); f += kPool;
-    s.p_ox = f; f += kPool; s.p_oy = f; f += kPool; s.p_oz = f; f += kPool;
     s.p_dx = f; f += kPool; s.p_dy = f; f += kPool; s.p_dz = f; f += kPool;
-    s.p_t = f; f += kPool; s.p_far = f; f += kPool;
-    s.p_ws = f; f += kPool; s.p_dep = f; f += kPool; s.p_r = f; f += kPool; s.p_g = f; f += kPool; s.p_b = f; f += kPool;
-    s.p_done = reinterpret_cast<uint32_t*>(f); f += kPool;
     s.sx = f; f += kPass; s.sy = f; f += kPass; s.sz = f; f += kPass; s.sdt = f; f += kPass; s.st = f; f += kPass; s.ob = f; f += kPass;
     s.hist = reinterpret_cast<uint32_t*>(f); f += kHistBins;
     s.misc = reinterpret_cast<uint32_t*>(f); f += 16;
@@ -139,10 +139,293 @@ __device__ uint32_t replay_budget(const uint32_t* __restrict__ hist, uint32_t N,
     return c;
 }
 
+// ---------------------------------------------------------------------------------------------------- field building blocks
+// One 4-step group of A operands: wave-uniform stream base (SGPRs) + 32-bit lane offset -> global_load_dwordx4 v, v_off, s[base]
+__device__ __forceinline__ float4 load_group(const char* __restrict__ Ws, uint32_t g, uint32_t lane16) {
+    return *reinterpret_cast<const float4*>(Ws + (size_t)g * 1024 + (size_t)lane16);
+}
+
+// The stream is consumed strictly in order (frame.hpp: G_AMB1 .. G_COL1G), so three registers quads form a FIFO that runs
+// kWAhead groups (>= 2 x 16 MFMAs = 2048 cycles) ahead of the MFMAs, across layer boundaries and barriers: q[g % 3] holds
+// group g from the moment group g - 3 has been issued.
+constexpr int kWAhead = 3;
+struct WPipe { float4 q[kWAhead]; };
+
+template <int G>
+__device__ __forceinline__ float4 wpipe_take(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
+    return wp.q[G % kWAhead];
+}
+template <int G>
+__device__ __forceinline__ void wpipe_refill(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
+    if constexpr (G + kWAhead < (int)gf::G_TOTAL) wp.q[G % kWAhead] = load_group(Ws, G + kWAhead, lane16);
+}
+
+// U 4-step groups (first one = group G0 of this wave's stream Ws) of this wave's output block over NT sample tiles.
+// Hb = &H[lane & 31][col0 + 4 * (lane >> 5)]: tile t is 32 rows further, group u eight floats further.
+// Software pipeline, pinned with sched_barrier so the scheduler cannot sink the loads next to their use: while the 16 MFMAs
+// of group u issue, the B operands of group u+1 (LDS) and the A operands of group u+3 (L2) are in flight.
+template <int NT, int G0, int U, int u>
+__device__ __forceinline__ void obw_step(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4],
+                                         const float4 (&b)[NT]) {
+    if constexpr (u < U) {
+        float4 bn[NT];
+        if constexpr (u + 1 < U) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) bn[t] = *reinterpret_cast<const float4*>(Hb + t * 32 * kHS + 8 * (u + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 a = wpipe_take<G0 + u>(wp, Ws, lane16);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        wpipe_refill<G0 + u>(wp, Ws, lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        obw_step<NT, G0, U, u + 1>(wp, Ws, lane16, Hb, acc, bn);
+    }
+}
+template <int NT, int G0, int U>
+__device__ __forceinline__ void obw_mfma(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4]) {
+    float4 b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4*>(Hb + t * 32 * kHS);
+    __builtin_amdgcn_sched_barrier(0);
+    obw_step<NT, G0, U, 0>(wp, Ws, lane16, Hb, acc, b);
+}
+
+template <int NT>
+__device__ __forceinline__ void obw_zero(floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+}
+
+// bias16 = this lane's 16 entries of a bias vector stored in accumulator-layout order [out_block][half][16]
+template <int NT>
+__device__ __forceinline__ void obw_bias(const float* bias16, floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 b = reinterpret_cast<const float4*>(bias16)[q];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w; }
+    }
+}
+
+// Accumulator registers 4q..4q+3 of (lane half h) are features 32w + 8q + 4h + 0..3 of sample (lane & 31): one ds_write_b128.
+// Hw = &H[lane & 31][32 * wave + 4 * (lane >> 5)].
+template <int NT, bool RELU>
+__device__ __forceinline__ void obw_store(float* Hw, const floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
+        }
+}
+
+// NOUT skinny outputs of one sample on a lane pair: lane half h sums features 64h .. 64h+63 of the sample's row, the halves
+// are added with one cross-half exchange (both lanes end up with the same value).
+template <int NOUT>
+__device__ __forceinline__ void rows_from_lds(const float* Hrow, const float* rows, int half, float (&res)[NOUT]) {
+    float sum[NOUT];
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) sum[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float4 x = *reinterpret_cast<const float4*>(Hrow + 64 * half + 4 * i);
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) {
+            const float4 w = *reinterpret_cast<const float4*>(rows + c * 128 + 64 * half + 4 * i);
+            sum[c] = __builtin_fmaf(w.x, x.x, sum[c]);
+            sum[c] = __builtin_fmaf(w.y, x.y, sum[c]);
+            sum[c] = __builtin_fmaf(w.z, x.z, sum[c]);
+            sum[c] = __builtin_fmaf(w.w, x.w, sum[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) res[c] = sum[c] + __shfl_xor(sum[c], 32);
+}
+
+__device__ __forceinline__ void store16(float* dst, const float (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(dst)[q] = float4{f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+}
+
+// The field (radnerf.py:73-105) for the round's Mv densely packed samples, NT = ceil(Mv / 32) tiles.
+template <int NT>
+__device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    // lane-pair view (grid lookups, skinny layers): sample sI of this wave's tile
+    const uint32_t sI = (uint32_t)(wave * 32 + j);
+    const bool tile_on = wave < NT;   // wave-uniform: this wave's tile holds samples
+    const bool valid = sI < Mv;
+    const uint32_t sC = valid ? sI : (uint32_t)(wave * 32);   // a valid stand-in inside an active tile
+    const uint32_t raw = tile_on ? s.d2r[sC] : 0u;
+    float* Hrow = s.H + sI * kHS;
+    // MFMA view: B-operand / write-back bases of sample column j
+    const float* Hb = s.H + j * kHS + 4 * half;
+    float* Hw = s.H + j * kHS + 32 * wave + 4 * half;
+    const char* Ws = reinterpret_cast<const char*>(a.head_pack + gf::HP_STREAM) + (size_t)wave * gf::G_TOTAL * 1024;   // wave-uniform
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    // Opaque to the optimiser: otherwise it folds base + lane into one 64-bit VGPR address per group (78 of them), hoists
+    // them all out of the round loop and spills them.  Kept symbolic, every load is `global_load v, v_lane16, s[base] offset`.
+    asm volatile("" : "+v"(lane16));
+    const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
+
+    floatx16 A[4], S[4];
+    WPipe wp;
+#pragma unroll
+    for (int g = 0; g < kWAhead; g++) wp.q[g] = load_group(Ws, g, lane16);   // lands while the grid lookups run
+
+    // ---- 3-D grid features -> H[:, 0:32]
+    if (tile_on) {
+        const float b2 = 2 * a.bound;
+        const float x3[3] = {(s.sx[raw] + a.bound) / b2, (s.sy[raw] + a.bound) / b2, (s.sz[raw] + a.bound) / b2};
+        float pf[16];
+        gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
+        store16(Hrow + 16 * half, pf);
+    }
+    GF_STAMP(7);
+    __syncthreads();
+    GF_STAMP(8);
+    // ---- ambient L1 (cond_feat folded into the bias) and the 3-D half of density L1, both from H[:, 0:32]
+    obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
+    obw_zero<NT>(S);
+    obw_mfma<NT, gf::G_AMB1, 4>(wp, Ws, lane16, Hb, A);
+    obw_mfma<NT, gf::G_SIG1A, 4>(wp, Ws, lane16, Hb, S);
+    GF_STAMP(9);
+    __syncthreads();
+    GF_STAMP(10);
+    obw_store<NT, true>(Hw, A);
+    GF_STAMP(11);
+    __syncthreads();
+    GF_STAMP(12);
+    // ---- ambient L2
+    obw_zero<NT>(A);
+    obw_mfma<NT, gf::G_AMB2, 16>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(13);
+    __syncthreads();
+    GF_STAMP(14);
+    obw_store<NT, true>(Hw, A);
+    GF_STAMP(15);
+    __syncthreads();
+    GF_STAMP(16);
+    // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 0:32]  (a lane pair only touches its own sample's row)
+    if (tile_on) {
+        float ambient[2];
+        rows_from_lds<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+        const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
+        float af[16];
+        gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
+        store16(Hrow + 16 * half, af);
+    }
+    GF_STAMP(17);
+    __syncthreads();
+    GF_STAMP(18);
+    // ---- density L1, 2-D half
+    obw_mfma<NT, gf::G_SIG1B, 4>(wp, Ws, lane16, Hb, S);
+    GF_STAMP(19);
+    __syncthreads();
+    GF_STAMP(20);
+    obw_store<NT, true>(Hw, S);
+    GF_STAMP(21);
+    __syncthreads();
+    GF_STAMP(22);
+    // ---- density L2
+    obw_zero<NT>(A);
+    obw_mfma<NT, gf::G_SIG2, 16>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(23);
+    __syncthreads();
+    GF_STAMP(24);
+    obw_store<NT, true>(Hw, A);
+    GF_STAMP(25);
+    __syncthreads();
+    GF_STAMP(26);
+    // ---- density L3: row 0 on the VALU (sigma = exp, trunc_exp forward has no clamp: utils.py:41), rows 1..128 = geometry feature
+    float sigma = 0.0f;
+    if (tile_on) {
+        float h0[1];
+        rows_from_lds<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+        sigma = expf(h0[0]);
+    }
+    obw_zero<NT>(A);
+    obw_mfma<NT, gf::G_SIG3, 16>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(27);
+    __syncthreads();
+    GF_STAMP(28);
+    obw_store<NT, false>(Hw, A);   // no activation
+    GF_STAMP(29);
+    __syncthreads();
+    GF_STAMP(30);
+    // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
+    obw_bias<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
+    {
+        float shb[NT][8];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            uint32_t d = (uint32_t)(t * 32 + j);
+            d = d < Mv ? d : Mv - 1u;
+            const uint32_t slot = s.rrank[d];
+            float sh[16];
+            gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) shb[t][4 * u + i] = half ? sh[8 * u + 4 + i] : sh[8 * u + i];
+        }
+        auto sh_group = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const float4 w4 = wpipe_take<gf::G_COL1S + u>(wp, Ws, lane16);
+#pragma unroll
+            for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, shb[t][4 * u + 0], A[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, shb[t][4 * u + 1], A[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, shb[t][4 * u + 2], A[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, shb[t][4 * u + 3], A[t], 0, 0, 0);
+            wpipe_refill<gf::G_COL1S + u>(wp, Ws, lane16);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        sh_group(std::integral_constant<int, 0>{});
+        sh_group(std::integral_constant<int, 1>{});
+    }
+    obw_mfma<NT, gf::G_COL1G, 16>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(31);
+    __syncthreads();
+    GF_STAMP(32);
+    obw_store<NT, true>(Hw, A);
+    GF_STAMP(33);
+    __syncthreads();
+    GF_STAMP(34);
+    // ---- colour L2 + sigmoid; outputs reuse the position slots (read before the first barrier of this function)
+    if (tile_on) {
+        float c[3];
+        rows_from_lds<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+        if (valid && half == 0) {
+            s.sx[raw] = sigma;
+            s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
+            s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
+            s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
+        }
+    }
+    GF_STAMP(35);
+    __syncthreads();
+    GF_STAMP(36);
+}
+
 __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: per-wave weight-stream bases stay in SGPRs
     const bool owner = tid < kPool;
 
     // ---- phase set-up (uniform) ----
@@ -173,30 +456,28 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
     if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
     if (tid < 32) {
-        const int g = tid >> 4, l = tid & 15;
-        const int* off = g ? a.amb_offsets : a.pos_offsets;
-        const gf::GridLevels& lv = g ? a.lv2 : a.lv3;
-        float* m = s.P + P_META + g * 64 + l * 4;
-        m[0] = lv.scale[l];
-        m[1] = __uint_as_float(lv.resolution[l]);
-        m[2] = __uint_as_float((uint32_t)off[l]);
-        m[3] = __uint_as_float((uint32_t)(off[l + 1] - off[l]));
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
     }
     if (tid < kHistBins) s.hist[tid] = 0;
-    if (owner) s.p_ray[tid] = -1;
-    const float* pack = a.head_pack;
-    uint32_t par = 0;               // which weight buffer the next chunk goes to
+
+    // pooled ray of this lane (owners only): everything the marcher and the compositor carry between rounds
+    int ray = -1;
+    float r_ox = 0, r_oy = 0, r_oz = 0, r_dx = 0, r_dy = 0, r_dz = 1, r_t = 0, r_far = 0;
+    gf::RayAcc acc = {0, 0, 0, 0, 0, 0};
+    uint32_t r_done = 0;
     uint32_t st_samples = 0, st_rounds = 0, st_tiles = 0;  // statistics (thread 0)
     bool queue_open = true;         // uniform
-
 #ifdef GF_TRACE
     uint32_t tr_round = 0;
 #endif
+
     for (;;) {
-        __syncthreads();  // previous round fully retired (pool, staging)
+        __syncthreads();  // previous round fully retired (staging, H)
         GF_STAMP(0);
         // ------------------------------------------------------------------ refill empty pool slots from the queue
-        int ray = owner ? s.p_ray[tid] : -1;
         if (queue_open && wave < 2) {  // wave-uniform branch
             const bool want = ray < 0 && (uint32_t)tid < pool_cap;
             const unsigned long long m = __ballot(want);
@@ -210,18 +491,18 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     ray = a.queue[idx];
                     const float* o = a.rays_o + (size_t)ray * 3;
                     const float* d = a.rays_d + (size_t)ray * 3;
-                    s.p_ox[tid] = o[0]; s.p_oy[tid] = o[1]; s.p_oz[tid] = o[2];
-                    s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
-                    s.p_t[tid] = a.rays_t[ray];
-                    s.p_far[tid] = a.fars[ray];
+                    r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
+                    r_dx = d[0]; r_dy = d[1]; r_dz = d[2];
+                    r_t = a.rays_t[ray];
+                    r_far = a.far_occ[ray];
                     if (a.phase == 0) {
-                        s.p_ws[tid] = 0.0f; s.p_dep[tid] = 0.0f; s.p_r[tid] = 0.0f; s.p_g[tid] = 0.0f; s.p_b[tid] = 0.0f;
+                        acc.weight_sum = 0.0f; acc.depth = 0.0f; acc.r = 0.0f; acc.g = 0.0f; acc.b = 0.0f;
                     } else {
-                        s.p_ws[tid] = a.weights_sum[ray]; s.p_dep[tid] = a.depth[ray];
-                        s.p_r[tid] = a.image[(size_t)ray * 3]; s.p_g[tid] = a.image[(size_t)ray * 3 + 1]; s.p_b[tid] = a.image[(size_t)ray * 3 + 2];
+                        acc.weight_sum = a.weights_sum[ray]; acc.depth = a.depth[ray];
+                        acc.r = a.image[(size_t)ray * 3]; acc.g = a.image[(size_t)ray * 3 + 1]; acc.b = a.image[(size_t)ray * 3 + 2];
                     }
-                    s.p_done[tid] = 0;
-                    s.p_ray[tid] = ray;
+                    r_done = 0;
+                    s.p_dx[tid] = r_dx; s.p_dy[tid] = r_dy; s.p_dz[tid] = r_dz;
                 }
             }
             if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= limit) ? 1u : 0u;  // this wave saw the end of the queue
@@ -246,18 +527,16 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         n = n > 8u ? 8u : n;          // >= 1 since n_pool <= 128
         // ------------------------------------------------------------------ A. march
         uint32_t cnt = 0, req = 0, rank = 0;
-        float t_ray = 0.0f;
         if (alive) {
             rank = (wave ? s.misc[0] : 0u) + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
-            const uint32_t left = budget - s.p_done[tid];
+            const uint32_t left = budget - r_done;
             req = n < left ? n : left;
-            t_ray = s.p_t[tid];
             const uint32_t base = rank * n;
-            cnt = gf::march_ray(a.mp, s.p_ox[tid], s.p_oy[tid], s.p_oz[tid], s.p_dx[tid], s.p_dy[tid], s.p_dz[tid], s.p_far[tid], 0.0f, req, t_ray,
+            cnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req, r_t,
                                 [&](uint32_t q, float x, float y, float z, float dt, float t_after, float) {
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
                                     s.sdt[base + q] = dt; s.st[base + q] = t_after;
-                                });
+                                }, req + kMarchSlack);
         }
         GF_STAMP(3);
         if (owner) s.rcnt[tid] = (uint8_t)cnt;
@@ -285,148 +564,46 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         if (tid == 0) { st_samples += Mv; st_rounds++; st_tiles += (Mv + 31) / 32; }
         GF_STAMP(5);
 
-        // ------------------------------------------------------------------ B. field on this wave's tile
+        // ------------------------------------------------------------------ B. field
         if (Mv > 0) {  // uniform over the workgroup
-            // chunk 0 (ambient L1) starts streaming now; the d2r table is published by the first barrier below
-            gf::dma_to_lds(s.buf[par], pack + gf::HP_AMB1, 4 * 16 * 64, wave, lane);
-            __syncthreads();
+            __syncthreads();   // dense map published
             GF_STAMP(6);
-            const uint32_t j = wave * 32 + (lane & 31);      // dense sample index
-            const bool active = (uint32_t)(wave * 32) < Mv;  // wave-uniform
-            const bool valid = j < Mv;
-            const uint32_t jj = valid ? j : (active ? (uint32_t)(wave * 32) : 0u);
-            const uint32_t raw = s.d2r[jj];
-            const uint32_t slot = s.rrank[jj];
-
-            float pf[16], af[16], act[64];
-            floatx16 h[4];
-            float sigma = 0.0f;
-            const float* cur;
-            [[maybe_unused]] int tr_i = 7;
-#define GF_NEXT_CHUNK(SRC, NFLOATS)                                   \
-            GF_STAMP(tr_i); tr_i++;                                    \
-            __syncthreads(); /* chunk landed; previous chunk's readers are done */ \
-            GF_STAMP(tr_i); tr_i++;                                    \
-            cur = s.buf[par]; par ^= 1u;                               \
-            gf::dma_to_lds(s.buf[par], pack + (SRC), (NFLOATS), wave, lane);
-#define GF_LAST_CHUNK()                                               \
-            GF_STAMP(tr_i); tr_i++;                                    \
-            __syncthreads();                                          \
-            GF_STAMP(tr_i); tr_i++;                                    \
-            cur = s.buf[par]; par ^= 1u;
-
-            if (active) {
-                const float b2 = 2 * a.bound;
-                const float x3[3] = {(s.sx[raw] + a.bound) / b2, (s.sy[raw] + a.bound) / b2, (s.sz[raw] + a.bound) / b2};
-                gf::encode_half<3>(a.pos_table, s.P + P_META, half, a.gridtype, a.interp, x3, pf);
-            }
-            GF_NEXT_CHUNK(gf::HP_AMB2, 2 * 64 * 64)                       // -> ambient L2, out-blocks 0-1
-            if (active) {
-                gf::mfma_layer<4, 16, true, false>(cur, lane, pf, s.P + P_AMBBIAS, h);   // ambient L1 (cond_feat folded into the bias)
-                gf::unpack<4>(h, act);
-            }
-            GF_NEXT_CHUNK(gf::HP_AMB2 + 2 * 64 * 64, 2 * 64 * 64)         // -> ambient L2, out-blocks 2-3
-            if (active) gf::mfma_part<4, 0, 2, 64, true, false>(cur, lane, act, nullptr, h);
-            GF_NEXT_CHUNK(gf::HP_SIG1, 4 * 32 * 64)                       // -> density L1
-            if (active) {
-                gf::mfma_part<4, 2, 2, 64, true, false>(cur, lane, act, nullptr, h);
-                gf::unpack<4>(h, act);
-                float ambient[2];
-                gf::valu_rows<2, 4>(s.P + P_SMALL + gf::HS_AMB3, half, act, ambient);
-                const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
-                gf::encode_half<2>(a.amb_table, s.P + P_META + 64, half, a.gridtype, a.interp, x2, af);
-            }
-            GF_NEXT_CHUNK(gf::HP_SIG2, 2 * 64 * 64)                       // -> density L2, 0-1
-            if (active) {
-                float in[32];
-#pragma unroll
-                for (int t = 0; t < 16; t++) { in[t] = pf[t]; in[16 + t] = af[t]; }
-                gf::mfma_layer<4, 32, true, false>(cur, lane, in, nullptr, h);
-                gf::unpack<4>(h, act);
-            }
-            GF_NEXT_CHUNK(gf::HP_SIG2 + 2 * 64 * 64, 2 * 64 * 64)         // -> density L2, 2-3
-            if (active) gf::mfma_part<4, 0, 2, 64, true, false>(cur, lane, act, nullptr, h);
-            GF_NEXT_CHUNK(gf::HP_SIG3, 2 * 64 * 64)                       // -> density L3 (geo), 0-1
-            if (active) {
-                gf::mfma_part<4, 2, 2, 64, true, false>(cur, lane, act, nullptr, h);
-                gf::unpack<4>(h, act);
-                float h0[1];
-                gf::valu_rows<1, 4>(s.P + P_SMALL + gf::HS_SIGROW, half, act, h0);
-                sigma = expf(h0[0]);  // trunc_exp forward: plain exp, no clamp (utils.py:41)
-            }
-            GF_NEXT_CHUNK(gf::HP_SIG3 + 2 * 64 * 64, 2 * 64 * 64)         // -> density L3 (geo), 2-3
-            if (active) gf::mfma_part<4, 0, 2, 64, false, false>(cur, lane, act, nullptr, h);  // geometry feature: no activation
-            GF_NEXT_CHUNK(gf::HP_COL1S, 4 * 8 * 64)                       // -> colour L1, SH columns
-            if (active) {
-                gf::mfma_part<4, 2, 2, 64, false, false>(cur, lane, act, nullptr, h);
-                gf::unpack<4>(h, act);
-            }
-            GF_NEXT_CHUNK(gf::HP_COL1G, 2 * 64 * 64)                      // -> colour L1, geo columns, 0-1
-            if (active) {
-                float sh[16], shh[8];
-                gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
-#pragma unroll
-                for (int t = 0; t < 8; t++) shh[t] = half ? sh[8 + t] : sh[t];
-                gf::mfma_layer<4, 8, false, false>(cur, lane, shh, s.P + P_SMALL + gf::HS_COLBIAS, h);  // bias = identity-code columns
-            }
-            GF_NEXT_CHUNK(gf::HP_COL1G + 2 * 64 * 64, 2 * 64 * 64)        // -> colour L1, geo columns, 2-3
-            if (active) gf::mfma_part<4, 0, 2, 64, true, true>(cur, lane, act, nullptr, h);
-            GF_LAST_CHUNK()
-            if (active) {
-                gf::mfma_part<4, 2, 2, 64, true, true>(cur, lane, act, nullptr, h);
-                gf::unpack<4>(h, act);
-                float c[3];
-                gf::valu_rows<3, 4>(s.P + P_SMALL + gf::HS_COL2, half, act, c);
-                if (valid && half == 0) {  // outputs reuse the position slots (every wave read its positions 11 barriers ago)
-                    s.sx[raw] = sigma;
-                    s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
-                    s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
-                    s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
-                }
-            }
-#undef GF_NEXT_CHUNK
-#undef GF_LAST_CHUNK
-            GF_STAMP(31);
-            __syncthreads();
+            const uint32_t nt = (Mv + 31) / 32;
+            if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
+            else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);
+            else if (nt == 2) field_round<2>(a, s, Mv, wave, lane);
+            else field_round<1>(a, s, Mv, wave, lane);
         }
-        GF_STAMP(32);
 
         // ------------------------------------------------------------------ C. composite, retire
         bool survivor = false;
         if (alive) {
-            gf::RayAcc acc;
-            acc.t = t_ray;
-            acc.weight_sum = s.p_ws[tid]; acc.depth = s.p_dep[tid];
-            acc.r = s.p_r[tid]; acc.g = s.p_g[tid]; acc.b = s.p_b[tid];
-            uint32_t done = s.p_done[tid];
             const uint32_t base = rank * n;
             bool died = false;
             uint32_t d = 0;
             for (uint32_t q = 0; q < cnt; q++) {
-                done++;
+                r_done++;
                 if (!gf::composite_sample(acc, s.sx[base + q], s.sy[base + q], s.sz[base + q], s.ob[base + q], s.sdt[base + q], s.st[base + q], a.T_thresh)) {
                     died = true;  // T < T_thresh: terminates at this sample (raymarching.cu:1004)
-                    d = done;
+                    d = r_done;
                     break;
                 }
             }
-            if (!died && cnt < req) {  // the marcher ran out: the next request finds nothing (raymarching.cu:977)
+            if (!died && cnt < req && !(r_t < r_far)) {  // the marcher ran out: the next request finds nothing (raymarching.cu:977)
                 died = true;
-                d = done + 1;
+                d = r_done + 1;
             }
-            const bool finished = !died && done == budget;
+            const bool finished = !died && r_done == budget;
             if (died || finished) {
                 a.weights_sum[ray] = acc.weight_sum;
                 a.depth[ray] = acc.depth;
                 a.image[(size_t)ray * 3 + 0] = acc.r; a.image[(size_t)ray * 3 + 1] = acc.g; a.image[(size_t)ray * 3 + 2] = acc.b;
-                if (finished) a.rays_t[ray] = t_ray;
+                if (finished) a.rays_t[ray] = r_t;
                 if (died && a.phase == 0) atomicAdd(&s.hist[d], 1u);
                 survivor = finished && a.phase == 0;
-                s.p_ray[tid] = -1;
-            } else {
-                s.p_ws[tid] = acc.weight_sum; s.p_dep[tid] = acc.depth; s.p_r[tid] = acc.r; s.p_g[tid] = acc.g; s.p_b[tid] = acc.b;
-                s.p_t[tid] = t_ray;
-                s.p_done[tid] = done;
+            }
+            if (died || finished) {
+                if (!survivor) ray = -1;   // survivors keep the index until the list below has taken it
             }
         }
         if (a.phase == 0 && wave < 2) {
@@ -435,11 +612,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             uint32_t base = 0;
             if (lane == 0 && ns) base = atomicAdd(&a.ctrl[gf::kCtrlNSurv], ns);
             base = __shfl(base, 0);
-            if (survivor) a.survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ray;
+            if (survivor) { a.survivors[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ray; ray = -1; }
         }
-        GF_STAMP(33);
+        GF_STAMP(37);
 #ifdef GF_TRACE
-        if (tid == 0) { s.tr[34] = Mv; s.tr[35] = n_pool; s.tr[36] = n; s.tr[37] = __builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */); }
+        if (tid == 0) { s.tr[38] = Mv; s.tr[39] = n_pool; s.tr[40] = n; s.tr[41] = __builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */); }
         __syncthreads();
         if (a.trace && blockIdx.x < kTraceWGs && tr_round < kTraceRounds && tid < kTraceSlots)
             a.trace[((a.phase * kTraceWGs + blockIdx.x) * kTraceRounds + tr_round) * kTraceSlots + tid] = s.tr[tid];
@@ -465,7 +642,8 @@ struct InitArgs {
     const float* rays_o_in; const float* rays_d_in;  // explicit rays, or NULL
     float pose[12]; float fx, fy, cx, cy; uint32_t img_w;
     const float* aabb; float min_near;
-    float *rays_o, *rays_d, *nears, *fars, *rays_t, *weights_sum, *depth, *image;
+    float occ[6]; uint32_t has_occ;
+    float *rays_o, *rays_d, *nears, *fars, *far_occ, *rays_t, *weights_sum, *depth, *image;
     int* hit_list; uint32_t* ctrl; uint32_t N;
 };
 
@@ -499,9 +677,19 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
         a.weights_sum[n] = 0.0f;
         a.depth[n] = 0.0f;
         a.image[(size_t)n * 3] = 0.0f; a.image[(size_t)n * 3 + 1] = 0.0f; a.image[(size_t)n * 3 + 2] = 0.0f;
+        // Marching may stop where the ray leaves the (slightly padded) box around the occupied cells: every position beyond
+        // it lies in an unoccupied cell, so the reference's marcher would only skip from there to `far`.
+        float far_m = far;
+        if (a.has_occ) {
+            float on, of;
+            gf::near_far_from_aabb_1(ox, oy, oz, dx, dy, dz, a.occ, 0.0f, on, of);
+            if (of == FLT_MAX) far_m = near;              // misses the occupied region: no sample on this ray
+            else far_m = fminf(far, of);
+        }
+        a.far_occ[n] = far_m;
         // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there
         float t = near, t_first = near;
-        const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far, 0.0f, 1u, t,
+        const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far_m, 0.0f, 1u, t,
                                            [&](uint32_t, float, float, float, float, float, float t_at) { t_first = t_at; });
         a.rays_t[n] = t_first;
         hit = got > 0;
@@ -564,7 +752,17 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ia.fx = f->intrinsics[0]; ia.fy = f->intrinsics[1]; ia.cx = f->intrinsics[2]; ia.cy = f->intrinsics[3];
     ia.img_w = f->img_w ? f->img_w : 1;
     ia.aabb = f->aabb; ia.min_near = f->min_near;
-    ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.rays_t = w.rays_t;
+    ia.has_occ = f->has_occ_aabb;
+    // pad the box by a hundredth of a cell: the slab test and the marcher's o + t*d round differently
+    const float pad = 0.01f * 2.0f * f->bound / (float)f->grid_size;
+    for (int i = 0; i < 3; i++) {
+        // positions are clamped to +-bound before the cell lookup (raymarching.cu:883-885): a side of the box that reaches the
+        // bound is open-ended, because everything beyond it maps onto its boundary cells
+        const float cell = 2.0f * f->bound / (float)f->grid_size;
+        ia.occ[i] = f->occ_aabb[i] <= -f->bound + cell ? -1e30f : f->occ_aabb[i] - pad;
+        ia.occ[3 + i] = f->occ_aabb[3 + i] >= f->bound - cell ? 1e30f : f->occ_aabb[3 + i] + pad;
+    }
+    ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.far_occ = w.far_occ; ia.rays_t = w.rays_t;
     ia.weights_sum = w.weights_sum; ia.depth = w.depth; ia.image = w.image; ia.hit_list = w.alive_b; ia.ctrl = w.ctrl; ia.N = N;
     hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, 256u)), dim3(256), 0, s, ia);
 
@@ -574,7 +772,7 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
         return gf_set_error(GF_ERR_INVALID, "frame: bad grid levels");
     ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
     ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
-    ha.rays_o = w.rays_o; ha.rays_d = w.rays_d; ha.fars = w.fars;
+    ha.rays_o = w.rays_o; ha.rays_d = w.rays_d; ha.far_occ = w.far_occ;
     ha.rays_t = w.rays_t; ha.weights_sum = w.weights_sum; ha.depth = w.depth; ha.image = w.image;
     ha.survivors = w.alive_a;
     ha.ctrl = w.ctrl; ha.N = N; ha.max_steps = f->max_steps; ha.gridtype = f->gridtype; ha.interp = f->interp;
@@ -622,6 +820,14 @@ GF_EXPORT uint64_t gf_frame_ctrl_offset(uint32_t n_rays) {
 }
 
 GF_EXPORT uint64_t gf_frame_sizeof(void) { return sizeof(gf_frame_t); }
+
+// HOST: do the fused kernels support these grid tables (see grid_core.hpp, LevelMeta)?  offsets_host = GridEncoder.offsets [L+1].
+GF_EXPORT int gf_grid_levels_fusable(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H) {
+    if (!offsets_host || L != 16 || (D != 2 && D != 3)) return gf_set_error(GF_ERR_UNSUPPORTED, "fused path: grids must have 16 levels and 2 or 3 dimensions");
+    if (!gf::grid_levels_fusable(offsets_host, L, D, S, H))
+        return gf_set_error(GF_ERR_UNSUPPORTED, "fused path: a wrapped grid level has a table size that is not a power of two");
+    return GF_OK;
+}
 
 // Head pass (NeRFRenderer.render inference branch up to the background blend): fills the workspace accumulators.
 // When f->torso_pack == NULL the head-only tail (bg blend, clamp, depth) is also enqueued and the outputs are final.

@@ -166,4 +166,116 @@ __device__ __forceinline__ void encode_half(const float* __restrict__ table, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Specialised lookup of the fused head kernel.  Per level the generic index rule above (grid_row) reduces to
+//   tiled : (x + y*s1 + z*s2) & mask      s_d = stride of dimension d, 0 once the running stride has passed the table size
+//   hash  : (x ^ y*P1 ^ z*P2) & mask      on the levels where the full lattice does not fit the table
+// with mask = all ones on dense levels (the index cannot reach the table size) and size-1 on wrapped levels, whose size
+// GridEncoder caps at 2^log2_hashmap_size (grid.py:118-134).  A wrapped level whose size is not a power of two is
+// rejected on the host (gf_grid_levels_fusable); the generic op kernel handles every case.
+struct LevelMeta {   // 8 words, kept in LDS
+    float scale; uint32_t s1, s2, mask, row_off, use_hash, pad0, pad1;
+};
+
+// One lane per level: derive LevelMeta from the table offsets exactly as grid_row walks the strides.
+template <uint32_t D>
+__device__ __forceinline__ LevelMeta make_level_meta(float scale, uint32_t resolution, const int* __restrict__ offsets, uint32_t l,
+                                                     uint32_t gridtype) {
+    const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+    uint32_t stride = 1, sd[3] = {0, 0, 0};
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= size) { sd[d] = stride; stride *= resolution + 1; }
+    }
+    LevelMeta m;
+    m.scale = scale;
+    m.s1 = sd[1]; m.s2 = sd[2];
+    m.mask = stride <= size ? 0xFFFFFFFFu : size - 1u;
+    m.row_off = (uint32_t)offsets[l];
+    m.use_hash = (gridtype == 0 && stride > size) ? 0xFFFFFFFFu : 0u;
+    m.pad0 = m.pad1 = 0;
+    return m;
+}
+
+// Eight consecutive levels at one point x (already mapped to [0,1]) -> f[16] = [level][channel].  All 8 * 2^D table reads
+// are independent straight-line loads, so they are in flight together.
+template <uint32_t D>
+__device__ __forceinline__ void encode8(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t gridtype,
+                                        uint32_t interp, const float (&x)[D], float (&f)[16]) {
+    static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
+    constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const uint4 m0 = reinterpret_cast<const uint4*>(meta8)[2 * l];
+        const uint2 m1 = reinterpret_cast<const uint2*>(meta8)[4 * l + 2];
+        const float scale = __uint_as_float(m0.x);
+        const uint32_t s1 = m0.y, s2 = m0.z, mask = m0.w, row_off = m1.x, use_hash = m1.y;
+        float w1[D], w0[D];
+        uint32_t g[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
+            const float fl = floorf(p);
+            g[d] = (uint32_t)fl;
+            p -= fl;
+            if (interp == 1) p = p * p * (3.0f - 2.0f * p);
+            w1[d] = p;
+            w0[d] = 1 - p;
+        }
+        uint32_t ix[2], iy[2], iz[2] = {0u, 0u};
+        if (gridtype == 0) {  // kernel-uniform
+            // hashed levels xor prime multiples, dense levels of a hash grid still use the strided index
+            ix[0] = g[0]; ix[1] = g[0] + 1u;
+            const uint32_t y0h = g[1] * P1, y0t = g[1] * s1;
+            iy[0] = use_hash ? y0h : y0t; iy[1] = use_hash ? y0h + P1 : y0t + s1;
+            if constexpr (D == 3) {
+                const uint32_t z0h = g[2] * P2, z0t = g[2] * s2;
+                iz[0] = use_hash ? z0h : z0t; iz[1] = use_hash ? z0h + P2 : z0t + s2;
+            }
+        } else {
+            ix[0] = g[0]; ix[1] = g[0] + 1u;
+            iy[0] = g[1] * s1; iy[1] = iy[0] + s1;
+            if constexpr (D == 3) { iz[0] = g[2] * s2; iz[1] = iz[0] + s2; }
+        }
+        float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+        for (uint32_t c = 0; c < (1u << D); c++) {
+            const uint32_t bx = c & 1u, by = (c >> 1) & 1u, bz = (c >> 2) & 1u;
+            float w = bx ? w1[0] : w0[0];
+            w *= by ? w1[1] : w0[1];
+            uint32_t idx;
+            if constexpr (D == 3) {
+                w *= bz ? w1[2] : w0[2];
+                idx = (gridtype == 0 && use_hash) ? (ix[bx] ^ iy[by] ^ iz[bz]) : (ix[bx] + iy[by] + iz[bz]);
+            } else {
+                idx = (gridtype == 0 && use_hash) ? (ix[bx] ^ iy[by]) : (ix[bx] + iy[by]);
+            }
+            const float2 v = rows[row_off + (idx & mask)];
+            o0 += w * v.x;
+            o1 += w * v.y;
+        }
+        f[l * 2 + 0] = oob ? 0.0f : o0;
+        f[l * 2 + 1] = oob ? 0.0f : o1;
+    }
+}
+
+// HOST: can the fused kernels' specialised lookup reproduce get_grid_index for these tables?  offsets is a HOST array [L+1].
+inline bool grid_levels_fusable(const int* offsets, uint32_t L, uint32_t D, float S, uint32_t H) {
+    GridLevels lv;
+    if (fill_grid_levels(lv, L, S, H)) return false;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+        if (size == 0) return false;
+        uint32_t stride = 1;
+        for (uint32_t d = 0; d < D; d++)
+            if (stride <= size) stride *= lv.resolution[l] + 1;
+        if (stride > size && (size & (size - 1u)) != 0) return false;  // wrapped level with a non power-of-two table
+    }
+    return true;
+}
+
 }  // namespace gf

@@ -86,15 +86,19 @@ __device__ __forceinline__ int mip_from_dt(float dt, float Hf, float max_cascade
 // March one ray from t (updated in place) for at most n_step occupied samples.
 // emit(step, x, y, z, dt, t_after, t_at) is called once per sample, in order (t_at = the ray parameter the sample was
 // taken at: restarting the march from t_at with noise 0 reproduces this sample and everything after it bit for bit).
-// Returns the sample count.
+// Returns the sample count.  `max_iters` bounds the loop trips (samples + empty-space skips) of this call: a caller that
+// keeps t may stop early and resume later (the loop carries no state but t), which lets a workgroup of rays advance in
+// bounded, similar-length slices instead of waiting for its longest empty-space traversal.
 template <typename Emit>
 __device__ __forceinline__ uint32_t march_ray(const MarchParams& p, float ox, float oy, float oz, float dx, float dy,
-                                              float dz, float far, float noise, uint32_t n_step, float& t, Emit&& emit) {
+                                              float dz, float far, float noise, uint32_t n_step, float& t, Emit&& emit,
+                                              uint32_t max_iters = 0xFFFFFFFFu) {
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    uint32_t step = 0;
+    uint32_t step = 0, iters = 0;
     t += clampf(t * p.dt_gamma, p.dt_min, p.dt_max) * noise;
 
-    while (t < far && step < n_step) {
+    while (t < far && step < n_step && iters < max_iters) {
+        iters++;
         const float x = clampf(__builtin_fmaf(t, dx, ox), -p.bound, p.bound);
         const float y = clampf(__builtin_fmaf(t, dy, oy), -p.bound, p.bound);
         const float z = clampf(__builtin_fmaf(t, dz, oz), -p.bound, p.bound);

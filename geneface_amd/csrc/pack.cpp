@@ -10,25 +10,8 @@ namespace {
 // MFMA 32x32 accumulator row held by (register r, lane half h): the "C-layout" feature order
 inline uint32_t c_row(uint32_t r, uint32_t h) { return (r & 3u) + 8u * (r >> 2) + 4u * h; }
 
-// Emit one A-operand stream: for out_block ob, step t, lane l  ->  W[ob*32 + (l&31)][col(t, l>>5)]
-template <typename ColFn>
-void emit_stream(float* dst, const float* W, uint32_t ld, uint32_t row0, uint32_t nsteps, ColFn col) {
-    for (uint32_t ob = 0; ob < 4; ob++)
-        for (uint32_t t = 0; t < nsteps; t++)
-            for (uint32_t l = 0; l < 64; l++) {
-                const uint32_t row = row0 + ob * 32 + (l & 31u);
-                dst[((ob * (nsteps / 4) + t / 4) * 64 + l) * 4 + (t & 3u)] = W[(size_t)row * ld + col(t, l >> 5)];
-            }
-}
-
 // hidden -> hidden: step t = ob_in*16 + r consumes C-layout feature ob_in*32 + c_row(r, half)
 inline uint32_t hidden_col(uint32_t t, uint32_t h) { return (t / 16) * 32 + c_row(t % 16, h); }
-
-void emit_valu_rows(float* dst, const float* W, uint32_t ld, uint32_t row, uint32_t col0) {
-    for (uint32_t ob = 0; ob < 4; ob++)
-        for (uint32_t h = 0; h < 2; h++)
-            for (uint32_t r = 0; r < 16; r++) dst[ob * 32 + h * 16 + r] = W[(size_t)row * ld + col0 + ob * 32 + c_row(r, h)];
-}
 
 }  // namespace
 
@@ -46,28 +29,33 @@ GF_EXPORT int gf_clayout_perm(uint32_t* perm128_host) {
 
 // All pointers are HOST pointers.  Shapes (May config, asserted by the Python side):
 //   amb0 [128,96] amb1 [128,128] amb2 [2,128] | sig0 [128,64] sig1 [128,128] sig2 [129,128] | col0 [128,148] col1 [3,128]
-//   ind_code [4] or NULL.   out [gf_head_pack_floats()]
+//   ind_code [4] or NULL.   out [gf_head_pack_floats()]   (layout: frame.hpp)
 GF_EXPORT int gf_head_pack(const float* amb0, const float* amb1, const float* amb2, const float* sig0, const float* sig1,
                            const float* sig2, const float* col0, const float* col1, const float* ind_code, float* out) {
     using namespace gf;
     if (!amb0 || !amb1 || !amb2 || !sig0 || !sig1 || !sig2 || !col0 || !col1 || !out) return gf_set_error(GF_ERR_INVALID, "head_pack: null pointer");
     memset(out, 0, sizeof(float) * HP_TOTAL);
-    // ambient L1: only the 32 grid columns go through MFMA (the 64 cond columns fold into amb_bias per frame).
-    // step t: lane half h supplies grid feature 16h + t  (levels 8h .. 8h+7, two channels each)
-    emit_stream(out + HP_AMB1, amb0, 96, 0, 16, [](uint32_t t, uint32_t h) { return 16 * h + t; });
-    emit_stream(out + HP_AMB2, amb1, 128, 0, 64, hidden_col);
-    // density L1: input = [3-D grid (32) | 2-D grid (32)]
-    emit_stream(out + HP_SIG1, sig0, 64, 0, 32, [](uint32_t t, uint32_t h) { return t < 16 ? 16 * h + t : 32 + 16 * h + (t - 16); });
-    emit_stream(out + HP_SIG2, sig1, 128, 0, 64, hidden_col);
-    // density L3: rows 1..128 are the geometry feature (row 0 = log-density goes to the VALU block)
-    emit_stream(out + HP_SIG3, sig2, 128, 1, 64, hidden_col);
-    // colour L1: columns [SH 0..15 | geo 16..143 | id 144..147]
-    emit_stream(out + HP_COL1S, col0, 148, 0, 8, [](uint32_t t, uint32_t h) { return 8 * h + t; });
-    emit_stream(out + HP_COL1G, col0, 148, 0, 64, [](uint32_t t, uint32_t h) { return 16 + hidden_col(t, h); });
+    // one layer = `groups` 4-step groups of every wave's stream, starting at group g0
+    auto layer = [&](uint32_t g0, uint32_t groups, const float* W, uint32_t ld, uint32_t row0, uint32_t col0) {
+        for (uint32_t w = 0; w < 4; w++)
+            for (uint32_t u = 0; u < groups; u++)
+                for (uint32_t l = 0; l < 64; l++)
+                    for (uint32_t i = 0; i < 4; i++)
+                        out[HP_STREAM + (((size_t)w * G_TOTAL + g0 + u) * 64 + l) * 4 + i] =
+                            W[(size_t)(row0 + 32 * w + (l & 31u)) * ld + col0 + 8 * u + 4 * (l >> 5) + i];
+    };
+    layer(G_AMB1, 4, amb0, 96, 0, 0);      // the 64 cond columns (32..95) fold into amb_bias per frame
+    layer(G_SIG1A, 4, sig0, 64, 0, 0);
+    layer(G_AMB2, 16, amb1, 128, 0, 0);
+    layer(G_SIG1B, 4, sig0, 64, 0, 32);
+    layer(G_SIG2, 16, sig1, 128, 0, 0);
+    layer(G_SIG3, 16, sig2, 128, 1, 0);    // rows 1..128: geometry feature (row 0 = log-density, VALU block)
+    layer(G_COL1S, 2, col0, 148, 0, 0);    // columns [SH 0..15 | geo 16..143 | id 144..147]
+    layer(G_COL1G, 16, col0, 148, 0, 16);
     float* s = out + HP_SMALL;
-    for (uint32_t c = 0; c < 2; c++) emit_valu_rows(s + HS_AMB3 + c * 128, amb2, 128, c, 0);
-    emit_valu_rows(s + HS_SIGROW, sig2, 128, 0, 0);
-    for (uint32_t c = 0; c < 3; c++) emit_valu_rows(s + HS_COL2 + c * 128, col1, 128, c, 0);
+    for (uint32_t c = 0; c < 2; c++) memcpy(s + HS_AMB3 + c * 128, amb2 + (size_t)c * 128, 128 * sizeof(float));
+    memcpy(s + HS_SIGROW, sig2, 128 * sizeof(float));
+    for (uint32_t c = 0; c < 3; c++) memcpy(s + HS_COL2 + c * 128, col1 + (size_t)c * 128, 128 * sizeof(float));
     for (uint32_t ob = 0; ob < 4; ob++)
         for (uint32_t h = 0; h < 2; h++)
             for (uint32_t r = 0; r < 16; r++) {
@@ -76,6 +64,33 @@ GF_EXPORT int gf_head_pack(const float* amb0, const float* amb1, const float* am
                 if (ind_code) for (uint32_t k = 0; k < 4; k++) b += col0[(size_t)row * 148 + 144 + k] * ind_code[k];
                 s[HS_COLBIAS + ob * 32 + h * 16 + r] = b;
             }
+    return GF_OK;
+}
+
+// Axis-aligned world-space box around every occupied cell of the Morton-ordered occupancy bitfield (HOST pointer):
+// cell (x,y,z) of cascade c covers ((v + {0,1}) / H * 2 - 1) * min(2^c, bound) per axis (raymarching.cu:883-892).  A sample
+// position outside this box lies in an unoccupied cell at every cascade, so the marcher can never emit a sample beyond
+// the ray's exit from it.  out6 = {xmin,ymin,zmin,xmax,ymax,zmax}; an empty grid gives an inverted box (min > max).
+GF_EXPORT int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, uint32_t H, float bound, float* out6_host) {
+    if (!bitfield_host || !out6_host || cascade == 0 || H == 0 || H > 1024) return gf_set_error(GF_ERR_INVALID, "occupancy_aabb: bad argument");
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    const uint64_t H3 = (uint64_t)H * H * H;
+    for (uint32_t c = 0; c < cascade; c++) {
+        double mb = (double)(1u << c);
+        if (mb > bound) mb = bound;
+        for (uint64_t i = 0; i < H3; i++) {
+            const uint64_t idx = c * H3 + i;
+            if (!(bitfield_host[idx >> 3] & (1u << (idx & 7u)))) continue;
+            const uint32_t m = (uint32_t)i;
+            const uint32_t v[3] = {gf::morton3d_invert(m), gf::morton3d_invert(m >> 1), gf::morton3d_invert(m >> 2)};
+            for (int d = 0; d < 3; d++) {
+                const double a = ((double)v[d] / H * 2 - 1) * mb, b = ((double)(v[d] + 1) / H * 2 - 1) * mb;
+                if (a < lo[d]) lo[d] = a;
+                if (b > hi[d]) hi[d] = b;
+            }
+        }
+    }
+    for (int d = 0; d < 3; d++) { out6_host[d] = (float)lo[d]; out6_host[3 + d] = (float)hi[d]; }
     return GF_OK;
 }
 

@@ -26,7 +26,8 @@ class GfFrame(C.Structure):
         ("pose", _f32 * 12), ("intrinsics", _f32 * 4),
         ("aabb", _vp), ("bitfield", _vp),
         ("min_near", _f32), ("bound", _f32), ("dt_gamma", _f32), ("T_thresh", _f32),
-        ("max_steps", _u32), ("cascade", _u32), ("grid_size", _u32), ("_pad1", _u32),
+        ("max_steps", _u32), ("cascade", _u32), ("grid_size", _u32), ("has_occ_aabb", _u32),
+        ("occ_aabb", _f32 * 6), ("_pad1", _f32 * 2),
         ("pos_table", _vp), ("pos_offsets", _vp), ("amb_table", _vp), ("amb_offsets", _vp),
         ("pos_S", _f32), ("amb_S", _f32),
         ("base_res", _u32), ("gridtype", _u32), ("interp", _u32), ("_pad2", _u32),
@@ -77,6 +78,15 @@ class FusedState:
         pe, ae = model.position_embedder, model.ambient_embedder
         self.pos_S, self.amb_S = float(np.log2(pe.per_level_scale)), float(np.log2(ae.per_level_scale))
         self.gridtype, self.interp, self.base_res = pe.gridtype_id, pe.interp_id, int(pe.base_resolution)
+        for enc, D, S in ((pe, 3, self.pos_S), (ae, 2, self.amb_S)):
+            off = np.ascontiguousarray(enc.offsets.detach().cpu().numpy().astype(np.int32))
+            if L.gf_grid_levels_fusable(_hp(off), enc.num_levels, D, S, self.base_res) != 0:
+                raise NotImplementedError(L.gf_last_error().decode() + " (use render_impl='ops')")
+        # box around the occupied cells of the density bitfield: the marcher stops at a ray's exit from it
+        bits = np.ascontiguousarray(model.density_bitfield.detach().cpu().numpy().astype(np.uint8))
+        box = np.zeros(6, dtype=np.float32)
+        check(L.gf_occupancy_aabb(_hp(bits), int(model.cascade), int(model.grid_size), float(model.bound), _hp(box)))
+        self.occ_aabb = [float(v) for v in box]
 
         if self.has_torso:
             d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
@@ -156,6 +166,9 @@ def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_th
     f.aabb, f.bitfield = ptr(model.aabb_infer, torch.float32), ptr(model.density_bitfield, torch.uint8)
     f.min_near, f.bound, f.dt_gamma, f.T_thresh = float(model.min_near), float(model.bound), float(dt_gamma), float(T_thresh)
     f.max_steps, f.cascade, f.grid_size = int(max_steps), int(model.cascade), int(model.grid_size)
+    f.has_occ_aabb = 1
+    for k in range(6):
+        f.occ_aabb[k] = st.occ_aabb[k]
     pe, ae = model.position_embedder, model.ambient_embedder
     f.pos_table, f.pos_offsets = ptr(pe.embeddings, torch.float32), ptr(pe.offsets, torch.int32)
     f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)

@@ -103,7 +103,9 @@ typedef struct gf_frame_t {
     const float* aabb;          /* [6] aabb_infer */
     const uint8_t* bitfield;    /* density_bitfield [cascade*grid^3/8] */
     float min_near, bound, dt_gamma, T_thresh;
-    uint32_t max_steps, cascade, grid_size, _pad1;
+    uint32_t max_steps, cascade, grid_size, has_occ_aabb;
+    float occ_aabb[6];          /* gf_occupancy_aabb(bitfield): box around the occupied cells; has_occ_aabb = 0 -> march to aabb's far */
+    float _pad1[2];
     /* head field (radnerf.py:41-59) */
     const float* pos_table;  const int32_t* pos_offsets;   /* position_embedder.embeddings / offsets (3-D, 16x2) */
     const float* amb_table;  const int32_t* amb_offsets;   /* ambient_embedder.embeddings / offsets  (2-D, 16x2) */
@@ -132,7 +134,12 @@ typedef struct gf_frame_t {
 uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
 uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */
-uint32_t gf_frame_ctrl_words(void);               /* [0..64] n_alive per iteration | [65..129] cumulative step | [130..194] valid samples */
+uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/csrc/frame.hpp (queue heads, counts, terminal-index histogram) */
+/* HOST: {xmin,ymin,zmin,xmax,ymax,zmax} of the occupied cells of a density_bitfield (HOST pointer).  No sample of
+ * kernel_march_rays (raymarching.cu:828-929) can lie outside it, so the fused marcher stops at a ray's exit from it. */
+int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, uint32_t H, float bound, float* out6_host);
+/* HOST: can the fused kernels index these grid tables (GridEncoder.offsets as a HOST array [L+1], gridencoder.cu:66-84)? */
+int gf_grid_levels_fusable(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H);
 uint32_t gf_head_pack_floats(void);
 uint32_t gf_torso_pack_floats(void);
 int gf_clayout_perm(uint32_t* perm128_host);
@@ -147,8 +154,8 @@ int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_ho
 int gf_render_head(const gf_frame_t* frame, void* stream);
 /* torso pass + final blend (radnerf_torso.py:156-198); gf_render_head must precede it on the same stream */
 int gf_render_torso(const gf_frame_t* frame, void* stream);
-/* measurement only: gf_render_head's march iterations bracketed by HIP events on `stream`; synchronises */
-int gf_render_head_timed(const gf_frame_t* frame, void* stream, float* iter_ms_host, uint32_t* n_iters_host);
+/* measurement only: gf_render_head's two field launches bracketed by HIP events on `stream`; synchronises */
+int gf_render_head_timed(const gf_frame_t* frame, void* stream, float* phase_ms_host, uint32_t* n_phases_host);
 
 #ifdef __cplusplus
 }

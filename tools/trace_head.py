@@ -21,20 +21,18 @@ os.environ["GF_HIP_LIB"] = os.path.join(ROOT, "geneface_amd", "csrc", "libgenefa
 
 NAMES = {
     (0, 1): "refill (queue atomic + ray loads)", (1, 2): "census barrier", (2, 3): "march", (3, 4): "barrier after march",
-    (4, 5): "scan + dense map", (5, 6): "dma chunk0 issue + barrier", (6, 7): "encode 3-D grid",
-    (7, 8): "BARRIER amb1", (8, 9): "mfma amb L1 (K=32)",
-    (9, 10): "BARRIER amb2a", (10, 11): "mfma amb L2 blocks 0-1",
-    (11, 12): "BARRIER amb2b", (12, 13): "mfma amb L2 blocks 2-3 + rows + tanh + encode 2-D",
-    (13, 14): "BARRIER sig1", (14, 15): "mfma sig L1 (K=64)",
-    (15, 16): "BARRIER sig2a", (16, 17): "mfma sig L2 blocks 0-1",
-    (17, 18): "BARRIER sig2b", (18, 19): "mfma sig L2 blocks 2-3 + sigma row + exp",
-    (19, 20): "BARRIER sig3a", (20, 21): "mfma sig L3 blocks 0-1",
-    (21, 22): "BARRIER sig3b", (22, 23): "mfma sig L3 blocks 2-3",
-    (23, 24): "BARRIER col1s", (24, 25): "SH + mfma col L1 SH part (K=16)",
-    (25, 26): "BARRIER col1g a", (26, 27): "mfma col L1 geo blocks 0-1",
-    (27, 28): "BARRIER col1g b (last)", (28, 31): "mfma col L1 geo blocks 2-3 + rgb rows + sigmoid",
-    (31, 32): "barrier end of field", (32, 33): "composite + retire",
+    (4, 5): "scan + dense map", (5, 6): "barrier (dense map)", (6, 7): "encode 3-D grid -> H",
+    (7, 8): "BARRIER", (8, 9): "mfma amb L1 + sig L1a (K=32+32)",
+    (9, 10): "BARRIER ", (10, 11): "store H", (11, 12): "BARRIER  ",
+    (12, 13): "mfma amb L2 (K=128)", (13, 14): "BARRIER   ", (14, 15): "store H ", (15, 16): "BARRIER    ",
+    (16, 17): "amb L3 rows + tanh + encode 2-D grid -> H", (17, 18): "BARRIER     ",
+    (18, 19): "mfma sig L1b (K=32)", (19, 20): "BARRIER      ", (20, 21): "store H  ", (21, 22): "BARRIER       ",
+    (22, 23): "mfma sig L2 (K=128)", (23, 24): "BARRIER        ", (24, 25): "store H   ", (25, 26): "BARRIER         ",
+    (26, 27): "sigma row + exp + mfma sig L3 (K=128)", (27, 28): "BARRIER          ", (28, 29): "store H    ", (29, 30): "BARRIER           ",
+    (30, 31): "SH + mfma col L1 (K=16+128)", (31, 32): "BARRIER            ", (32, 33): "store H     ", (33, 34): "BARRIER             ",
+    (34, 35): "col L2 rows + sigmoid", (35, 36): "barrier end of field", (36, 37): "composite + retire",
 }
+SLOT_END, SLOT_MV, SLOT_NPOOL, SLOT_N = 37, 38, 39, 40
 
 
 def main():
@@ -83,16 +81,16 @@ def main():
     report = {"phase_ms": [ms[0], ms[1]], "stats": fs, "phases": []}
     for ph in range(2):
         tp = t[ph]
-        used = tp[:, :, 33] != 0
+        used = tp[:, :, SLOT_END] != 0
         if not used.any():
             continue
-        full = used & (tp[:, :, 34] >= 96)   # rounds with >= 3 full tiles of samples: the steady state
+        full = used & (tp[:, :, SLOT_MV] >= 97)   # rounds with >= 3 full tiles of samples: the steady state
         sel = full if full.any() else used
         rounds = tp[sel]
-        total = (rounds[:, 33] - rounds[:, 0]) & 0xFFFFFFFF
+        total = (rounds[:, SLOT_END] - rounds[:, 0]) & 0xFFFFFFFF
         print(f"\n== phase {ph}: {int(used.sum())} traced rounds over {nwg} workgroups, {int(sel.sum())} selected "
-              f"(Mv>=96: {bool(full.any())}); round = {total.mean():.0f} cycles mean, p50 {np.median(total):.0f}, p90 {np.percentile(total, 90):.0f}; "
-              f"Mv mean {rounds[:, 34].mean():.1f}, n_pool mean {rounds[:, 35].mean():.1f}, n mean {rounds[:, 36].mean():.2f}")
+              f"(Mv>=97: {bool(full.any())}); round = {total.mean():.0f} cycles mean, p50 {np.median(total):.0f}, p90 {np.percentile(total, 90):.0f}; "
+              f"Mv mean {rounds[:, SLOT_MV].mean():.1f}, n_pool mean {rounds[:, SLOT_NPOOL].mean():.1f}, n mean {rounds[:, SLOT_N].mean():.2f}")
         rows = []
         for (a, b), name in NAMES.items():
             d = (rounds[:, b] - rounds[:, a]) & 0xFFFFFFFF
@@ -104,8 +102,8 @@ def main():
         for name, mean, p50, p90, share in rows:
             print(f"  {name:58s} mean {mean:9.0f}  p50 {p50:9.0f}  p90 {p90:9.0f}  {100 * share:5.1f}%")
         bar = sum(r[1] for r in rows if r[0].startswith("BARRIER"))
-        mf = sum(r[1] for r in rows if r[0].startswith("mfma") or r[0].startswith("SH"))
-        print(f"  -> weight-chunk barriers {100 * bar / total.mean():.1f}%  mfma segments {100 * mf / total.mean():.1f}% of the round")
+        mf = sum(r[1] for r in rows if "mfma" in r[0])
+        print(f"  -> layer barriers {100 * bar / total.mean():.1f}%  mfma segments {100 * mf / total.mean():.1f}% of the round")
         # rounds per workgroup and the span of each workgroup's activity
         per_wg = used.sum(axis=1)
         print(f"  rounds per traced workgroup: {per_wg.tolist()}")
