@@ -1,0 +1,84 @@
+"""World-size-2 CPU (gloo) coverage of the multi-GPU path: frame sharding (base_nerf_infer.py:150-155) and the one
+collective of the render path, the flattened weight broadcast (the DDP constructor's implicit broadcast, :126,145).
+The GPU bench launches the same code with backend nccl (= RCCL); nothing here needs a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from geneface_amd import hparams as HP
+from geneface_amd.infer import broadcast_model_, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("T,W", [(100, 1), (100, 2), (272, 8), (3000, 8), (7, 8), (5, 2)])
+def test_shard_range_partitions_all_frames(T, W):
+    """Contiguous blocks of T // W, last rank takes the remainder: every frame exactly once, in order."""
+    seen = []
+    for r in range(W):
+        a, b = shard_range(T, r, W)
+        assert 0 <= a <= b <= T
+        if r < W - 1:
+            assert b - a == T // W
+        seen.extend(range(a, b))
+    assert seen == list(range(T))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = HP.may_hparams(True)
+    torch.manual_seed(1234 + rank)  # replicas start DIFFERENT: only rank 0's weights must survive
+    model = RADNeRFTorso(hp)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(float(rank))
+        model.density_bitfield.fill_(rank + 1)
+        model.density_grid_torso.fill_(0.25 * (rank + 1))
+    broadcast_model_(model, src=0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.save(sd, os.path.join(out_dir, f"sd_{rank}.pt"))
+    # every rank renders its own contiguous block and nothing else: gather the block bounds
+    T = 101
+    a, b = shard_range(T, rank, world)
+    bounds = [None] * world
+    dist.all_gather_object(bounds, (a, b))
+    if rank == 0:
+        covered = [i for lo, hi in bounds for i in range(lo, hi)]
+        assert covered == list(range(T))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_broadcast_world2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sd0 = torch.load(tmp_path / "sd_0.pt")
+    sd1 = torch.load(tmp_path / "sd_1.pt")
+    assert sd0.keys() == sd1.keys()
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    # rank 0's distinguishing marks won (uint8 bitfield and fp32 buffers ride in the same broadcast path)
+    assert int(sd1["density_bitfield"][0]) == 1
+    assert float(sd1["density_grid_torso"].flatten()[0]) == 0.25
+
+
+def test_broadcast_is_noop_without_process_group():
+    from geneface_amd.radnerf import RADNeRF
+    m = RADNeRF(HP.may_hparams(False))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    assert broadcast_model_(m) is m
+    for k, v in m.state_dict().items():
+        assert torch.equal(before[k], v)
