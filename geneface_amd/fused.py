@@ -40,6 +40,19 @@ class GfFrame(C.Structure):
     ]
 
 
+class GfCond(C.Structure):
+    """ctypes mirror of gf_cond_t (include/geneface_hip.h); size is checked against gf_cond_sizeof()."""
+    _fields_ = [
+        ("cond", _vp), ("S", _u32), ("T", _u32), ("C", _u32), ("dim_aud", _u32),
+        ("conv_w", _vp * 4), ("conv_b", _vp * 4), ("conv_stride", _u32 * 4), ("conv_ch", _u32 * 5),
+        ("fc1_w", _vp), ("fc1_b", _vp), ("fc2_w", _vp), ("fc2_b", _vp),
+        ("att_w", _vp * 5), ("att_b", _vp * 5), ("att_lin_w", _vp), ("att_lin_b", _vp),
+        ("cond_feat", _vp), ("W_cond", _vp), ("amb_bias", _vp),
+        ("pose6", _vp), ("torso_code", _vp), ("code_dim", _u32), ("_pad", _u32),
+        ("W_tconst", _vp), ("torso_bias", _vp),
+    ]
+
+
 def _np(t):
     return np.ascontiguousarray(t.detach().float().cpu().numpy())
 
@@ -99,6 +112,40 @@ class FusedState:
             self.W_tconst = torch.cat([d[0].weight.detach()[p64, 42:], cn[0].weight.detach()[p32, 74:]], dim=0).contiguous()  # [96, 62]
             self.torso_S = float(np.log2(model.torso_embedder.per_level_scale))
         self._ws = {}
+        self.cond = self._build_cond(model)
+
+    def _build_cond(self, model):
+        """gf_cond_t with every weight pointer filled in (None when the encoder is not the AudioNet + AudioAttNet pair the
+        HIP kernel implements: the torch modules then run instead, still on the GPU)."""
+        pre, att = getattr(model, "cond_prenet", None), getattr(model, "cond_att_net", None)
+        if pre is None or att is None or not getattr(model, "with_att", False):
+            return None
+        L = lib()
+        assert C.sizeof(GfCond) == L.gf_cond_sizeof(), "gf_cond_t layout mismatch between fused.py and geneface_hip.h"
+        convs = [m for m in pre.encoder_conv if isinstance(m, torch.nn.Conv1d)]
+        aconvs = [m for m in att.attentionConvNet if isinstance(m, torch.nn.Conv1d)]
+        fcs = [m for m in pre.encoder_fc1 if isinstance(m, torch.nn.Linear)]
+        lin = att.attentionNet[0]
+        if len(convs) != 4 or len(aconvs) != 5 or len(fcs) != 2 or [c.out_channels for c in aconvs] != [16, 8, 4, 2, 1]:
+            return None
+        c = GfCond()
+        f32 = torch.float32
+        for i, m in enumerate(convs):
+            c.conv_w[i], c.conv_b[i], c.conv_stride[i] = ptr(m.weight, f32), ptr(m.bias, f32), int(m.stride[0])
+            c.conv_ch[i] = int(m.in_channels)
+        c.conv_ch[4] = int(convs[3].out_channels)
+        c.fc1_w, c.fc1_b, c.fc2_w, c.fc2_b = ptr(fcs[0].weight, f32), ptr(fcs[0].bias, f32), ptr(fcs[1].weight, f32), ptr(fcs[1].bias, f32)
+        for i, m in enumerate(aconvs):
+            c.att_w[i], c.att_b[i] = ptr(m.weight, f32), ptr(m.bias, f32)
+        c.att_lin_w, c.att_lin_b = ptr(lin.weight, f32), ptr(lin.bias, f32)
+        c.S, c.T, c.C, c.dim_aud = int(att.seq_len), int(pre.win_size), int(convs[0].in_channels), int(pre.dim_aud)
+        c.W_cond = ptr(self.W_cond)
+        if self.has_torso:
+            c.W_tconst = ptr(self.W_tconst)
+            c.code_dim = int(model.torso_individual_embedding_dim)
+            self._torso_code = model.torso_individual_codes[0].detach().contiguous() if c.code_dim > 0 else None
+            c.torso_code = ptr(self._torso_code) if self._torso_code is not None else None
+        return c
 
     @staticmethod
     def check_architecture(model):
@@ -126,14 +173,16 @@ class FusedState:
                 if tuple(sd[k].shape) != shp:
                     raise NotImplementedError(f"fused path: {k} must have shape {shp}")
 
-    def workspace(self, n_rays):
-        if n_rays not in self._ws:
+    def workspace(self, n_rays, slot=0):
+        """(buffer, control-block view) of frame slot `slot`: frames in flight on different streams use different slots."""
+        key = (n_rays, slot)
+        if key not in self._ws:
             nbytes = lib().gf_frame_workspace_bytes(n_rays)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             off = lib().gf_frame_ctrl_offset(n_rays)
             ctrl = buf[off:off + 4 * lib().gf_frame_ctrl_words()].view(torch.int32)
-            self._ws[n_rays] = (buf, ctrl)
-        return self._ws[n_rays]
+            self._ws[key] = (buf, ctrl)
+        return self._ws[key]
 
 
 def get_state(model) -> FusedState:
@@ -161,7 +210,8 @@ def _bg_tensor(bg_color, N, device):
     return bg.reshape(N, 3).contiguous()
 
 
-def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth, out_rgb8=None):
+def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth, out_rgb8=None,
+                 slot=0):
     f.n_rays = N
     f.aabb, f.bitfield = ptr(model.aabb_infer, torch.float32), ptr(model.density_bitfield, torch.uint8)
     f.min_near, f.bound, f.dt_gamma, f.T_thresh = float(model.min_near), float(model.bound), float(dt_gamma), float(T_thresh)
@@ -178,7 +228,7 @@ def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_th
     f.bg_color = ptr(bg, torch.float32)
     f.out_rgb, f.out_depth = ptr(out_rgb), ptr(out_depth)
     f.out_rgb8 = ptr(out_rgb8, torch.uint8) if out_rgb8 is not None else None
-    f.workspace = st.workspace(N)[0].data_ptr()
+    f.workspace = st.workspace(N, slot)[0].data_ptr()
 
 
 def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_alpha, out_trgb, out_deform):
@@ -195,7 +245,23 @@ def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_al
 
 
 def _per_frame_vectors(model, st, cond, poses6=None):
-    """cond encoder + the per-frame bias folds (tiny torch ops on the current stream)."""
+    """cond encoder + the per-frame bias folds: one HIP launch (gf_cond_encode) on the current stream; the torch modules only
+    when the encoder is not the AudioNet + AudioAttNet pair (or the window shape is outside the kernel's limits)."""
+    c = st.cond
+    if c is not None and tuple(cond.shape) == (c.S, c.T, c.C) and cond.dtype == torch.float32 and cond.is_contiguous():
+        dev = cond.device
+        cond_feat = torch.empty(c.dim_aud, dtype=torch.float32, device=dev)
+        amb_bias = torch.empty(128, dtype=torch.float32, device=dev)
+        torso_bias = torch.empty(96, dtype=torch.float32, device=dev) if poses6 is not None else None
+        call = GfCond.from_buffer_copy(c)
+        call.cond, call.cond_feat, call.amb_bias = ptr(cond), ptr(cond_feat), ptr(amb_bias)
+        if poses6 is not None:
+            p6 = poses6.reshape(-1).float().contiguous()
+            call.pose6, call.torso_bias = ptr(p6), ptr(torso_bias)
+        else:
+            call.torso_bias = None
+        check(lib().gf_cond_encode(C.byref(call), current_stream(dev)))
+        return cond_feat, amb_bias, torso_bias
     cond_feat = model.cal_cond_feat(cond).reshape(-1).float()
     amb_bias = torch.mv(st.W_cond, cond_feat)
     torso_bias = None
@@ -295,17 +361,16 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
 class _PipeBuffers:
     def __init__(self, pipe):
         dev, N = pipe.device, pipe.H * pipe.W
-        self.rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        self.depth = torch.empty(N, dtype=torch.float32, device=dev)
+        self.rgb = [torch.empty(N, 3, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.depth = [torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2)]
         self.rgb8 = [torch.empty(pipe.H, pipe.W, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.k = 0
         self.bg = pipe.bg.reshape(N, 3).contiguous()
         self.bg_coords = pipe.bg_coords.reshape(N, 2).contiguous()
         self.poses_host = pipe.poses.cpu().numpy()
 
 
-def _fill_pose_frame(pipe, i, f, rgb8):
-    """Describe frame i of the pipeline: rays come from pose + intrinsics inside the kernel."""
+def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
+    """Describe frame i of the pipeline (frame slot `slot`): rays come from pose + intrinsics inside the kernel."""
     model, hp = pipe.model, pipe.hp
     st = get_state(model)
     bufs = getattr(pipe, "_fused_bufs", None)
@@ -314,7 +379,7 @@ def _fill_pose_frame(pipe, i, f, rgb8):
     N = pipe.H * pipe.W
     torso = st.has_torso
     _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
-    _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], 1e-4, amb_bias, bufs.bg, bufs.rgb, bufs.depth, rgb8)
+    _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], 1e-4, amb_bias, bufs.bg, bufs.rgb[slot], bufs.depth[slot], rgb8, slot)
     f.img_h, f.img_w = pipe.H, pipe.W
     f.rays_o = f.rays_d = None
     p = bufs.poses_host[i]
@@ -328,14 +393,15 @@ def _fill_pose_frame(pipe, i, f, rgb8):
     return st, bufs, (amb_bias, torso_bias)
 
 
-def render_frame_fused(pipe, i):
-    """One frame of FramePipeline on the fused path -> device uint8 [H,W,3] (two buffers alternate, so the async
-    D2H copy of frame i may still be reading one while frame i+1 is rendered into the other)."""
+def render_frame_fused(pipe, i, slot=0):
+    """One frame of FramePipeline on the fused path -> device uint8 [H,W,3], enqueued on the CURRENT stream.  Frame slots
+    0/1 own separate workspaces and output buffers, so two consecutive frames may be in flight on two streams (the next
+    frame's kernels fill the CUs the previous frame's draining persistent grid leaves idle) and the async D2H copy of
+    frame i may still be reading one uint8 buffer while frame i+1 is rendered into the other."""
     with torch.no_grad():
         f = GfFrame()
-        st, bufs, keep = _fill_pose_frame(pipe, i, f, None)
-        rgb8 = bufs.rgb8[bufs.k]
-        bufs.k = 1 - bufs.k
+        st, bufs, keep = _fill_pose_frame(pipe, i, f, None, slot)
+        rgb8 = bufs.rgb8[slot]
         f.out_rgb8 = rgb8.data_ptr()
         s = current_stream(pipe.device)
         check(lib().gf_render_head(C.byref(f), s))

@@ -69,6 +69,13 @@ class FramePipeline:
             if dev.type == "cuda" else [torch.empty(self.H, self.W, 3, dtype=torch.uint8)]
         self._events = [None] * len(self._pinned)
         self._slot = 0
+        # fused path: consecutive frames alternate between two side streams (and two frame slots), so frame i+1 overlaps the
+        # tail of frame i; each stream is in order, and the pinned-buffer events order the host reads
+        self._streams = None
+        if dev.type == "cuda" and self.impl == "fused":
+            self._streams = [torch.cuda.Stream(dev) for _ in range(2)]
+            for st in self._streams:
+                st.wait_stream(torch.cuda.current_stream(dev))
 
     def __len__(self):
         return len(self.frame_ids)
@@ -89,19 +96,30 @@ class FramePipeline:
     def render_frame(self, i: int) -> torch.Tensor:
         """One step of the frame loop: returns the pinned-host uint8 [H,W,3] RGB frame (valid after `wait(slot)` /
         a stream sync; double-buffered so the D2H copy of frame i overlaps the kernels of frame i+1)."""
-        if self.impl == "fused":
-            from .fused import render_frame_fused
-            rgb8 = render_frame_fused(self, i)
-        else:
-            out = self.run_model(self.sample(i))
-            rgb8 = (out["rgb_map"] * 255).view(self.H, self.W, 3).to(torch.uint8)
         slot = self._slot
         self._slot = (slot + 1) % len(self._pinned)
         if self._events[slot] is not None:
-            self._events[slot].synchronize()
+            self._events[slot].synchronize()   # the host side of this slot's previous frame has been handed out and may be reused
+        if self.impl == "fused":
+            from .fused import render_frame_fused
+            with torch.cuda.stream(self._streams[slot % 2]):
+                rgb8 = render_frame_fused(self, i, slot % 2)
+                self._pinned[slot].copy_(rgb8, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._events[slot] = ev
+            return self._pinned[slot]
+        out = self.run_model(self.sample(i))
+        rgb8 = (out["rgb_map"] * 255).view(self.H, self.W, 3).to(torch.uint8)
         self._pinned[slot].copy_(rgb8, non_blocking=True)
         if self.device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record()
             self._events[slot] = ev
         return self._pinned[slot]
+
+    def wait(self, frame: torch.Tensor = None):
+        """Block until every enqueued frame (or all work) has reached pinned host memory."""
+        for ev in self._events:
+            if ev is not None:
+                ev.synchronize()

@@ -131,6 +131,34 @@ typedef struct gf_frame_t {
     void* workspace;            /* gf_frame_workspace_bytes(n_rays) bytes, 256-byte aligned */
 } gf_frame_t;
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-frame condition encoder: RADNeRF.cal_cond_feat (modules/radnerfs/radnerf.py:61-71) =
+ *   AudioNet.forward (cond_encoder.py:44-52) + AudioAttNet.forward (:79-89), in one launch, plus the two bias folds the
+ *   fused field kernels consume (amb_bias / torso_bias below).  All weights are the nn.Module tensors as they are.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gf_cond_t {
+    const float* cond;                  /* [S, T, C] window (smo_win_size, cond_win_size, cond dim), e.g. [5,1,204] */
+    uint32_t S, T, C, dim_aud;
+    const float* conv_w[4];             /* cond_prenet.encoder_conv.{0,2,4,6}.weight [Cout, Cin, 3] */
+    const float* conv_b[4];             /* ....bias */
+    uint32_t conv_stride[4];            /* cond_encoder.py:14-41: strides by window size */
+    uint32_t conv_ch[5];                /* C, 32, 32, 64, 64 */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;   /* cond_prenet.encoder_fc1.{0,2} */
+    const float* att_w[5];              /* cond_att_net.attentionConvNet.{0,2,4,6,8}.weight: dim_aud->16->8->4->2->1 */
+    const float* att_b[5];
+    const float *att_lin_w, *att_lin_b; /* cond_att_net.attentionNet.0: Linear(S, S) */
+    float* cond_feat;                   /* out [dim_aud] */
+    const float* W_cond;                /* [128, dim_aud] = ambient_net.net.0.weight[gf_clayout_perm, 32:]; NULL with amb_bias NULL */
+    float* amb_bias;                    /* out [128] or NULL */
+    const float* pose6;                 /* [6] euler + translation (utils.py:263-269) */
+    const float* torso_code;            /* [code_dim] torso_individual_codes[0] or NULL */
+    uint32_t code_dim, _pad;
+    const float* W_tconst;              /* [96, 54 + code_dim] per-frame-constant columns of the torso first layers */
+    float* torso_bias;                  /* out [96] or NULL */
+} gf_cond_t;
+uint64_t gf_cond_sizeof(void);
+int gf_cond_encode(const gf_cond_t* cond, void* stream);
+
 uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
 uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */

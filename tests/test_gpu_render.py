@@ -142,3 +142,26 @@ def test_frame_pipeline_pose_mode_vs_oracle(torso):
         frame_ops = pipe_ops.render_frame(i).clone()
         torch.cuda.synchronize()
         assert ((frame_ops.int() - frame.int()).abs() <= 1).float().mean().item() > 0.995
+
+
+def test_cond_encode_kernel_vs_oracle():
+    """gf_cond_encode (AudioNet + AudioAttNet + the two bias folds in one launch) against the oracle's cal_cond_feat
+    (the reference's cond_encoder.py modules in torch fp32) and torch folds of the same matrices."""
+    from geneface_amd.fused import _per_frame_vectors, get_state
+    hp, sd, model = build(True, "fused")
+    st = get_state(model)
+    assert st.cond is not None, "the May config must be served by the HIP condition encoder"
+    g = torch.Generator().manual_seed(5)
+    for trial in range(3):
+        cond = torch.randn(5, 1, 204, generator=g)
+        p6 = torch.tensor([[0.1 * trial, -0.05, 0.02, 0.01, 3.3, -0.02]])
+        cf_ref = R.cal_cond_feat(sd, hp, cond)
+        with torch.no_grad():
+            cf, amb_bias, torso_bias = _per_frame_vectors(model, st, cond.to(DEV), p6.to(DEV))
+            torch.cuda.synchronize()
+            assert (cf.cpu() - cf_ref).abs().max() < 1e-5
+            assert (amb_bias.cpu() - torch.mv(st.W_cond.cpu(), cf_ref)).abs().max() < 2e-5
+            v = torch.cat([model.torso_pose_embedder(p6.to(DEV)).reshape(-1), model.torso_individual_codes[0]]).cpu()
+            assert (torso_bias.cpu() - torch.mv(st.W_tconst.cpu(), v)).abs().max() < 2e-5
+            # and the module-API encoder (torch modules on the GPU) agrees with both
+            assert (model.cal_cond_feat(cond.to(DEV)).cpu() - cf_ref).abs().max() < 1e-5
