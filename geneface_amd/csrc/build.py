@@ -44,12 +44,14 @@ def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False, trace: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, trace: bool = False, variant: str = None, defines=()) -> str:
     """trace=True builds the instrumented variant (-DGF_TRACE: per-round s_memtime timeline of the head kernel, read by
-    tools/trace_head.py) into libgeneface_hip_trace.so; the product library never contains the instrumentation."""
-    obj_dir = OBJ_DIR + ("_trace" if trace else "")
-    out = OUT.replace(".so", "_trace.so") if trace else OUT
-    extra = ("-DGF_TRACE",) if trace else ()
+    tools/trace_head.py) into libgeneface_hip_trace.so; the product library never contains the instrumentation.
+    variant="x", defines=("-DFOO",) builds an experiment library libgeneface_hip_x.so (A/B runs select it with GF_HIP_LIB)."""
+    tag = "trace" if trace else variant
+    obj_dir = OBJ_DIR + (f"_{tag}" if tag else "")
+    out = OUT.replace(".so", f"_{tag}.so") if tag else OUT
+    extra = (("-DGF_TRACE",) if trace else ()) + tuple(defines)
     os.makedirs(obj_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         results = list(ex.map(lambda s: _compile(s, force, extra, obj_dir), sources()))
@@ -65,4 +67,6 @@ def build(force: bool = False, verbose: bool = False, trace: bool = False) -> st
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _defs = tuple(a for a in sys.argv[1:] if a.startswith("-D"))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, variant=_variant, defines=_defs))

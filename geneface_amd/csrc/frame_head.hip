@@ -279,6 +279,16 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     asm volatile("" : "+v"(lane16));
     const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
 
+    // Wave priority: the short VALU / LDS / gather segments run at high priority, the MFMA segments at low priority.  The
+    // co-resident workgroup is usually inside an MFMA segment (one issue slot per 64 cycles): letting this wave's scalar work
+    // through first shortens the stretch in which BOTH workgroups are off the matrix pipe, the only time it idles.
+#ifndef GF_NO_SETPRIO
+#define GF_PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define GF_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define GF_PRIO_HI() do { } while (0)
+#define GF_PRIO_LO() do { } while (0)
+#endif
     floatx16 A[4], S[4];
     WPipe wp;
 #pragma unroll
@@ -295,11 +305,13 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     GF_STAMP(7);
     __syncthreads();
     GF_STAMP(8);
+    GF_PRIO_LO();
     // ---- ambient L1 (cond_feat folded into the bias) and the 3-D half of density L1, both from H[:, 0:32]
     obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
     obw_zero<NT>(S);
     obw_mfma<NT, gf::G_AMB1, 4>(wp, Ws, lane16, Hb, A);
     obw_mfma<NT, gf::G_SIG1A, 4>(wp, Ws, lane16, Hb, S);
+    GF_PRIO_HI();
     GF_STAMP(9);
     __syncthreads();
     GF_STAMP(10);
@@ -308,8 +320,10 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(12);
     // ---- ambient L2
+    GF_PRIO_LO();
     obw_zero<NT>(A);
     obw_mfma<NT, gf::G_AMB2, 16>(wp, Ws, lane16, Hb, A);
+    GF_PRIO_HI();
     GF_STAMP(13);
     __syncthreads();
     GF_STAMP(14);
@@ -330,7 +344,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(18);
     // ---- density L1, 2-D half
+    GF_PRIO_LO();
     obw_mfma<NT, gf::G_SIG1B, 4>(wp, Ws, lane16, Hb, S);
+    GF_PRIO_HI();
     GF_STAMP(19);
     __syncthreads();
     GF_STAMP(20);
@@ -339,8 +355,10 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(22);
     // ---- density L2
+    GF_PRIO_LO();
     obw_zero<NT>(A);
     obw_mfma<NT, gf::G_SIG2, 16>(wp, Ws, lane16, Hb, A);
+    GF_PRIO_HI();
     GF_STAMP(23);
     __syncthreads();
     GF_STAMP(24);
@@ -355,8 +373,10 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         rows_from_lds<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
         sigma = expf(h0[0]);
     }
+    GF_PRIO_LO();
     obw_zero<NT>(A);
     obw_mfma<NT, gf::G_SIG3, 16>(wp, Ws, lane16, Hb, A);
+    GF_PRIO_HI();
     GF_STAMP(27);
     __syncthreads();
     GF_STAMP(28);
@@ -394,10 +414,12 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
             wpipe_refill<gf::G_COL1S + u>(wp, Ws, lane16);
             __builtin_amdgcn_sched_barrier(0);
         };
+        GF_PRIO_LO();
         sh_group(std::integral_constant<int, 0>{});
         sh_group(std::integral_constant<int, 1>{});
     }
     obw_mfma<NT, gf::G_COL1G, 16>(wp, Ws, lane16, Hb, A);
+    GF_PRIO_HI();
     GF_STAMP(31);
     __syncthreads();
     GF_STAMP(32);
@@ -474,6 +496,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     uint32_t tr_round = 0;
 #endif
 
+#ifndef GF_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);   // everything outside the MFMA segments runs at high priority (see field_round)
+#endif
     for (;;) {
         __syncthreads();  // previous round fully retired (staging, H)
         GF_STAMP(0);
@@ -523,15 +548,23 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             if (!queue_open) break;   // nothing alive, nothing left to fetch
             continue;                 // the queue still has entries: fetch again
         }
+        // Samples per ray this round: n = floor(128 / n_pool) for everyone, one more for the first `extra` rays, so the 128
+        // slots are all used whenever the pool is not full (how a ray's budget is cut into rounds does not change its result).
         uint32_t n = kPass / n_pool;
         n = n > 8u ? 8u : n;          // >= 1 since n_pool <= 128
+#ifndef GF_UNIFORM_N
+        const uint32_t extra = n < 8u ? (uint32_t)kPass - n * n_pool : 0u;   // < n_pool
+#else
+        const uint32_t extra = 0u;
+#endif
         // ------------------------------------------------------------------ A. march
         uint32_t cnt = 0, req = 0, rank = 0;
         if (alive) {
             rank = (wave ? s.misc[0] : 0u) + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
             const uint32_t left = budget - r_done;
-            req = n < left ? n : left;
-            const uint32_t base = rank * n;
+            const uint32_t mine = n + (rank < extra ? 1u : 0u);
+            req = mine < left ? mine : left;
+            const uint32_t base = rank * n + (rank < extra ? rank : extra);
             cnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req, r_t,
                                 [&](uint32_t q, float x, float y, float z, float dt, float t_after, float) {
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
@@ -559,7 +592,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         const uint32_t Mv = s.misc[2];
         if (alive) {
             const uint32_t b = s.rbase[tid];
-            for (uint32_t q = 0; q < cnt; q++) { s.d2r[b + q] = (uint8_t)(rank * n + q); s.rrank[b + q] = (uint8_t)tid; }
+            const uint32_t base = rank * n + (rank < extra ? rank : extra);
+            for (uint32_t q = 0; q < cnt; q++) { s.d2r[b + q] = (uint8_t)(base + q); s.rrank[b + q] = (uint8_t)tid; }
         }
         if (tid == 0) { st_samples += Mv; st_rounds++; st_tiles += (Mv + 31) / 32; }
         GF_STAMP(5);
@@ -578,7 +612,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         // ------------------------------------------------------------------ C. composite, retire
         bool survivor = false;
         if (alive) {
-            const uint32_t base = rank * n;
+            const uint32_t base = rank * n + (rank < extra ? rank : extra);
             bool died = false;
             uint32_t d = 0;
             for (uint32_t q = 0; q < cnt; q++) {

@@ -12,6 +12,13 @@ for s in $STEPS; do
   case $s in
     test)  timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest.log; tail -3 $OUT/pytest.log ;;
     bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
+    ab:*)  # A/B of an experiment library against the product one, interleaved, short benches: ab:<variant>
+           V=${s#ab:}
+           for rep in 1 2 3; do
+             for lib in "" "_$V"; do
+               GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip$lib.so timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/ab_$V.txt
+             done
+           done ;;
     trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160 ;;
     pmc)   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmc_sq -o sq --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 > $OUT/pmc_sq.log 2>&1)
