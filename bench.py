@@ -153,12 +153,31 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic():
+    """HBM bytes per k_head_phase launch from the newest committed PMC summary (separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes of this same command, tools/gpu_round.sh + tools/pmc_summary.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")))
+    for path in reversed(files):
+        try:
+            d = json.load(open(path)).get("k_head_phase")
+            if d and "fetch_MB_x2" in d and "write_MB_raw" in d:
+                return (d["fetch_MB_x2"] + d["write_MB_raw"]) * 1e6, os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def measure_roofline(pipe, impl, first, n_frames):
     """Dominant-kernel roofline from live HIP-event timing of that kernel's launches (outside the fps region)."""
     import torch
     if impl == "fused":
         from geneface_amd.fused import profile_frames
-        return profile_frames(pipe, first, n_frames, FLOP_PER_HEAD_SAMPLE, PEAK_F32_MFMA_TFLOPS)
+        r = profile_frames(pipe, first, n_frames, FLOP_PER_HEAD_SAMPLE, PEAK_F32_MFMA_TFLOPS)
+        r["traffic"], r["traffic_source"] = pmc_traffic()
+        r["algorithmic_bytes_per_launch"] = r["samples_per_frame"] * BYTES_PER_HEAD_SAMPLE / 2 if r.get("samples_per_frame") else None
+        return r
     # impl == "ops": the dominant kernel is whichever rocBLAS SGEMM torch dispatches; it is not ours to time per launch.
     return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
             "note": "impl=ops runs the MLPs through rocBLAS; per-kernel roofline is reported for impl=fused only"}

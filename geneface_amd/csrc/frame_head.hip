@@ -40,6 +40,7 @@
 #include "sh_core.hpp"
 #include "mfma_mlp.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -823,7 +824,10 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     }
     // persistent grid: 2 workgroups per CU x 256 CUs, never more workgroups than pools' worth of rays
     const uint32_t pools = gf_div_up(N, (uint32_t)kPool);
-    const uint32_t grid = pools < 512u ? pools : 512u;
+    uint32_t grid = pools < 512u ? pools : 512u;
+#ifdef GF_TRACE
+    if (const char* e = getenv("GF_HEAD_GRID")) { const uint32_t g = (uint32_t)atoi(e); if (g >= 1 && g <= 512) grid = g; }   // timeline experiments
+#endif
     for (uint32_t phase = 0; phase < 2; phase++) {
         ha.phase = phase;
         ha.queue = phase ? w.alive_a : w.alive_b;

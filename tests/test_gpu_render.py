@@ -165,3 +165,60 @@ def test_cond_encode_kernel_vs_oracle():
             assert (torso_bias.cpu() - torch.mv(st.W_tconst.cpu(), v)).abs().max() < 2e-5
             # and the module-API encoder (torch modules on the GPU) agrees with both
             assert (model.cal_cond_feat(cond.to(DEV)).cpu() - cf_ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("grid_type,interp", [("hashgrid", "linear"), ("hashgrid", "smoothstep"), ("tiledgrid", "smoothstep")])
+def test_fused_other_grid_configs_vs_oracle(grid_type, interp):
+    """The specialised lookup of the fused head kernel (grid_core.hpp::encode8: strides / mask / hash flag per level) on the
+    grid variants GridEncoder offers besides the May default: xor-prime hashing on the levels whose lattice does not fit
+    the table (gridencoder.cu:50-63) and smoothstep interpolation (:152-157).  Same tables, different index rule."""
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd = model_fixture(True)
+    hp = dict(hp, grid_type=grid_type, grid_interpolation_type=interp)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(sd, strict=True)
+    model.render_impl = "fused"
+    model = model.to(DEV).eval()
+    fi = frame_inputs(sequence(4, 96, 96), 2)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+    out = render_gpu(model, hp, fi)
+    check(out, ref, True)
+    model.render_impl = "ops"
+    out_ops = render_gpu(model, hp, fi)
+    check(out_ops, ref, True)
+
+
+def test_full_size_fused_vs_ops_and_invariants():
+    """BASELINE.json's full size (512x512 head+torso), where the CPU oracle takes ~6 s per frame: the two GPU execution
+    strategies (reference loop structure over stand-alone ops vs the fused two-phase kernels) must produce the same picture,
+    and size-independent properties of the path must hold: the schedule replayed on the device equals the one the op-by-op
+    loop actually ran; pixels whose ray misses the occupancy are exactly the blended background; weights stay in [0, 1]."""
+    from geneface_amd.fused import frame_stats
+    hp, sd, model = build(True, "ops")
+    fi = frame_inputs(sequence(4, 512, 512), 1)
+    out_ops = render_gpu(model, hp, fi)
+    sched_ops = [s for _, s in model.last_schedule]
+    model.render_impl = "fused"
+    out = render_gpu(model, hp, fi)
+    fs = frame_stats(model.last_ctrl, 512 * 512, hp["max_steps"])
+    assert [n for _, n in fs["schedule"]] == sched_ops
+    assert fs["budget"] == fs["budget_device"] == sum(sched_ops)
+    a, b = out["rgb_map"].float().cpu(), out_ops["rgb_map"].float().cpu()
+    assert (a - b).abs().max().item() < 5e-4 and psnr(a, b) > 65
+    u8 = (a * 255).to(torch.uint8).int() - (b * 255).to(torch.uint8).int()
+    assert (u8.abs() <= 1).float().mean().item() > 0.999
+    assert (out["depth_map"].cpu() - out_ops["depth_map"].cpu()).abs().max().item() < 2e-3
+    # rays that pass outside the (one cell padded) box around the occupied cells can have no sample at all:
+    # rgb == torso-over-background exactly (image = 0, weights_sum = 0)
+    from geneface_amd.fused import get_state
+    box = torch.tensor(get_state(model).occ_aabb)
+    cell = 2.0 * hp["bound"] / hp["grid_size"]
+    lo, hi = box[:3] - cell, box[3:] + cell
+    o, d = fi["rays_o"].reshape(-1, 3), fi["rays_d"].reshape(-1, 3)
+    t0, t1 = (lo - o) / d, (hi - o) / d
+    tn, tf = torch.minimum(t0, t1).max(dim=1).values, torch.maximum(t0, t1).min(dim=1).values
+    miss = tn > tf
+    assert 0.3 < miss.float().mean().item() < 0.9
+    bgmix = out["torso_rgb_map"].reshape(-1, 3).cpu()
+    assert torch.equal(a.reshape(-1, 3)[miss], bgmix[miss].clamp(0, 1))
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0

@@ -29,7 +29,7 @@ def main():
                 dur[(k, row["Dispatch_Id"], path)] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     summary = {}
     for k, ctrs in per.items():
-        if not any(n in k for n in ("k_head", "k_torso", "k_frame")):
+        if not any(n in k for n in ("k_head", "k_torso", "k_frame", "k_cond")):
             continue
         d = {name: sum(v) / len(v) for name, v in ctrs.items()}
         d["dispatches"] = max(len(v) for v in ctrs.values())

@@ -107,6 +107,15 @@ def main():
         # rounds per workgroup and the span of each workgroup's activity
         per_wg = used.sum(axis=1)
         print(f"  rounds per traced workgroup: {per_wg.tolist()}")
+        # lifetime of each traced workgroup in shader ticks vs the launch's wall time -> effective shader clock
+        spans = []
+        for w in range(nwg):
+            idx = np.nonzero(used[w])[0]
+            if len(idx):
+                spans.append(int((tp[w, idx[-1], SLOT_END] - tp[w, idx[0], 0]) & 0xFFFFFFFF))
+        if spans:
+            print(f"  workgroup lifetimes (ticks): min {min(spans)} max {max(spans)} -> effective clock >= {max(spans) / (ms[ph] * 1e-3) / 1e9:.3f} GHz "
+                  f"(phase {ms[ph]:.3f} ms; traced rounds are capped at {nrounds})")
         report["phases"].append({"phase": ph, "round_cycles_mean": float(total.mean()), "segments": rows})
     if args.json:
         with open(args.json, "w") as fh:
