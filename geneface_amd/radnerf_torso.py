@@ -6,6 +6,8 @@ Drop-in for `RADNeRFTorso` of modules/radnerfs/radnerf_torso.py:17-241 on the in
 and `torso_head_aware` are read from the hparams given to the constructor rather than from a
 process-global dict.  `torso_head_aware=True` (random branch at inference, :175-179) is not built.
 """
+import random
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -14,6 +16,7 @@ from . import raymarching
 from .cond_encoder import MLP
 from .encoders import get_encoder
 from .radnerf import RADNeRF
+from .renderer import _rand_like
 
 
 class RADNeRFTorso(RADNeRF):
@@ -99,5 +102,36 @@ class RADNeRFTorso(RADNeRF):
             results["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
             return results
 
-    def update_extra_state(self, decay=0.95, S=128):
-        raise NotImplementedError("density-grid maintenance is the next scope row (SURVEY.md 8f-1)")
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128, pose6=None, ind_code=None, generator=None):
+        """radnerf_torso.py:200-241: only the 2-D torso occupancy is refreshed (the head grid is frozen while the torso trains):
+        alpha of the torso field on the jittered cell centres, 5x5 max-pool dilation, EMA-max, new mean_density_torso.
+        The reference draws pose and identity code at random from `self.poses`; pass `pose6` [1,6] to fix them."""
+        dev = self.density_bitfield.device
+        if pose6 is None:
+            if not hasattr(self, "poses"):
+                raise RuntimeError("RADNeRFTorso.update_extra_state: give `pose6` or set model.poses (tasks/radnerfs/radnerf_torso.py:44-46)")
+            from .utils import convert_poses
+            rand_idx = random.randint(0, self.poses.shape[0] - 1)
+            pose6 = convert_poses(self.poses[[rand_idx]]).to(dev)
+            if ind_code is None and self.torso_individual_embedding_dim > 0:
+                ind_code = self.torso_individual_codes[rand_idx]
+        elif ind_code is None and self.torso_individual_embedding_dim > 0:
+            ind_code = self.torso_individual_codes[0]
+        G = self.grid_size
+        tmp = torch.zeros_like(self.density_grid_torso)
+        X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
+        half_grid_size = 1 / G
+        for xs in X:
+            for ys in X:
+                xx, yy = torch.meshgrid(xs, ys, indexing="ij")
+                coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1)], dim=-1)
+                indices = (coords[:, 1] * G + coords[:, 0]).long()   # xy transposed, as in the reference
+                xys = (2 * coords.float() / (G - 1) - 1) * (1 - half_grid_size)
+                noise = _rand_like(xys, generator)
+                xys = xys + (noise * 2 - 1) * half_grid_size
+                alphas, _, _ = self.forward_torso(xys, pose6.to(dev), ind_code)
+                tmp[indices] = alphas.squeeze(1).float()
+        tmp = torch.nn.functional.max_pool2d(tmp.view(1, 1, G, G), kernel_size=5, stride=1, padding=2).view(-1)
+        self.density_grid_torso = torch.maximum(self.density_grid_torso * decay, tmp)
+        self.mean_density_torso = torch.mean(self.density_grid_torso).item()

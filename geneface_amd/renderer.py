@@ -13,11 +13,21 @@ arithmetic (geneface_amd/csrc):
 Training (`self.training == True`) and density-grid maintenance are outside this round's scope.
 """
 import math
+import random
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import raymarching
+
+
+def _rand_like(x, generator=None):
+    """U[0,1) noise shaped like x; with a generator the numbers are drawn on the generator's device (a CPU generator gives
+    the same jitter to a CPU restatement and to the GPU run) and moved to x's."""
+    if generator is None:
+        return torch.rand_like(x)
+    return torch.rand(x.shape, generator=generator, device=generator.device, dtype=x.dtype).to(x.device)
 
 
 class NeRFRenderer(nn.Module):
@@ -74,11 +84,91 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
+    @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        raise NotImplementedError("density-grid maintenance is the next scope row (SURVEY.md 8f-1)")
+        """renderer.py:129-196: cells no training camera sees get density -1 (never marched, never updated).
+        poses [B,4,4] c2w (ngp axes), intrinsic (fx, fy, cx, cy).  Morton indices come from the HIP op."""
+        if not self.cuda_ray:
+            return
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        B = poses.shape[0]
+        fx, fy, cx, cy = intrinsic
+        dev = self.density_bitfield.device
+        G = self.grid_size
+        X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
+        count = torch.zeros_like(self.density_grid)
+        poses = poses.to(dev).float()
+        for xs in X:
+            for ys in X:
+                for zs in X:
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                    indices = raymarching.morton3D(coords).long()
+                    world_xyzs = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)
+                    for cas in range(self.cascade):
+                        bound = min(2 ** cas, self.bound)
+                        half_grid_size = bound / G
+                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
+                        head = 0
+                        while head < B:
+                            tail = min(head + S, B)
+                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
+                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
+                            mask_z = cam_xyzs[:, :, 2] > 0
+                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
+                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
+                            count[cas, indices] += (mask_z & mask_x & mask_y).sum(0).reshape(-1)
+                            head += S
+        self.density_grid[count == 0] = -1
 
-    def update_extra_state(self, decay=0.95, S=128):
-        raise NotImplementedError("density-grid maintenance is the next scope row (SURVEY.md 8f-1)")
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128, cond=None, generator=None):
+        """renderer.py:199-260: re-sample the density field on the jittered cell centres of every cascade, dilate in Morton
+        space, EMA-max into density_grid, re-derive mean_density and the packed density_bitfield.  The reference draws the
+        condition window at random from `self.conds` (set by the task); pass `cond` ([smo_win, cond_win, C]) to fix it.
+        `generator` seeds the cell jitter.  Field queries, Morton codes, dilation and bit packing run in libgeneface_hip.so."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        if cond is None:
+            if not hasattr(self, "conds"):
+                raise RuntimeError("update_extra_state: give `cond` or set model.conds (the task does, tasks/radnerfs/radnerf.py:44-47)")
+            from .utils import get_audio_features
+            rand_idx = random.randint(0, self.conds.shape[0] - 1)
+            cond = get_audio_features(self.conds, 2, rand_idx, self.smo_win_size)
+        enc_a = self.cal_cond_feat(cond.to(dev))
+        G = self.grid_size
+        tmp_grid = torch.zeros_like(self.density_grid)
+        X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
+        for xs in X:
+            for ys in X:
+                for zs in X:
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                    indices = raymarching.morton3D(coords).long()
+                    xyzs = 2 * coords.float() / (G - 1) - 1
+                    for cas in range(self.cascade):
+                        bound = min(2 ** cas, self.bound)
+                        half_grid_size = bound / G
+                        cas_xyzs = xyzs * (bound - half_grid_size)
+                        noise = _rand_like(cas_xyzs, generator)
+                        cas_xyzs = cas_xyzs + (noise * 2 - 1) * half_grid_size
+                        sigmas = self.density(cas_xyzs, enc_a)["sigma"].reshape(-1).detach().to(tmp_grid.dtype)
+                        tmp_grid[cas, indices] = sigmas * self.density_scale
+        tmp_grid = raymarching.morton3D_dilation(tmp_grid)
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+        from .fused import invalidate
+        invalidate(self)   # the fused path caches the occupancy bounding box of the bitfield
 
     def _pick_impl(self, impl, perturb, max_steps):
         if impl != "auto":

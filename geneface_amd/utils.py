@@ -78,3 +78,26 @@ def smooth_camera_path(poses: np.ndarray, kernel_size=7) -> np.ndarray:
         except Exception:
             poses[i, :3, :3] = rots[i] if i == 0 else poses[i - 1, :3, :3]
     return poses
+
+
+def get_audio_features(features, att_mode, index, smo_win_size):
+    """modules/radnerfs/utils.py:71-103: the window of condition frames around `index` (zero padded at the ends)."""
+    if att_mode == 0:
+        return features[[index]]
+    if att_mode == 1:
+        left = index - smo_win_size
+        pad_left = max(0, -left)
+        auds = features[max(left, 0):index]
+        if pad_left > 0:
+            auds = torch.cat([torch.zeros(pad_left, *auds.shape[1:], device=auds.device, dtype=auds.dtype), auds], dim=0)
+        return auds
+    if att_mode == 2:
+        left, right = index - smo_win_size // 2, index + (smo_win_size - smo_win_size // 2)
+        pad_left, pad_right = max(0, -left), max(0, right - features.shape[0])
+        auds = features[max(left, 0):min(right, features.shape[0])]
+        if pad_left > 0:
+            auds = torch.cat([torch.zeros(pad_left, *auds.shape[1:], device=auds.device, dtype=auds.dtype), auds], dim=0)
+        if pad_right > 0:
+            auds = torch.cat([auds, torch.zeros(pad_right, *auds.shape[1:], device=auds.device, dtype=auds.dtype)], dim=0)
+        return auds
+    raise NotImplementedError(f"wrong att_mode: {att_mode}")

@@ -253,3 +253,97 @@ def convert_poses(pose44):
     out[:, 2] = torch.atan2(-m[:, 0, 1], m[:, 0, 0])
     out[:, 3:] = pose44[:, :3, 3]
     return out
+
+
+# ----------------------------------------------------------------------------- occupancy-grid maintenance
+def _cell_coords(G, S):
+    X = torch.arange(G, dtype=torch.int32).split(S)
+    for xs in X:
+        for ys in X:
+            for zs in X:
+                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                yield torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).contiguous()
+
+
+def _morton(coords):
+    idx = torch.empty(coords.shape[0], dtype=torch.int32)
+    RM.morton3D(coords, coords.shape[0], idx)
+    return idx.long()
+
+
+def update_density_grid(sd, hp, density_grid, cond, generator, decay=0.95, S=128, density_scale=1.0):
+    """NeRFRenderer.update_extra_state (modules/radnerfs/renderer.py:199-260) for a fixed condition window and jitter
+    generator: returns (new density_grid [C, G^3], mean_density, density_bitfield u8 [C*G^3/8])."""
+    G, bound = hp["grid_size"], hp["bound"]
+    cascade = 1 + math.ceil(math.log2(bound))
+    enc_a = cal_cond_feat(sd, hp, cond)
+    tmp = torch.zeros_like(density_grid)
+    dummy_ind = sd["individual_embeddings"][0] if hp["individual_embedding_dim"] > 0 else None
+    for coords in _cell_coords(G, S):
+        indices = _morton(coords)
+        xyzs = 2 * coords.float() / (G - 1) - 1
+        for cas in range(cascade):
+            b = min(2 ** cas, bound)
+            hgs = b / G
+            cas_xyzs = xyzs * (b - hgs)
+            cas_xyzs = cas_xyzs + (torch.rand(cas_xyzs.shape, generator=generator) * 2 - 1) * hgs
+            d = torch.zeros_like(cas_xyzs)
+            d[:, 2] = 1.0
+            sigma, _, _ = head_field(sd, hp, cas_xyzs, d, enc_a, dummy_ind)
+            tmp[cas, indices] = sigma.reshape(-1) * density_scale
+    dil = torch.empty_like(tmp)
+    RM.morton3D_dilation(tmp.contiguous(), cascade, G, dil)
+    grid = density_grid.clone()
+    valid = (grid >= 0) & (dil >= 0)
+    grid[valid] = torch.maximum(grid[valid] * decay, dil[valid])
+    mean_density = torch.mean(grid.clamp(min=0)).item()
+    thresh = min(mean_density, hp["density_thresh"])
+    bits = torch.zeros(cascade * G ** 3 // 8, dtype=torch.uint8)
+    RM.packbits(grid.contiguous(), bits.numel(), thresh, bits)
+    return grid, mean_density, bits
+
+
+def update_density_grid_torso(sd, hp, density_grid_torso, pose6, code, generator, decay=0.95, S=128):
+    """RADNeRFTorso.update_extra_state (modules/radnerfs/radnerf_torso.py:200-241) for a fixed pose / identity code."""
+    G = hp["grid_size"]
+    tmp = torch.zeros_like(density_grid_torso)
+    X = torch.arange(G, dtype=torch.int32).split(S)
+    hgs = 1 / G
+    for xs in X:
+        for ys in X:
+            xx, yy = torch.meshgrid(xs, ys, indexing="ij")
+            coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1)], dim=-1)
+            indices = (coords[:, 1] * G + coords[:, 0]).long()
+            xys = (2 * coords.float() / (G - 1) - 1) * (1 - hgs)
+            xys = xys + (torch.rand(xys.shape, generator=generator) * 2 - 1) * hgs
+            alphas, _, _ = torso_field(sd, hp, xys, pose6, code)
+            tmp[indices] = alphas.squeeze(1).float()
+    tmp = F.max_pool2d(tmp.view(1, 1, G, G), kernel_size=5, stride=1, padding=2).view(-1)
+    grid = torch.maximum(density_grid_torso * decay, tmp)
+    return grid, torch.mean(grid).item()
+
+
+def mark_untrained_grid(hp, density_grid, poses, intrinsic, S=64):
+    """NeRFRenderer.mark_untrained_grid (modules/radnerfs/renderer.py:129-196): -1 where no camera sees the cell."""
+    G, bound = hp["grid_size"], hp["bound"]
+    cascade = 1 + math.ceil(math.log2(bound))
+    fx, fy, cx, cy = intrinsic
+    count = torch.zeros_like(density_grid)
+    B = poses.shape[0]
+    for coords in _cell_coords(G, S):
+        indices = _morton(coords)
+        world = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)
+        for cas in range(cascade):
+            b = min(2 ** cas, bound)
+            hgs = b / G
+            cw = world * (b - hgs)
+            head = 0
+            while head < B:
+                tail = min(head + S, B)
+                cam = (cw - poses[head:tail, :3, 3].unsqueeze(1)) @ poses[head:tail, :3, :3]
+                m = (cam[:, :, 2] > 0) & (cam[:, :, 0].abs() < cx / fx * cam[:, :, 2] + hgs * 2) & (cam[:, :, 1].abs() < cy / fy * cam[:, :, 2] + hgs * 2)
+                count[cas, indices] += m.sum(0).reshape(-1)
+                head += S
+    out = density_grid.clone()
+    out[count == 0] = -1
+    return out
