@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-frames", type=int, default=8)
+    ap.add_argument("--head-only", action="store_true", help="BASELINE.json configs[1]: May lm3d_radnerf head-only (default: configs[2], head+torso)")
     return ap.parse_args()
 
 
-def cpu_baseline(hp, sd, seq, n_frames):
+def cpu_baseline(hp, sd, seq, n_frames, torso=True):
     """The oracle (CPU port of the reference's render path: torch-fp32 layers over the C kernels) timed on the host
     cores of this box, on a bounded sample of the same workload."""
     import torch
@@ -55,14 +56,14 @@ def cpu_baseline(hp, sd, seq, n_frames):
     def one(i):
         pose = torch.from_numpy(seq["poses"][i:i + 1])
         ro, rd = R.get_rays(pose, seq["intrinsics"], H, W)
-        return R.render(sd, hp, ro, rd, torch.from_numpy(seq["cond_wins"][i]), bgc, R.convert_poses(pose), bg, torso=True)
+        return R.render(sd, hp, ro, rd, torch.from_numpy(seq["cond_wins"][i]), bgc, R.convert_poses(pose), bg, torso=torso)
     one(0)  # warm-up (thread pools, page faults)
     t0 = time.perf_counter()
     for i in range(1, 1 + n_frames):
         one(i)
     dt = time.perf_counter() - t0
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_frames} head+torso {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
+            "sample": f"{n_frames} {'head+torso' if torso else 'head-only'} {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
 
 
 def main():
@@ -87,6 +88,7 @@ def main():
     from geneface_amd import hparams as HP
     from geneface_amd import synthetic as S
     from geneface_amd.infer import FramePipeline, broadcast_model_, shard_range
+    from geneface_amd.radnerf import RADNeRF
     from geneface_amd.radnerf_torso import RADNeRFTorso
 
     impl = args.impl
@@ -97,12 +99,13 @@ def main():
         except ImportError:
             impl = "ops"
 
-    hp = HP.may_hparams(True)
+    torso = not args.head_only
+    hp = HP.may_hparams(torso)
     K, Wm = args.steps, args.warmup
     per_rank = K + Wm
     seq = S.make_sequence(per_rank * world, args.size, args.size, hp)
-    sd = S.make_state_dict(hp, True)
-    model = RADNeRFTorso(hp)
+    sd = S.make_state_dict(hp, torso)
+    model = (RADNeRFTorso if torso else RADNeRF)(hp)
     if rank == 0:
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
@@ -134,17 +137,19 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "rendered 512x512 fps (head+torso)", "value": world * K / dt, "unit": "frames/s", "n_gpus": world,
+            "metric": "rendered 512x512 fps (head+torso)" if torso else "rendered 512x512 fps (head only)", "value": world * K / dt, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
-                                   f"(BASELINE.json configs[2]); frame-sharded over {world} GPU(s)",
+            "config": {"workload": (f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
+                                    f"(BASELINE.json configs[2])" if torso else
+                                    f"May lm3d_radnerf head-only {args.size}x{args.size}, {K} frames per GPU (BASELINE.json configs[1])")
+                                   + f"; frame-sharded over {world} GPU(s)",
                        "impl": impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
                        "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}"},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(hp, sd, seq, args.cpu_frames)
+            line["cpu_baseline"] = cpu_baseline(hp, sd, seq, args.cpu_frames, torso)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -171,26 +171,40 @@ __global__ void __launch_bounds__(kThreads) k_cond_encode(const gf_cond_t a) {
 
 }  // namespace
 
+// Validation only (HOST): 0 when gf_cond_encode can serve this encoder / window, else an error code + gf_last_error() text.
+// Pointers that change per frame (cond, outputs, pose6) are not examined.
+GF_EXPORT int gf_cond_check(const gf_cond_t* c) {
+    if (!c) return gf_set_error(GF_ERR_INVALID, "cond_encode: null descriptor");
+    if (c->S == 0 || c->S > (uint32_t)kMaxS || c->T == 0 || c->T > (uint32_t)kMaxT || c->C == 0 || c->C > (uint32_t)kMaxC)
+        return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: window [%u, %u, %u] outside the fused encoder's limits", c->S, c->T, c->C);
+    if (c->dim_aud == 0 || c->dim_aud > 128) return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: dim_aud must be 1..128");
+    if (c->conv_ch[0] != c->C || c->conv_ch[4] != 64) return gf_set_error(GF_ERR_INVALID, "cond_encode: conv channels must run C -> ... -> 64");
+    uint32_t len = c->T, biggest = c->S * c->C * c->T;
+    for (int l = 0; l < 4; l++) {
+        if (!c->conv_w[l] || !c->conv_b[l] || c->conv_stride[l] == 0 || c->conv_ch[l + 1] == 0 || c->conv_ch[l + 1] > 64)
+            return gf_set_error(GF_ERR_INVALID, "cond_encode: bad conv layer %d", l);
+        if (c->conv_ch[l + 1] * c->conv_ch[l] * 3 > (uint32_t)kWFloats) return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: conv layer %d does not fit the LDS weight stage", l);
+        len = (len + 2 - 3) / c->conv_stride[l] + 1;
+        const uint32_t sz = c->S * c->conv_ch[l + 1] * len;
+        biggest = sz > biggest ? sz : biggest;
+    }
+    if (len != 1) return gf_set_error(GF_ERR_INVALID, "cond_encode: the conv stack must shrink the window to length 1 (got %u)", len);
+    if (biggest > (uint32_t)kActFloats || 2 * c->S * c->dim_aud > (uint32_t)kActFloats)
+        return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: activations of window [%u, %u, %u] exceed the LDS buffers", c->S, c->T, c->C);
+    if (!c->fc1_w || !c->fc1_b || !c->fc2_w || !c->fc2_b || !c->att_lin_w || !c->att_lin_b) return gf_set_error(GF_ERR_INVALID, "cond_encode: null FC / attention weights");
+    for (int l = 0; l < 5; l++) if (!c->att_w[l] || !c->att_b[l]) return gf_set_error(GF_ERR_INVALID, "cond_encode: null attention conv %d", l);
+    if (c->code_dim > 64) return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: identity code longer than 64");
+    return GF_OK;
+}
+
 // cond [S, T, C] -> cond_feat [dim_aud] (= RADNeRF.cal_cond_feat with with_att, radnerf.py:61-71) and, when the output pointers
 // are given, the folded first-layer biases of the fused field kernels.  Enqueues one launch on `stream`.
 GF_EXPORT int gf_cond_encode(const gf_cond_t* c, void* stream) {
     if (!c || !c->cond || !c->cond_feat) return gf_set_error(GF_ERR_INVALID, "cond_encode: null pointer");
-    if (c->S == 0 || c->S > (uint32_t)kMaxS || c->T == 0 || c->T > (uint32_t)kMaxT || c->C == 0 || c->C > (uint32_t)kMaxC ||
-        c->S * c->T * (c->C > 64 ? c->C : 64) > (uint32_t)kActFloats)
-        return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: window [%u, %u, %u] outside the fused encoder's limits", c->S, c->T, c->C);
-    if (c->dim_aud == 0 || c->dim_aud > 128) return gf_set_error(GF_ERR_UNSUPPORTED, "cond_encode: dim_aud must be 1..128");
-    if (c->conv_ch[0] != c->C || c->conv_ch[4] != 64) return gf_set_error(GF_ERR_INVALID, "cond_encode: conv channels must run C -> ... -> 64");
-    uint32_t len = c->T;
-    for (int l = 0; l < 4; l++) {
-        if (!c->conv_w[l] || !c->conv_b[l] || c->conv_stride[l] == 0 || c->conv_ch[l + 1] == 0 || c->conv_ch[l + 1] > 64)
-            return gf_set_error(GF_ERR_INVALID, "cond_encode: bad conv layer %d", l);
-        len = (len + 2 - 3) / c->conv_stride[l] + 1;
-    }
-    if (len != 1) return gf_set_error(GF_ERR_INVALID, "cond_encode: the conv stack must shrink the window to length 1 (got %u)", len);
-    if (!c->fc1_w || !c->fc1_b || !c->fc2_w || !c->fc2_b || !c->att_lin_w || !c->att_lin_b) return gf_set_error(GF_ERR_INVALID, "cond_encode: null FC / attention weights");
-    for (int l = 0; l < 5; l++) if (!c->att_w[l] || !c->att_b[l]) return gf_set_error(GF_ERR_INVALID, "cond_encode: null attention conv %d", l);
+    const int rc = gf_cond_check(c);
+    if (rc) return rc;
     if (c->amb_bias && !c->W_cond) return gf_set_error(GF_ERR_INVALID, "cond_encode: amb_bias needs W_cond");
-    if (c->torso_bias && (!c->W_tconst || !c->pose6 || (c->code_dim && !c->torso_code) || c->code_dim > 64))
+    if (c->torso_bias && (!c->W_tconst || !c->pose6 || (c->code_dim && !c->torso_code)))
         return gf_set_error(GF_ERR_INVALID, "cond_encode: torso_bias needs W_tconst, pose6 and the identity code");
     static bool attr_set = false;
     if (!attr_set) {

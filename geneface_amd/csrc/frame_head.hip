@@ -58,6 +58,7 @@ constexpr uint32_t kMarchSlack = 3;   // empty-space skips a ray may add to its 
 #ifdef GF_TRACE
 constexpr int kTraceSlots = 48, kTraceRounds = 48, kTraceWGs = 16;
 static uint32_t* g_trace_buf = nullptr;
+static unsigned long long* g_span_buf = nullptr;
 #define GF_STAMP(i)                                                              \
     do {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                       \
@@ -83,6 +84,7 @@ struct HeadArgs {
     float T_thresh, bound;
 #ifdef GF_TRACE
     uint32_t* trace;
+    unsigned long long* spans;   // [2 phases][512 workgroups][start tick, end tick, rounds, XCC id]
 #endif
 };
 
@@ -450,6 +452,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: per-wave weight-stream bases stay in SGPRs
     const bool owner = tid < kPool;
+#ifdef GF_TRACE
+    const unsigned long long span_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- phase set-up (uniform) ----
     uint32_t budget, limit;
@@ -664,6 +669,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         const uint32_t v = s.hist[tid];
         if (v) atomicAdd(&a.ctrl[gf::kCtrlHist + tid], v);
     }
+#ifdef GF_TRACE
+    if (tid == 0 && a.spans) {   // per-workgroup lifetime (s_memtime offsets differ between CUs: only differences are meaningful)
+        unsigned long long* sp = a.spans + ((size_t)a.phase * 512 + blockIdx.x) * 4;
+        sp[0] = span_t0; sp[1] = __builtin_amdgcn_s_memtime(); sp[2] = st_rounds; sp[3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID */);
+    }
+#endif
     if (tid == 0) {
         atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], st_samples);
         atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], st_rounds);
@@ -814,6 +825,7 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.T_thresh = f->T_thresh; ha.bound = f->bound;
 #ifdef GF_TRACE
     ha.trace = g_trace_buf;
+    ha.spans = g_span_buf;
 #endif
 
     static bool attr_set = false;
@@ -843,6 +855,8 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
 #ifdef GF_TRACE
 // trace build only: device buffer of 2 * kTraceWGs * kTraceRounds * kTraceSlots uint32 (phase, workgroup, round, slot)
 GF_EXPORT void gf_trace_set(void* dev_buf) { g_trace_buf = reinterpret_cast<uint32_t*>(dev_buf); }
+// device buffer of 2 * 512 * 4 uint64: per phase and workgroup {start tick, end tick, rounds, XCC id}
+GF_EXPORT void gf_trace_set_spans(void* dev_buf) { g_span_buf = reinterpret_cast<unsigned long long*>(dev_buf); }
 GF_EXPORT uint32_t gf_trace_dims(uint32_t which) { return which == 0 ? kTraceWGs : which == 1 ? kTraceRounds : kTraceSlots; }
 #endif
 

@@ -145,6 +145,8 @@ class FusedState:
             c.code_dim = int(model.torso_individual_embedding_dim)
             self._torso_code = model.torso_individual_codes[0].detach().contiguous() if c.code_dim > 0 else None
             c.torso_code = ptr(self._torso_code) if self._torso_code is not None else None
+        if L.gf_cond_check(C.byref(c)) != 0:
+            return None   # window / encoder outside the kernel's limits: the torch modules serve it
         return c
 
     @staticmethod

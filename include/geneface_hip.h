@@ -157,6 +157,7 @@ typedef struct gf_cond_t {
     float* torso_bias;                  /* out [96] or NULL */
 } gf_cond_t;
 uint64_t gf_cond_sizeof(void);
+int gf_cond_check(const gf_cond_t* cond);            /* HOST: can gf_cond_encode serve this encoder / window? (no launch) */
 int gf_cond_encode(const gf_cond_t* cond, void* stream);
 
 uint64_t gf_frame_sizeof(void);

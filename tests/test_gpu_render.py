@@ -222,3 +222,33 @@ def test_full_size_fused_vs_ops_and_invariants():
     bgmix = out["torso_rgb_map"].reshape(-1, 3).cpu()
     assert torch.equal(a.reshape(-1, 3)[miss], bgmix[miss].clamp(0, 1))
     assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+
+
+@pytest.mark.parametrize("cond_type,cin", [("esperanto", 44), ("deepspeech", 29)])
+def test_audio_driven_identity_vs_oracle(cond_type, cin):
+    """The audio-driven RAD-NeRF variant the reference ships for its second identity (egs/datasets/videos/Obama/radnerf.yaml ->
+    egs/egs_bases/radnerf/radnerf.yaml:4-7: 16-frame audio-feature windows, smo_win_size 8) with different weights and a
+    different seed: same kernels, the condition encoder runs its strided-conv branch (cond_encoder.py:14-41, T=16 -> 1)."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.fused import _per_frame_vectors, get_state
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = dict(HP.may_hparams(True), cond_type=cond_type, cond_win_size=16, smo_win_size=8)
+    sd = S.make_state_dict(hp, True, seed=1000)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(sd, strict=True)
+    model.render_impl = "fused"
+    model = model.to(DEV).eval()
+    fi = frame_inputs(sequence(4, 64, 64), 1)
+    cond = torch.randn(8, 16, cin, generator=torch.Generator().manual_seed(9))
+    st = get_state(model)
+    assert st.cond is not None and (st.cond.S, st.cond.T, st.cond.C) == (8, 16, cin)
+    cf_ref = R.cal_cond_feat(sd, hp, cond)
+    with torch.no_grad():
+        cf, _, _ = _per_frame_vectors(model, st, cond.to(DEV), fi["pose6"].to(DEV))
+    assert (cf.cpu() - cf_ref).abs().max() < 2e-5
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], cond, fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+    to = lambda t: t.to(DEV)
+    out = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(cond), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                       bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    check(out, ref, True)

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["GF_HIP_LIB"] = os.path.join(ROOT, "geneface_amd", "csrc", "libgeneface_hip_trace.so")
+os.environ.setdefault("GF_HIP_LIB", os.path.join(ROOT, "geneface_amd", "csrc", "libgeneface_hip_trace.so"))
 
 NAMES = {
     (0, 1): "refill (queue atomic + ray loads)", (1, 2): "census barrier", (2, 3): "march", (3, 4): "barrier after march",
@@ -67,6 +67,9 @@ def main():
     torch.cuda.synchronize()
     L.gf_trace_set(C.c_void_p(buf.data_ptr()))
     buf.zero_()
+    spans = torch.zeros(2 * 512 * 4, dtype=torch.int64, device=dev)
+    L.gf_trace_set_spans.argtypes = [C.c_void_p]
+    L.gf_trace_set_spans(C.c_void_p(spans.data_ptr()))
     with torch.no_grad():
         f = GfFrame()
         st, bufs, keep = _fill_pose_frame(pipe, args.frame, f, None)
@@ -79,6 +82,17 @@ def main():
     t = buf.cpu().numpy().astype(np.int64).reshape(2, nwg, nrounds, nslots) & 0xFFFFFFFF
     print(f"frame {args.frame} {args.size}x{args.size}: phase ms = {ms[0]:.3f} {ms[1]:.3f}; stats = {json.dumps(fs)}")
     report = {"phase_ms": [ms[0], ms[1]], "stats": fs, "phases": []}
+    sp = spans.cpu().numpy().reshape(2, 512, 4)
+    for ph in range(2):
+        live = sp[ph][sp[ph][:, 1] != 0]
+        if not len(live):
+            continue
+        life = live[:, 1] - live[:, 0]
+        q = np.percentile(life, [10, 50, 90])
+        print(f"phase {ph}: {len(live)} workgroups; lifetime min/p10/p50/p90/max = {life.min()}/{q[0]:.0f}/{q[1]:.0f}/{q[2]:.0f}/{life.max()} ticks "
+              f"(mean {life.mean():.0f}); max lifetime over {ms[ph]:.3f} ms -> shader clock >= {life.max() / (ms[ph] * 1e-3) / 1e9:.3f} GHz; "
+              f"rounds min/mean/max {live[:, 2].min()}/{live[:, 2].mean():.1f}/{live[:, 2].max()}; perfectly balanced the phase would take "
+              f"{100 * life.mean() / life.max():.1f}% of its time")
     for ph in range(2):
         tp = t[ph]
         used = tp[:, :, SLOT_END] != 0
