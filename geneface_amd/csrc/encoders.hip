@@ -132,6 +132,38 @@ GF_EXPORT int gf_grid_encode_forward_blc(const float* inputs, const float* embed
     return grid_encode_any(true, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, stream);
 }
 
+// ---- the fused head kernel's specialised lookup (grid_core.hpp::encode8), exposed stand-alone so that it can be checked point
+// by point against the generic operator: one lane pair per point (half h evaluates levels 8h .. 8h+7), output [B, 32].
+template <uint32_t D>
+__global__ void __launch_bounds__(256) k_encode8(const float* __restrict__ inputs, const float* __restrict__ table, const int* __restrict__ offsets,
+                                                 gf::GridLevels lv, uint32_t B, uint32_t gridtype, uint32_t interp, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) gf::LevelMeta meta[16];
+    if (threadIdx.x < 16) meta[threadIdx.x] = gf::make_level_meta<D>(lv.scale[threadIdx.x], lv.resolution[threadIdx.x], offsets, threadIdx.x, gridtype);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5;
+    const uint32_t b = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 32u + (lane & 31u);
+    if (b >= B) return;
+    float x[D], f[16];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+    gf::encode8<D>(table, meta + half * 8, gridtype, interp, x, f);
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[(size_t)b * 32 + half * 16 + i] = f[i];
+}
+
+GF_EXPORT int gf_grid_encode_fused_lookup(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                                          uint32_t D, float S, uint32_t H, uint32_t gridtype, uint32_t interp, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!inputs || !embeddings || !offsets || !outputs) return gf_set_error(GF_ERR_INVALID, "grid_encode_fused_lookup: null pointer");
+    if (D != 2 && D != 3) return gf_set_error(GF_ERR_UNSUPPORTED, "grid_encode_fused_lookup: D must be 2 or 3");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, 16, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_fused_lookup: bad levels");
+    const dim3 grid(gf_div_up(B, 128u)), block(256);
+    if (D == 3) hipLaunchKernelGGL(k_encode8<3>, grid, block, 0, gf_stream(stream), inputs, embeddings, offsets, lv, B, gridtype, interp, outputs);
+    else hipLaunchKernelGGL(k_encode8<2>, grid, block, 0, gf_stream(stream), inputs, embeddings, offsets, lv, B, gridtype, interp, outputs);
+    return gf_check_launch("grid_encode_fused_lookup");
+}
+
 GF_EXPORT int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out, uint32_t* resolution_out) {
     gf::GridLevels lv;
     if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_level_meta: L must be in [1,32]");

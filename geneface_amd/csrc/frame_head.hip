@@ -219,6 +219,14 @@ __device__ __forceinline__ void obw_bias(const float* bias16, floatx16 (&acc)[4]
     }
 }
 
+// max(x, 0) as ONE v_max_f32: fmaxf / fmed3 lower to a canonicalising v_max_f32 x, x, x followed by the max (IEEE sNaN quieting),
+// which doubles the VALU work of every write-back; MFMA results are never signalling NaNs.
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 // Accumulator registers 4q..4q+3 of (lane half h) are features 32w + 8q + 4h + 0..3 of sample (lane & 31): one ds_write_b128.
 // Hw = &H[lane & 31][32 * wave + 4 * (lane >> 5)].
 template <int NT, bool RELU>
@@ -228,7 +236,7 @@ __device__ __forceinline__ void obw_store(float* Hw, const floatx16 (&acc)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-            if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
             *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
         }
 }

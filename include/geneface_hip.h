@@ -70,6 +70,10 @@ int gf_grid_encode_forward(const float* inputs, const float* embeddings, const i
 int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
                                int align_corners, uint32_t interp, void* stream);
+/* The fused head kernel's specialised 16-level C=2 lookup (strides / mask / hash flag per level), stand-alone: inputs [B,D] in [0,1], outputs [B,32].  Same results as gf_grid_encode_forward_blc; exists so
+ * tests can compare the two point by point (level sizes must satisfy gf_grid_levels_fusable). */
+int gf_grid_encode_fused_lookup(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
+                                uint32_t D, float S, uint32_t H, uint32_t gridtype, uint32_t interp, void* stream);
 /* HOST helper: per-level scale / resolution exactly as the kernels use them (gridencoder.cu:138-139). */
 int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out_host, uint32_t* resolution_out_host);
 

@@ -169,3 +169,48 @@ def test_empty_inputs_are_noops():
     assert n.numel() == 0 and f.numel() == 0
     sh, _ = get_encoder("spherical_harmonics")
     assert sh(z).shape == (0, 16)
+
+
+@pytest.mark.parametrize("D,desired", [(3, 2048), (2, 2048)])
+@pytest.mark.parametrize("gridtype,interp", [(1, 0), (1, 1), (0, 0)])
+def test_fused_lookup_equals_generic_operator(D, desired, gridtype, interp):
+    """grid_core.hpp::encode8 (what the fused head kernel evaluates: per-level strides / mask / hash flag instead of the
+    generic stride walk + integer modulo) against the generic operator on 2 M random points PLUS points constructed to sit
+    in the last row of a wrapped level, where the x-neighbour wraps to row 0 (index & mask == mask)."""
+    import ctypes as C
+    from geneface_amd.encoders.gridencoder import grid_offsets, per_level_scale_for
+    from geneface_amd.lib import check, current_stream, lib, ptr
+    L, Hres, log2 = 16, 16, 16
+    off = grid_offsets(D, L, Hres, log2, desired)
+    pls = per_level_scale_for(desired, Hres, L)
+    S = float(np.log2(pls))
+    g = torch.Generator().manual_seed(D * 10 + gridtype)
+    table = (torch.rand(int(off[-1]), 2, generator=g) * 2 - 1).to(DEV)
+    offsets = torch.from_numpy(off).to(DEV)
+    pts = [torch.rand(2_000_000, D, generator=g)]
+    # cells whose tiled index lands on the last row of a wrapped level (mask = 65535)
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * np.float32(S)) * Hres - 1)
+        res1 = int(np.ceil(scale)) + 1 + 1
+        size = int(off[l + 1] - off[l])
+        if res1 ** D <= size:
+            continue
+        s1 = res1 if 1 <= size else 0
+        ys = torch.arange(0, res1 - 1)
+        xs = (65535 - (ys * s1) % 65536) % 65536
+        ok = xs < res1 - 1
+        cells = torch.stack([xs[ok], ys[ok]] + ([torch.zeros_like(xs[ok])] if D == 3 else []), dim=1).float()
+        if D == 3 and res1 * res1 <= size:   # z participates in the index on this level: keep z = 0 (contributes nothing)
+            pass
+        pts.append(((cells + 0.25) - 0.5) / float(scale))   # pos = x * scale + 0.5 lands inside cell `cells`
+    x = torch.cat(pts).clamp(0, 1).contiguous().to(DEV)
+    B = x.shape[0]
+    ref = torch.empty(B, 32, device=DEV)
+    out = torch.empty(B, 32, device=DEV)
+    check(lib().gf_grid_encode_forward_blc(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(ref), B, D, 2, L, S, Hres, None, gridtype, 0, interp,
+                                           current_stream(x.device)))
+    check(lib().gf_grid_encode_fused_lookup(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(out), B, D, S, Hres, gridtype, interp,
+                                            current_stream(x.device)))
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 1e-6
+    assert B > 2_000_000   # the wrap cases were generated
