@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 for s in $STEPS; do
   case $s in
     test)  timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest.log; tail -3 $OUT/pytest.log ;;
+    testv:*) V=${s#testv:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_$V.log; tail -3 $OUT/pytest_$V.log ;;
     bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     ab:*)  # A/B of an experiment library against the product one, interleaved, short benches: ab:<variant>
            V=${s#ab:}
