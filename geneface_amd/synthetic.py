@@ -157,12 +157,12 @@ def head_occupancy(G: int, bound: float, seed: int = 0) -> np.ndarray:
 
 
 def make_density_bitfield(G=128, cascade=1, bound=1.0, seed=0) -> np.ndarray:
-    occ = head_occupancy(G, bound, seed)
     idx = np.arange(G)
     X, Y, Z = np.meshgrid(idx, idx, idx, indexing="ij")
     flat = np.zeros(cascade * G ** 3, dtype=np.uint8)
     m = _morton3d(X.ravel(), Y.ravel(), Z.ravel())
-    flat[m] = occ.ravel()  # cascade 0 only: bound == 1 gives a single cascade
+    for c in range(cascade):  # cascade c covers [-min(2^c, bound), min(2^c, bound)]^3 (raymarching.cu:883-892)
+        flat[c * G ** 3 + m] = head_occupancy(G, min(2.0 ** c, float(bound)), seed).ravel()
     return np.packbits(flat.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
 
 

@@ -252,3 +252,23 @@ def test_audio_driven_identity_vs_oracle(cond_type, cin):
     out = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(cond), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
                        bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
     check(out, ref, True)
+
+
+def test_two_cascades_vs_oracle():
+    """bound = 2 (two occupancy cascades, renderer.py:67): the marcher picks the mip level per sample from position and step
+    size (raymarching.cu:42-54,868-878), the occupancy bounding box spans both cascades, the 3-D grid covers [-2, 2]."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = dict(HP.may_hparams(True), bound=2)
+    sd = S.make_state_dict(hp, True, seed=3)
+    for impl in ("ops", "fused"):
+        model = RADNeRFTorso(hp)
+        model.load_state_dict(sd, strict=True)
+        model.render_impl = impl
+        model = model.to(DEV).eval()
+        assert model.cascade == 2
+        fi = frame_inputs(sequence(4, 96, 96), 1)
+        ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+        out = render_gpu(model, hp, fi)
+        check(out, ref, True)
