@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-frames", type=int, default=8)
+    ap.add_argument("--no-overlap", action="store_true", help="one stream: frames do not overlap (per-kernel profiling runs)")
     ap.add_argument("--head-only", action="store_true", help="BASELINE.json configs[1]: May lm3d_radnerf head-only (default: configs[2], head+torso)")
     return ap.parse_args()
 
@@ -110,7 +111,7 @@ def main():
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     broadcast_model_(model, src=0)  # the only collective (RCCL): one flattened weight buffer
-    pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl)
+    pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl, overlap=not args.no_overlap)
 
     def barrier():
         if world > 1:
@@ -145,7 +146,8 @@ def main():
                                     f"May lm3d_radnerf head-only {args.size}x{args.size}, {K} frames per GPU (BASELINE.json configs[1])")
                                    + f"; frame-sharded over {world} GPU(s)",
                        "impl": impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
-                       "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}"},
+                       "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}",
+                       "frames_in_flight": 1 if (args.no_overlap or impl != "fused") else 2},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

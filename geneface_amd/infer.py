@@ -52,7 +52,7 @@ class FramePipeline:
     cond_wins [T,smo,win,C], poses [T,4,4] (ngp axes, already smoothed), intrinsics [4], bg_img [H*W,3], H, W.
     """
 
-    def __init__(self, model, hp: dict, seq: dict, device, frames=None, impl: str = None, pinned_outputs: int = 2):
+    def __init__(self, model, hp: dict, seq: dict, device, frames=None, impl: str = None, pinned_outputs: int = 2, overlap: bool = True):
         self.model, self.hp, self.device = model, hp, torch.device(device)
         self.H, self.W = int(seq["H"]), int(seq["W"])
         self.impl = impl or model.render_impl
@@ -73,7 +73,9 @@ class FramePipeline:
         # tail of frame i; each stream is in order, and the pinned-buffer events order the host reads
         self._streams = None
         if dev.type == "cuda" and self.impl == "fused":
-            self._streams = [torch.cuda.Stream(dev) for _ in range(2)]
+            # overlap=False keeps every frame on ONE side stream: kernels of consecutive frames never share the GPU, which is
+            # what per-kernel profiling (rocprofv3 durations, HIP-event timing) wants; throughput runs use two
+            self._streams = [torch.cuda.Stream(dev) for _ in range(2 if overlap else 1)]
             for st in self._streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
 
@@ -102,7 +104,7 @@ class FramePipeline:
             self._events[slot].synchronize()   # the host side of this slot's previous frame has been handed out and may be reused
         if self.impl == "fused":
             from .fused import render_frame_fused
-            with torch.cuda.stream(self._streams[slot % 2]):
+            with torch.cuda.stream(self._streams[slot % len(self._streams)]):
                 rgb8 = render_frame_fused(self, i, slot % 2)
                 self._pinned[slot].copy_(rgb8, non_blocking=True)
                 ev = torch.cuda.Event()
