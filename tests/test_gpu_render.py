@@ -272,3 +272,89 @@ def test_two_cascades_vs_oracle():
         ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
         out = render_gpu(model, hp, fi)
         check(out, ref, True)
+
+
+def _render_both(hp, sd, fi, torso=True, **over):
+    """oracle + both GPU strategies for one frame with hparams overrides."""
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = dict(hp, **over)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
+    outs = {}
+    for impl in ("ops", "fused"):
+        m = (RADNeRFTorso if torso else RADNeRF)(hp)
+        m.load_state_dict(sd, strict=True)
+        m.render_impl = impl
+        m = m.to(DEV).eval()
+        outs[impl] = render_gpu(m, hp, fi)
+    return ref, outs
+
+
+def test_edge_empty_occupancy():
+    """No occupied cell: every ray terminates in the set-up kernel, both field launches find empty queues, the frame is the
+    (torso-blended) background exactly and depth is 0."""
+    hp, sd = model_fixture(True)
+    sd = dict(sd, density_bitfield=torch.zeros_like(sd["density_bitfield"]))
+    fi = frame_inputs(sequence(4, 64, 64), 0)
+    ref, outs = _render_both(hp, sd, fi)
+    for impl, out in outs.items():
+        check(out, ref, True)
+        assert torch.equal(out["rgb_map"].cpu().reshape(-1, 3), out["torso_rgb_map"].cpu().reshape(-1, 3).clamp(0, 1)), impl
+        assert float(out["depth_map"].abs().max()) == 0.0
+
+
+def test_edge_full_occupancy_and_long_budgets():
+    """Every cell occupied (rays march from the box entry, budgets are what the schedule gives them) and the three budget
+    regimes of the fused path: max_steps below, at and above the May value, up to the fused limit of 64."""
+    hp, sd = model_fixture(False)
+    sd = dict(sd, density_bitfield=torch.full_like(sd["density_bitfield"], 255))
+    fi = frame_inputs(sequence(4, 48, 48), 2)
+    for ms in (4, 16, 64):
+        ref, outs = _render_both(hp, sd, fi, torso=False, max_steps=ms)
+        for out in outs.values():
+            check(out, ref, False)
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (1, 3), (37, 50), (5, 129)])
+def test_edge_ragged_ray_counts(H, W):
+    """Ray counts that are not multiples of the wave / workgroup / tile sizes, down to a single ray."""
+    hp, sd = model_fixture(True)
+    seq = sequence(4, 64, 64)
+    fi64 = frame_inputs(seq, 1)
+    idx = torch.linspace(0, 64 * 64 - 1, H * W).long()        # a ragged subset of the 64x64 frame's rays
+    fi = dict(fi64, rays_o=fi64["rays_o"][:, idx].contiguous(), rays_d=fi64["rays_d"][:, idx].contiguous(),
+              bg_coords=fi64["bg_coords"][:, idx].contiguous(), bg=fi64["bg"][:, idx].contiguous())
+    ref, outs = _render_both(hp, sd, fi)
+    for out in outs.values():
+        check_small(out, ref)
+
+
+def check_small(out, ref):
+    rgb, rgb_ref = out["rgb_map"].cpu(), ref["rgb_map"]
+    assert rgb.shape == rgb_ref.shape
+    assert (rgb - rgb_ref).abs().max().item() < RGB_ATOL
+    assert (out["depth_map"].cpu() - ref["depth_map"]).abs().max().item() < 2e-3
+    for k in ("torso_alpha_map", "torso_rgb_map"):
+        assert (out[k].cpu().reshape(ref[k].shape) - ref[k]).abs().max().item() < 2e-5
+
+
+def test_edge_thresholds_and_step_scale():
+    """T_thresh (early termination) and dt_gamma (distance-proportional steps, raymarching.cu:868) away from the May values."""
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 64, 64), 3)
+    for over in ({"dt_gamma": 0.0}, {"dt_gamma": 1.0 / 64}, {"max_steps": 24}):
+        ref, outs = _render_both(hp, sd, fi, **over)
+        for out in outs.values():
+            check(out, ref, True)
+    # T_thresh is a render() argument, not an hparam
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True, T_thresh=0.05)
+    to = lambda t: t.to(DEV)
+    for impl in ("ops", "fused"):
+        m = RADNeRFTorso(hp)
+        m.load_state_dict(sd, strict=True)
+        m.render_impl = impl
+        m = m.to(DEV).eval()
+        out = m.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                       bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, T_thresh=0.05, **hp)
+        check(out, ref, True)
