@@ -22,34 +22,50 @@ constexpr int kSmemBytes = (kWFloats + 2 * kActFloats + 256) * 4;
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.0f ? x : 0.02f * x; }
 
+// Copy a layer's weights into LDS: eight 16-byte loads per lane in flight before the first store (the copy is pure latency).
 __device__ __forceinline__ void stage(float* __restrict__ dst, const float* __restrict__ src, int n) {
     const int tid = threadIdx.x;
     if (((uintptr_t)src & 15u) == 0) {
         const int n4 = n >> 2;
-        for (int i = tid; i < n4; i += kThreads) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
-        for (int i = (n4 << 2) + tid; i < n; i += kThreads) dst[i] = src[i];
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        int i = tid;
+        for (; i + 7 * kThreads < n4; i += 8 * kThreads) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = s4[i + k * kThreads];
+#pragma unroll
+            for (int k = 0; k < 8; k++) d4[i + k * kThreads] = v[k];
+        }
+        for (; i < n4; i += kThreads) d4[i] = s4[i];
+        for (int j = (n4 << 2) + tid; j < n; j += kThreads) dst[j] = src[j];
     } else {
         for (int i = tid; i < n; i += kThreads) dst[i] = src[i];
     }
 }
 
 // out[s][co][p] = act(b[co] + sum_ci sum_k w[co][ci][k] * in[s][ci][p*stride + k - 1]),  zero padding 1 (torch Conv1d k=3)
+// Four adjacent lanes share one output and split the input channels (ci = part, part + 4, ...); only the taps that fall inside
+// the window are visited.
 __device__ void conv1d_k3(const float* __restrict__ w /*LDS*/, const float* __restrict__ b /*global*/, const float* in, float* out,
                           int S, int cin, int cout, int lin, int lout, int stride) {
     const int total = S * cout * lout;
-    for (int idx = threadIdx.x; idx < total; idx += kThreads) {
-        const int p = idx % lout, co = (idx / lout) % cout, s = idx / (lout * cout);
-        float sum = b[co];
-        const float* wr = w + (size_t)co * cin * 3;
-        const float* xr = in + (size_t)s * cin * lin;
-        for (int ci = 0; ci < cin; ci++) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int pos = p * stride + k - 1;
-                if (pos >= 0 && pos < lin) sum = __builtin_fmaf(wr[ci * 3 + k], xr[ci * lin + pos], sum);
-            }
+    const int part = threadIdx.x & 3;
+    for (int base = 0; base < total; base += kThreads / 4) {
+        const int idx = base + (threadIdx.x >> 2);
+        float sum = 0.0f;
+        if (idx < total) {
+            const int p = idx % lout, co = (idx / lout) % cout, s = idx / (lout * cout);
+            const float* wr = w + (size_t)co * cin * 3;
+            const float* xr = in + (size_t)s * cin * lin;
+            const int pos0 = p * stride - 1;
+            const int k_lo = pos0 < 0 ? -pos0 : 0, k_hi = pos0 + 2 >= lin ? lin - 1 - pos0 : 2;   // valid taps k_lo..k_hi
+            for (int ci = part; ci < cin; ci += 4)
+                for (int k = k_lo; k <= k_hi; k++) sum = __builtin_fmaf(wr[ci * 3 + k], xr[ci * lin + pos0 + k], sum);
         }
-        out[idx] = leaky(sum);
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        if (idx < total && part == 0) out[idx] = leaky(sum + b[(idx / lout) % cout]);
     }
 }
 
