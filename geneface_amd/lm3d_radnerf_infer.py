@@ -11,8 +11,9 @@ Keeps the reference's call surface -- `LM3d_RADNeRFInfer(hparams, ...)`, `.get_c
     materialises rays for every frame up front (lm3d_radnerf_infer.py:18-32, 6 MB per frame on the GPU); here only the 3x4
     poses go to the device and rays are generated inside the kernel;
   * frames: contiguous block per rank (base_nerf_infer.py:150-155), one weight broadcast, FramePipeline per rank;
-  * output: uint8 RGB frames.  PNG + ffmpeg muxing (base_nerf_infer.py:97-101,307) is side I/O outside the hot path: frames
-    are returned (and written as .npy when `out_video_name` ends in .npy); cv2 / ffmpeg are used only if present.
+  * output: uint8 RGB frames, returned; with `tmp_imgs_dir` in `inp` every frame is also written as `<dir>/<idx:05d>.png`
+    (the files base_nerf_infer.py:97-101 produces) by worker threads, off the render thread; `out_video_name` ending in .npy
+    stores the stack.  The ffmpeg mux (:307) runs only when an ffmpeg binary exists (this image has none).
 """
 import os
 
@@ -108,7 +109,7 @@ class LM3d_RADNeRFInfer:
         return samples
 
     # ------------------------------------------------------------------ frame loop (base_nerf_infer.py:81-193)
-    def forward_system(self, batches, rank: int = 0, world_size: int = 1):
+    def forward_system(self, batches, rank: int = 0, world_size: int = 1, writer=None):
         """Renders this rank's contiguous block of frames -> uint8 [n, H, W, 3] (host).  With torch.distributed initialised the
         caller passes its rank / world size; weights are made identical to rank 0's with one broadcast."""
         T = len(batches)
@@ -128,21 +129,39 @@ class LM3d_RADNeRFInfer:
                     if ev is not None:
                         ev.synchronize()
                     out[j] = buf.numpy()
+                    if writer is not None:
+                        writer.submit(lo + j, out[j])
             for j, buf, ev in pending:
                 if ev is not None:
                     ev.synchronize()
                 out[j] = buf.numpy()
+                if writer is not None:
+                    writer.submit(lo + j, out[j])
         return out
 
     def infer_once(self, inp: dict):
         samples = self.get_pose_from_ds(self.get_cond_from_input(inp))
-        frames = self.forward_system(samples)
+        writer = None
+        if inp.get("tmp_imgs_dir"):
+            from .png import FrameWriter
+            writer = FrameWriter(inp["tmp_imgs_dir"])
+        frames = self.forward_system(samples, writer=writer)
+        if writer is not None:
+            writer.close()
         name = inp.get("out_video_name", "")
         if name.endswith(".npy"):
             os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
             np.save(name, frames)
         elif name:
-            print(f"| {name}: PNG/ffmpeg muxing is outside the render path (base_nerf_infer.py:97-101,307); frames are returned")
+            import shutil
+            import subprocess
+            if shutil.which("ffmpeg") and writer is not None:   # base_nerf_infer.py:307 (video only; the wav is muxed when given)
+                wav = inp.get("audio_source_name") or None
+                cmd = ["ffmpeg", "-y", "-loglevel", "error", "-r", "25", "-i", os.path.join(inp["tmp_imgs_dir"], "%05d.png")]
+                cmd += (["-i", wav] if wav and os.path.exists(wav) else []) + ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-r", "25", name]
+                subprocess.run(cmd, check=True)
+            else:
+                print(f"| {name}: no ffmpeg binary (or no tmp_imgs_dir): the frames are returned / written as PNG only")
         return frames
 
     @classmethod

@@ -90,7 +90,10 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
     raw = S.make_landmarks(5).astype(np.float32)
     cond_path, out_path = os.path.join(tmp_path, "lm.npy"), os.path.join(tmp_path, "out", "frames.npy")
     np.save(cond_path, raw[None])
-    frames = inf.infer_once({"cond_name": cond_path, "out_video_name": out_path, "audio_source_name": ""})
+    frames = inf.infer_once({"cond_name": cond_path, "out_video_name": out_path, "audio_source_name": "", "tmp_imgs_dir": os.path.join(tmp_path, "imgs")})
+    from geneface_amd.png import decode_rgb8
+    for i in range(5):
+        np.testing.assert_array_equal(decode_rgb8(open(os.path.join(tmp_path, "imgs", f"{i:05d}.png"), "rb").read()), frames[i])
     assert frames.shape == (5, 64, 64, 3) and frames.dtype == np.uint8
     np.testing.assert_array_equal(np.load(out_path), frames)
     samples = inf.get_pose_from_ds(inf.get_cond_from_input({"cond_name": cond_path}))
@@ -103,3 +106,28 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         got = torch.from_numpy(frames[i])
         assert ((got.int() - ref8.int()).abs() <= 1).float().mean().item() > 0.995
         assert psnr(got.float() / 255, ref8.float() / 255) > 45
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """The %05d.png frame files of base_nerf_infer.py:97-101, written without cv2: valid PNG signature/chunks/CRCs, lossless."""
+    import struct
+    import zlib
+    from geneface_amd.png import FrameWriter, decode_rgb8, encode_rgb8
+    rng = np.random.default_rng(0)
+    for H, W in ((1, 1), (7, 5), (64, 48)):
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        data = encode_rgb8(img)
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        n, tag = struct.unpack(">I4s", data[8:16])
+        assert tag == b"IHDR" and n == 13 and struct.unpack(">II", data[16:24]) == (W, H)
+        assert struct.unpack(">I", data[29:33])[0] == zlib.crc32(data[12:29]) & 0xFFFFFFFF
+        np.testing.assert_array_equal(decode_rgb8(data), img)
+    w = FrameWriter(str(tmp_path / "imgs"), workers=2)
+    frames = rng.integers(0, 256, size=(5, 16, 16, 3), dtype=np.uint8)
+    for i, f in enumerate(frames):
+        w.submit(i, f)
+    w.close()
+    for i, f in enumerate(frames):
+        np.testing.assert_array_equal(decode_rgb8(open(tmp_path / "imgs" / f"{i:05d}.png", "rb").read()), f)
+    with pytest.raises(ValueError):
+        encode_rgb8(np.zeros((4, 4), dtype=np.uint8))
