@@ -1,7 +1,7 @@
 """Drop-in for the reference's pybind module `_raymarching_face`
 (modules/radnerfs/raymarching/src/bindings.cpp:5-21): same function names, same positional
 arguments (at::Tensor -> torch.Tensor, outputs pre-allocated by the caller, in-place, returns None),
-executed by libgeneface_hip.so on the current HIP stream.  Training-only exports raise."""
+executed by libgeneface_hip.so on the current HIP stream."""
 import torch
 
 from ..lib import check, current_stream, lib, ptr
@@ -44,15 +44,42 @@ def morton3D_dilation(grid, C, H, grid_dilation):
     check(lib().gf_morton3D_dilation(ptr(grid, _F), C, H, ptr(grid_dilation, _F), current_stream(grid.device)))
 
 
-def _training_only(name):
-    def f(*a, **k):
-        raise NotImplementedError(f"_raymarching_face.{name}: training path, outside this round's scope (SURVEY.md 8f-2)")
-    f.__name__ = name
-    return f
+_ws_cache = {}
 
 
-sph_from_ray = _training_only("sph_from_ray")  # no call site in GeneFace
-march_rays_train = _training_only("march_rays_train")
-march_rays_train_backward = _training_only("march_rays_train_backward")
-composite_rays_train_forward = _training_only("composite_rays_train_forward")
-composite_rays_train_backward = _training_only("composite_rays_train_backward")
+def _train_ws(N, device):
+    """scratch for the three-pass march_rays_train (per-ray counts, prefixes, block totals)"""
+    key = (device, N)
+    if key not in _ws_cache:
+        _ws_cache.clear()
+        _ws_cache[key] = torch.empty(lib().gf_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=device)
+    return _ws_cache[key]
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):
+    check(lib().gf_march_rays_train(ptr(rays_o, _F), ptr(rays_d, _F), ptr(grid, _U8), bound, dt_gamma, max_steps, N, C, H, M, ptr(nears, _F),
+                                    ptr(fars, _F), ptr(xyzs, _F), ptr(dirs, _F), ptr(deltas, _F), ptr(rays, _I), ptr(counter, _I), ptr(noises, _F),
+                                    _train_ws(N, rays_o.device).data_ptr(), current_stream(rays_o.device)))
+
+
+def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):
+    check(lib().gf_march_rays_train_backward(ptr(grad_xyzs, _F), ptr(grad_dirs, _F), ptr(rays, _I), ptr(deltas, _F), N, M, ptr(grad_rays_o, _F),
+                                             ptr(grad_rays_d, _F), current_stream(rays.device)))
+
+
+def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):
+    check(lib().gf_composite_rays_train_forward(ptr(sigmas, _F), ptr(rgbs, _F), ptr(ambient, _F), ptr(deltas, _F), ptr(rays, _I), M, N, T_thresh,
+                                                ptr(weights_sum, _F), ptr(ambient_sum, _F), ptr(depth, _F), ptr(image, _F),
+                                                current_stream(sigmas.device)))
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum,
+                                  image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_ambient):
+    check(lib().gf_composite_rays_train_backward(ptr(grad_weights_sum, _F), ptr(grad_ambient_sum, _F), ptr(grad_image, _F), ptr(sigmas, _F),
+                                                 ptr(rgbs, _F), ptr(ambient, _F), ptr(deltas, _F), ptr(rays, _I), ptr(weights_sum, _F),
+                                                 ptr(ambient_sum, _F), ptr(image, _F), M, N, T_thresh, ptr(grad_sigmas, _F), ptr(grad_rgbs, _F),
+                                                 ptr(grad_ambient, _F), current_stream(sigmas.device)))
+
+
+def sph_from_ray(*a, **k):
+    raise NotImplementedError("_raymarching_face.sph_from_ray: no call site in GeneFace (SURVEY.md 2.2A)")

@@ -49,6 +49,27 @@ int gf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t
                       const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
                       float* image, void* stream);
 
+/* Training tier.  march_rays_train (raymarching.h:13, kernel raymarching.cu:353-518): rays_o/rays_d [N,3], nears/fars/noises [N];
+ * xyzs/dirs [M,3], deltas [M,2] ZERO-FILLED by the caller; rays i32 [N,3] = (ray, point offset, point count); counter i32 [2]
+ * accumulates (points, rays).  Offsets are handed out in RAY ORDER (exclusive prefix sum of the counts): deterministic, one of the
+ * orders the reference's two atomicAdds per ray can produce.  workspace: gf_march_rays_train_workspace_bytes(N) device bytes. */
+uint64_t gf_march_rays_train_workspace_bytes(uint32_t N);
+int gf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
+                        float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* workspace, void* stream);
+/* march_rays_train_backward (raymarching.h:14, .cu:536-583): grad_rays_o/grad_rays_d [N,3] accumulate. */
+int gf_march_rays_train_backward(const float* grad_xyzs, const float* grad_dirs, const int32_t* rays, const float* deltas, uint32_t N,
+                                 uint32_t M, float* grad_rays_o, float* grad_rays_d, void* stream);
+/* composite_rays_train_forward / _backward (raymarching.h:15-16, .cu:604-687, :712-809); the backward's grad outputs are
+ * ZERO-FILLED by the caller. */
+int gf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays,
+                                    uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* ambient_sum, float* depth, float* image,
+                                    void* stream);
+int gf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_ambient_sum, const float* grad_image, const float* sigmas,
+                                     const float* rgbs, const float* ambient, const float* deltas, const int32_t* rays, const float* weights_sum,
+                                     const float* ambient_sum, const float* image, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                     float* grad_rgbs, float* grad_ambient, void* stream);
+
 /* occupancy-grid maintenance: morton3D (raymarching.h:9, .cu:214-226), morton3D_invert (:10, .cu:237-254),
  * packbits (:11, .cu:268-289; N = number of output bytes), morton3D_dilation (:12, .cu:304-335). */
 int gf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);

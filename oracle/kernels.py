@@ -85,6 +85,36 @@ class raymarching_face:
     def morton3D_dilation(grid, Cc, H, grid_dilation):
         lib().orc_morton3D_dilation(_p(grid, torch.float32), _u(Cc), _u(H), _p(grid_dilation, torch.float32))
 
+    # ---- training tier (raymarching.h:13-18)
+    @staticmethod
+    def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, Cc, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):
+        lib().orc_march_rays_train(_p(rays_o, torch.float32), _p(rays_d, torch.float32), _p(grid, torch.uint8), _f(bound), _f(dt_gamma),
+                                   _u(max_steps), _u(N), _u(Cc), _u(H), _u(M), _p(nears, torch.float32), _p(fars, torch.float32),
+                                   _p(xyzs, torch.float32), _p(dirs, torch.float32), _p(deltas, torch.float32), _p(rays, torch.int32),
+                                   _p(counter, torch.int32), _p(noises, torch.float32))
+
+    @staticmethod
+    def march_rays_train_backward(grad_xyzs, grad_dirs, rays, deltas, N, M, grad_rays_o, grad_rays_d):
+        lib().orc_march_rays_train_backward(_p(grad_xyzs, torch.float32), _p(grad_dirs, torch.float32), _p(rays, torch.int32),
+                                            _p(deltas, torch.float32), _u(N), _u(M), _p(grad_rays_o, torch.float32), _p(grad_rays_d, torch.float32))
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, weights_sum, ambient_sum, depth, image):
+        lib().orc_composite_rays_train_forward(_p(sigmas, torch.float32), _p(rgbs, torch.float32), _p(ambient, torch.float32),
+                                               _p(deltas, torch.float32), _p(rays, torch.int32), _u(M), _u(N), _f(T_thresh),
+                                               _p(weights_sum, torch.float32), _p(ambient_sum, torch.float32), _p(depth, torch.float32),
+                                               _p(image, torch.float32))
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image, sigmas, rgbs, ambient, deltas, rays, weights_sum,
+                                      ambient_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, grad_ambient):
+        lib().orc_composite_rays_train_backward(_p(grad_weights_sum, torch.float32), _p(grad_ambient_sum, torch.float32),
+                                                _p(grad_image, torch.float32), _p(sigmas, torch.float32), _p(rgbs, torch.float32),
+                                                _p(ambient, torch.float32), _p(deltas, torch.float32), _p(rays, torch.int32),
+                                                _p(weights_sum, torch.float32), _p(ambient_sum, torch.float32), _p(image, torch.float32),
+                                                _u(M), _u(N), _f(T_thresh), _p(grad_sigmas, torch.float32), _p(grad_rgbs, torch.float32),
+                                                _p(grad_ambient, torch.float32))
+
 
 class gridencoder:
     """`_gridencoder` forward (encoders/gridencoder/src/gridencoder.h:11)."""

@@ -434,3 +434,185 @@ ORC_EXPORT void orc_freq_encode_forward(const float* inputs, uint32_t B, uint32_
         }
     }
 }
+
+
+/* =====================================================================================================
+ * Training tier: raymarching/src/raymarching.cu:353-518 (march_rays_train),
+ * :536-583 (march_rays_train_backward), :604-687 (composite_rays_train_forward), :712-809 (backward).
+ * The CUDA kernel assigns point offsets / ray slots with atomicAdd (nondeterministic order);
+ * this restatement -- like the HIP kernels -- assigns them in ray order, which is one of the orders the
+ * reference can produce: rays[n] = (n, offset_n, count_n), offset_n = sum of the counts before n.
+ * ===================================================================================================== */
+
+/* one marcher trip: returns 1 and fills the sample when the cell at t is occupied, else skips to the next cell */
+static inline int orc_march_trip(float ox, float oy, float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz,
+                                 float bound, float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H,
+                                 const uint8_t* grid, float* t_io, float* x_, float* y_, float* z_, float* dt_) {
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    float t = *t_io;
+    const float x = orc_clampf(fmaf(t, dx, ox), -bound, bound);
+    const float y = orc_clampf(fmaf(t, dy, oy), -bound, bound);
+    const float z = orc_clampf(fmaf(t, dz, oz), -bound, bound);
+    const float dt = orc_clampf(t * dt_gamma, dt_min, dt_max);
+    const int lp = orc_mip_from_pos(x, y, z, (float)C), ld = orc_mip_from_dt(dt, (float)H, (float)C);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1, level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = (int)orc_clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const int ny = (int)orc_clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const int nz = (int)orc_clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const uint32_t idx = (uint32_t)((float)level * H3 + (float)orc_morton3D_1((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    if (grid[idx / 8] & (1 << (idx % 8))) {
+        *x_ = x; *y_ = y; *z_ = z; *dt_ = dt;
+        *t_io = t + dt;
+        return 1;
+    }
+    const float tx = ((((float)nx + 0.5f + 0.5f * orc_signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+    const float ty = ((((float)ny + 0.5f + 0.5f * orc_signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+    const float tz = ((((float)nz + 0.5f + 0.5f * orc_signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        t += orc_clampf(t * dt_gamma, dt_min, dt_max);
+    } while (t < tt);
+    *t_io = t;
+    return 0;
+}
+
+/* raymarching.cu:353-518.  xyzs/dirs [M,3], deltas [M,2] pre-zeroed by the caller; rays int32 [N,3]; counter int32 [2]
+ * (accumulated, like the atomicAdd: counter[0] += points, counter[1] += N). */
+ORC_EXPORT void orc_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                     const float* fars, float* xyzs_, float* dirs_, float* deltas_, int32_t* rays, int32_t* counter,
+                                     const float* noises) {
+    const float dt_max = 2 * ORC_SQRT3 * (float)(1 << (C - 1)) / (float)H;
+    const float dt_min = fminf(dt_max, 2 * ORC_SQRT3 / (float)max_steps);
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        const float far = fars[n];
+        float t0 = nears[n];
+        t0 += orc_clampf(t0 * dt_gamma, dt_min, dt_max) * noises[n];
+        /* first pass: count */
+        float t = t0, x, y, z, dt;
+        uint32_t num_steps = 0;
+        while (t < far && num_steps < max_steps)
+            num_steps += (uint32_t)orc_march_trip(ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, bound, dt_gamma, dt_min, dt_max, C, H, grid, &t, &x, &y, &z, &dt);
+        const uint32_t point_index = (uint32_t)counter[0];
+        const uint32_t ray_index = (uint32_t)counter[1];
+        counter[0] += (int32_t)num_steps;
+        counter[1] += 1;
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = (int32_t)num_steps;
+        if (num_steps == 0) continue;
+        if (point_index + num_steps > M) continue;
+        /* second pass: write */
+        float* xyzs = xyzs_ + (size_t)point_index * 3;
+        float* dirs = dirs_ + (size_t)point_index * 3;
+        float* deltas = deltas_ + (size_t)point_index * 2;
+        t = t0;
+        uint32_t step = 0;
+        while (t < far && step < num_steps) {
+            if (orc_march_trip(ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, bound, dt_gamma, dt_min, dt_max, C, H, grid, &t, &x, &y, &z, &dt)) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+                deltas[0] = dt; deltas[1] = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+                step++;
+            }
+        }
+    }
+}
+
+/* raymarching.cu:536-583.  grad_rays_o/d [N,3] accumulate (the caller zero-fills). */
+ORC_EXPORT void orc_march_rays_train_backward(const float* grad_xyzs_, const float* grad_dirs_, const int32_t* rays, const float* deltas_,
+                                              uint32_t N, uint32_t M, float* grad_rays_o_, float* grad_rays_d_) {
+    for (uint32_t n = 0; n < N; n++) {
+        float* go = grad_rays_o_ + (size_t)n * 3;   /* indexed by the thread id n, as the reference does */
+        float* gd = grad_rays_d_ + (size_t)n * 3;
+        const uint32_t offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float* gx = grad_xyzs_ + (size_t)offset * 3;
+        const float* gdd = grad_dirs_ + (size_t)offset * 3;
+        const float* deltas = deltas_ + (size_t)offset * 2;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            go[0] += gx[0]; go[1] += gx[1]; go[2] += gx[2];
+            gd[0] += gx[0] * deltas[1] + gdd[0];
+            gd[1] += gx[1] * deltas[1] + gdd[1];
+            gd[2] += gx[2] * deltas[1] + gdd[2];
+            gx += 3; gdd += 3; deltas += 2;
+        }
+    }
+}
+
+/* raymarching.cu:604-687 */
+ORC_EXPORT void orc_composite_rays_train_forward(const float* sigmas_, const float* rgbs_, const float* ambient_, const float* deltas_,
+                                                 const int32_t* rays, uint32_t M, uint32_t N, float T_thresh, float* weights_sum,
+                                                 float* ambient_sum, float* depth, float* image) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) {
+            weights_sum[index] = 0; ambient_sum[index] = 0; depth[index] = 0;
+            image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0;
+            continue;
+        }
+        const float* sigmas = sigmas_ + offset;
+        const float* rgbs = rgbs_ + (size_t)offset * 3;
+        const float* ambient = ambient_ + offset;
+        const float* deltas = deltas_ + (size_t)offset * 2;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, d = 0, amb = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-sigmas[0] * deltas[0]);
+            const float weight = alpha * T;
+            r += weight * rgbs[0]; g += weight * rgbs[1]; b += weight * rgbs[2];
+            d += weight * deltas[1];
+            ws += weight;
+            amb += ambient[0];
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+            sigmas++; rgbs += 3; ambient++; deltas += 2;
+        }
+        weights_sum[index] = ws; ambient_sum[index] = amb; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+/* raymarching.cu:712-809 (grad_sigmas / grad_rgbs / grad_ambient pre-zeroed by the caller) */
+ORC_EXPORT void orc_composite_rays_train_backward(const float* grad_weights_sum_, const float* grad_ambient_sum_, const float* grad_image_,
+                                                  const float* sigmas_, const float* rgbs_, const float* ambient_, const float* deltas_,
+                                                  const int32_t* rays, const float* weights_sum_, const float* ambient_sum_,
+                                                  const float* image_, uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas_,
+                                                  float* grad_rgbs_, float* grad_ambient_) {
+    (void)ambient_; (void)ambient_sum_;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float gws = grad_weights_sum_[index], gas = grad_ambient_sum_[index];
+        const float* gi = grad_image_ + (size_t)index * 3;
+        const float r_final = image_[index * 3], g_final = image_[index * 3 + 1], b_final = image_[index * 3 + 2], ws_final = weights_sum_[index];
+        const float* sigmas = sigmas_ + offset;
+        const float* rgbs = rgbs_ + (size_t)offset * 3;
+        const float* deltas = deltas_ + (size_t)offset * 2;
+        float* grad_sigmas = grad_sigmas_ + offset;
+        float* grad_rgbs = grad_rgbs_ + (size_t)offset * 3;
+        float* grad_ambient = grad_ambient_ + offset;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-sigmas[0] * deltas[0]);
+            const float weight = alpha * T;
+            r += weight * rgbs[0]; g += weight * rgbs[1]; b += weight * rgbs[2];
+            ws += weight;
+            T *= 1.0f - alpha;
+            grad_rgbs[0] = gi[0] * weight; grad_rgbs[1] = gi[1] * weight; grad_rgbs[2] = gi[2] * weight;
+            grad_ambient[0] = gas;
+            grad_sigmas[0] = deltas[0] * (gi[0] * (T * rgbs[0] - (r_final - r)) + gi[1] * (T * rgbs[1] - (g_final - g)) +
+                                          gi[2] * (T * rgbs[2] - (b_final - b)) + gws * (1 - ws_final));
+            if (T < T_thresh) break;
+            sigmas++; rgbs += 3; deltas += 2; grad_sigmas++; grad_rgbs += 3; grad_ambient++;
+        }
+    }
+}

@@ -1,0 +1,98 @@
+"""-m gpu: training-tier ray-marching ops through the C ABI against the oracle, and the autograd wrappers
+of geneface_amd/raymarching.py (raymarching.py:185-342 of the reference)."""
+import pytest
+import torch
+
+from helpers import frame_inputs, model_fixture, sequence
+from oracle import kernels as K
+from oracle import radnerf_ref as R
+from test_oracle_train import march_train
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RM = K.raymarching_face
+
+
+def _scene(size=64, idx=1):
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, size, size), idx)
+    ro, rd = fi["rays_o"].view(-1, 3).contiguous(), fi["rays_d"].view(-1, 3).contiguous()
+    nears, fars = R.near_far_from_aabb(ro, rd, sd["aabb_infer"], hp["min_near"])
+    return hp, sd, ro, rd, nears, fars
+
+
+@pytest.mark.parametrize("size,max_steps", [(64, 16), (37, 64), (128, 16)])
+def test_march_rays_train_bit_exact_vs_oracle(size, max_steps):
+    from geneface_amd import raymarching as GR
+    hp, sd, ro, rd, nears, fars = _scene(size)
+    ref = march_train(hp, sd, ro, rd, nears, fars, max_steps=max_steps)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    xyzs, dirs, deltas, rays = GR.march_rays_train(ro.to(DEV), rd.to(DEV), float(hp["bound"]), sd["density_bitfield"].to(DEV), 1, hp["grid_size"],
+                                                   nears.to(DEV), fars.to(DEV), counter, -1, False, 128, True, hp["dt_gamma"], max_steps)
+    tot = ref[4][0].item()
+    assert counter.cpu().tolist() == ref[4].tolist()
+    assert torch.equal(rays.cpu(), ref[3])                      # (ray, offset, count): integer decisions identical, ray order
+    assert xyzs.shape[0] == tot + (128 - tot % 128)             # align=128 padding rule of the wrapper
+    assert torch.equal(xyzs[:tot].cpu(), ref[0][:tot]) and torch.equal(dirs[:tot].cpu(), ref[1][:tot]) and torch.equal(deltas[:tot].cpu(), ref[2][:tot])
+    assert not xyzs[tot:].any()
+
+
+def test_march_rays_train_overflow_and_perturb():
+    from geneface_amd.compat import _raymarching_face as B
+    hp, sd, ro, rd, nears, fars = _scene(48)
+    N = ro.shape[0]
+    g = torch.Generator().manual_seed(3)
+    noises = torch.rand(N, generator=g)
+    full = march_train(hp, sd, ro, rd, nears, fars, noises=noises)
+    M = full[4][0].item() // 3
+    ref = march_train(hp, sd, ro, rd, nears, fars, M=M, noises=noises)
+    d = lambda t: t.to(DEV)
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=DEV), torch.zeros(M, 3, device=DEV), torch.zeros(M, 2, device=DEV)
+    rays, counter = torch.empty(N, 3, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+    B.march_rays_train(d(ro), d(rd), d(sd["density_bitfield"]), float(hp["bound"]), hp["dt_gamma"], hp["max_steps"], N, 1, hp["grid_size"], M,
+                       d(nears), d(fars), xyzs, dirs, deltas, rays, counter, d(noises))
+    assert torch.equal(rays.cpu(), ref[3]) and counter.cpu().tolist() == ref[4].tolist()
+    assert torch.equal(xyzs.cpu(), ref[0]) and torch.equal(deltas.cpu(), ref[2])
+    # a second call accumulates into the counter like the reference's atomics
+    B.march_rays_train(d(ro), d(rd), d(sd["density_bitfield"]), float(hp["bound"]), hp["dt_gamma"], hp["max_steps"], N, 1, hp["grid_size"], M,
+                       d(nears), d(fars), xyzs, dirs, deltas, rays, counter, d(noises))
+    assert counter.cpu().tolist() == [2 * ref[4][0].item(), 2 * N]
+
+
+def test_composite_rays_train_and_backward_vs_oracle_and_autograd():
+    from geneface_amd import raymarching as GR
+    hp, sd, ro, rd, nears, fars = _scene(64)
+    xyzs, dirs, deltas, rays, counter = march_train(hp, sd, ro, rd, nears, fars)
+    N, M = ro.shape[0], counter[0].item()
+    g = torch.Generator().manual_seed(4)
+    sigmas, rgbs, ambient = torch.rand(M, generator=g) * 40, torch.rand(M, 3, generator=g), torch.rand(M, generator=g)
+    gws, gamb, gimg = torch.rand(N, generator=g), torch.rand(N, generator=g), torch.rand(N, 3, generator=g)
+    de = deltas[:M].contiguous()
+    for T_thresh in (1e-4, 0.2):
+        ws, amb, dep, img = torch.empty(N), torch.empty(N), torch.empty(N), torch.empty(N, 3)
+        RM.composite_rays_train_forward(sigmas, rgbs, ambient, de, rays, M, N, T_thresh, ws, amb, dep, img)
+        gs, gc, ga = torch.zeros(M), torch.zeros(M, 3), torch.zeros(M)
+        RM.composite_rays_train_backward(gws, gamb, gimg, sigmas, rgbs, ambient, de, rays, ws, amb, img, M, N, T_thresh, gs, gc, ga)
+        s_g, c_g, a_g = (t.to(DEV).requires_grad_(True) for t in (sigmas, rgbs, ambient))
+        ws_g, amb_g, dep_g, img_g = GR.composite_rays_train(s_g, c_g, a_g, de.to(DEV), rays.to(DEV), T_thresh)
+        assert (ws_g.cpu() - ws).abs().max() < 1e-5 and (img_g.cpu() - img).abs().max() < 1e-5
+        assert (dep_g.cpu() - dep).abs().max() < 1e-4 and (amb_g.cpu() - amb).abs().max() < 1e-4
+        ((ws_g * gws.to(DEV)).sum() + (amb_g * gamb.to(DEV)).sum() + (img_g * gimg.to(DEV)).sum() + 0.0 * dep_g.sum()).backward()
+        assert (c_g.grad.cpu() - gc).abs().max() < 1e-5 and (a_g.grad.cpu() - ga).abs().max() < 1e-6
+        assert (s_g.grad.cpu() - gs).abs().max() < 1e-4 * max(1.0, float(gs.abs().max()))
+
+
+def test_march_rays_train_backward_vs_oracle():
+    from geneface_amd import raymarching as GR
+    hp, sd, ro, rd, nears, fars = _scene(48)
+    N = ro.shape[0]
+    ro_g, rd_g = ro.to(DEV).requires_grad_(True), rd.to(DEV).requires_grad_(True)
+    xyzs, dirs, deltas, rays = GR.march_rays_train(ro_g, rd_g, float(hp["bound"]), sd["density_bitfield"].to(DEV), 1, hp["grid_size"], nears.to(DEV),
+                                                   fars.to(DEV), None, -1, False, -1, True, hp["dt_gamma"], hp["max_steps"])
+    M = xyzs.shape[0]
+    g = torch.Generator().manual_seed(5)
+    gx, gd = torch.randn(M, 3, generator=g), torch.randn(M, 3, generator=g)
+    ((xyzs * gx.to(DEV)).sum() + (dirs * gd.to(DEV)).sum()).backward()
+    go, gdd = torch.zeros(N, 3), torch.zeros(N, 3)
+    RM.march_rays_train_backward(gx, gd, rays.cpu(), deltas.detach().cpu().contiguous(), N, M, go, gdd)
+    assert (ro_g.grad.cpu() - go).abs().max() < 1e-4 and (rd_g.grad.cpu() - gdd).abs().max() < 1e-3
