@@ -10,5 +10,6 @@ def freq_encode_forward(inputs, B, D, deg, C, outputs):
                                        current_stream(inputs.device)))
 
 
-def freq_encode_backward(*a, **k):
-    raise NotImplementedError("_freqencoder.freq_encode_backward: training path, outside this round's scope (SURVEY.md 8f-2)")
+def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):
+    check(lib().gf_freq_encode_backward(ptr(grad, torch.float32), ptr(outputs, torch.float32), B, D, deg, C, ptr(grad_inputs, torch.float32),
+                                        current_stream(grad.device)))

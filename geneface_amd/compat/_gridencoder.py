@@ -14,8 +14,11 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 
                                        current_stream(inputs.device)))
 
 
-def grid_encode_backward(*a, **k):
-    raise NotImplementedError("_gridencoder.grid_encode_backward: training path, outside this round's scope (SURVEY.md 8f-2)")
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
+    check(lib().gf_grid_encode_backward(ptr(grad, torch.float32), ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
+                                        ptr(grad_embeddings, torch.float32), B, D, C, L, float(S), H, ptr(dy_dx, torch.float32, allow_none=True),
+                                        ptr(grad_inputs, torch.float32, allow_none=True), gridtype, int(bool(align_corners)), interp,
+                                        current_stream(grad.device)))
 
 
 def grad_total_variation(*a, **k):

@@ -10,5 +10,6 @@ def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
                                      ptr(dy_dx, torch.float32, allow_none=True), current_stream(inputs.device)))
 
 
-def sh_encode_backward(*a, **k):
-    raise NotImplementedError("_shencoder.sh_encode_backward: training path, outside this round's scope (SURVEY.md 8f-2)")
+def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+    check(lib().gf_sh_encode_backward(ptr(grad, torch.float32), ptr(inputs, torch.float32), B, D, C, ptr(dy_dx, torch.float32),
+                                      ptr(grad_inputs, torch.float32), current_stream(grad.device)))

@@ -99,14 +99,127 @@ int grid_encode_any(bool blc, const float* inputs, const float* embeddings, cons
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_sh(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t degree) {
+__global__ void __launch_bounds__(kBlock) k_sh(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t degree,
+                                               float* __restrict__ dy_dx) {
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= B) return;
+    const float x = inputs[(size_t)b * 3], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
     float sh[16];
-    gf::sh4(inputs[(size_t)b * 3], inputs[(size_t)b * 3 + 1], inputs[(size_t)b * 3 + 2], sh);
+    gf::sh4(x, y, z, sh);
     const uint32_t n = degree * degree;
     float* o = outputs + (size_t)b * n;
     for (uint32_t i = 0; i < n; i++) o[i] = sh[i];
+    if (dy_dx) {   // [B, 3, degree^2]
+        float gx[16], gy[16], gz[16];
+        gf::sh4_grad(x, y, z, gx, gy, gz);
+        float* d = dy_dx + (size_t)b * 3 * n;
+        for (uint32_t i = 0; i < n; i++) { d[i] = gx[i]; d[n + i] = gy[i]; d[2 * n + i] = gz[i]; }
+    }
+}
+
+// shencoder.cu:359-383: grad_inputs[b][d] += sum_k grad[b][k] * dy_dx[b][d][k]
+__global__ void __launch_bounds__(kBlock) k_sh_backward(const float* __restrict__ grad, const float* __restrict__ dy_dx, uint32_t B, uint32_t n,
+                                                        float* __restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= B * 3) return;
+    const uint32_t b = t / 3, d = t - b * 3;
+    const float* g = grad + (size_t)b * n;
+    const float* dd = dy_dx + (size_t)b * 3 * n + (size_t)d * n;
+    float acc = grad_inputs[t];
+    for (uint32_t k = 0; k < n; k++) acc += g[k] * dd[k];
+    grad_inputs[t] = acc;
+}
+
+// freqencoder.cu:63-94
+__global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restrict__ grad, const float* __restrict__ outputs, uint32_t B, uint32_t D,
+                                                          uint32_t deg, uint32_t C, float* __restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float* g = grad + (size_t)b * C;
+    const float* o = outputs + (size_t)b * C;
+    float result = g[d];
+    g += D; o += D;
+    for (uint32_t f = 0; f < deg; f++) {
+        result += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+        g += 2 * D; o += 2 * D;
+    }
+    grad_inputs[t] = result;
+}
+
+// gridencoder.cu:248-339: one lane per (point, level); every corner's share of the output gradient is scattered into the table
+// with hardware f32 atomics (the accumulation order, hence the last bits, vary from run to run exactly as in the reference).
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBlock) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                          const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
+                                                          gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        if (x[d] < 0 || x[d] > 1) return;
+    }
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    float g[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) g[c] = grad[((size_t)level * B + b) * C + c];
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = __builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= fl;
+        if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+    }
+    float* table = grad_grid + (size_t)off * C;
+#pragma unroll
+    for (uint32_t corner = 0; corner < (1u << D); corner++) {
+        float w = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((corner & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+        }
+        const uint32_t row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
+    }
+}
+
+// gridencoder.cu:343-368
+__global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __restrict__ grad, const float* __restrict__ dy_dx,
+                                                                float* __restrict__ grad_inputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float* dd = dy_dx + (size_t)b * L * D * C;
+    float result = 0.0f;
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t ch = 0; ch < C; ch++) result += grad[((size_t)l * B + b) * C + ch] * dd[l * D * C + d * C + ch];
+    grad_inputs[t] = result;
+}
+
+template <uint32_t D>
+int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, const int* offsets, float* grad_grid, uint32_t B,
+                        const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
+    const dim3 grid(gf_div_up(B, (uint32_t)kBlock), lv.L), block(kBlock);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
+        case 2: hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
+        case 4: hipLaunchKernelGGL((k_grid_backward<D, 4>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
+        case 8: hipLaunchKernelGGL((k_grid_backward<D, 8>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+    return gf_check_launch("grid_encode_backward");
 }
 
 // one lane per output element, like the reference (the output row is what bounds this kernel)
@@ -175,10 +288,60 @@ GF_EXPORT int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t
     if (B == 0) return GF_OK;
     if (D != 3) return gf_set_error(GF_ERR_INVALID, "SH encoder only support input dim == 3");
     if (degree < 1 || degree > 4) return gf_set_error(GF_ERR_UNSUPPORTED, "SH encoder: this build implements degree 1..4 (GeneFace uses 4)");
-    if (dy_dx) return gf_set_error(GF_ERR_UNSUPPORTED, "SH encoder: dy_dx (training) is not built yet");
     if (!inputs || !outputs) return gf_set_error(GF_ERR_INVALID, "sh_encode_forward: null pointer");
-    hipLaunchKernelGGL(k_sh, dim3(gf_div_up(B, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), inputs, outputs, B, degree);
+    hipLaunchKernelGGL(k_sh, dim3(gf_div_up(B, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), inputs, outputs, B, degree, dy_dx);
     return gf_check_launch("sh_encode_forward");
+}
+
+// sh_encode_backward (shencoder.h:10, kernel shencoder.cu:359-383): grad [B, degree^2], dy_dx [B, 3, degree^2], grad_inputs [B,3] accumulates.
+GF_EXPORT int gf_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t degree, const float* dy_dx,
+                                    float* grad_inputs, void* stream) {
+    (void)inputs;
+    if (B == 0) return GF_OK;
+    if (D != 3 || degree < 1 || degree > 4) return gf_set_error(GF_ERR_INVALID, "sh_encode_backward: D must be 3, degree 1..4");
+    if (!grad || !dy_dx || !grad_inputs) return gf_set_error(GF_ERR_INVALID, "sh_encode_backward: null pointer");
+    hipLaunchKernelGGL(k_sh_backward, dim3(gf_div_up(B * 3, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), grad, dy_dx, B, degree * degree, grad_inputs);
+    return gf_check_launch("sh_encode_backward");
+}
+
+// freq_encode_backward (freqencoder.h:10, kernel freqencoder.cu:63-94): grad / outputs [B,C], grad_inputs [B,D].
+GF_EXPORT int gf_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* grad_inputs,
+                                      void* stream) {
+    if (B == 0) return GF_OK;
+    if (C != D + 2 * D * deg) return gf_set_error(GF_ERR_INVALID, "freq_encode_backward: C must equal D + 2*D*deg");
+    if (!grad || !outputs || !grad_inputs) return gf_set_error(GF_ERR_INVALID, "freq_encode_backward: null pointer");
+    hipLaunchKernelGGL(k_freq_backward, dim3(gf_div_up(B * D, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), grad, outputs, B, D, deg, C, grad_inputs);
+    return gf_check_launch("freq_encode_backward");
+}
+
+// grid_encode_backward (gridencoder.h:12, kernels gridencoder.cu:248-368).  grad [L,B,C]; grad_embeddings [sO,C] ZERO-FILLED by the
+// caller (accumulated with f32 atomics); dy_dx [B, L*D*C] from the forward and grad_inputs [B,D] are both NULL or both given.
+GF_EXPORT int gf_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets, float* grad_embeddings,
+                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
+                                      uint32_t gridtype, int align_corners, uint32_t interp, void* stream) {
+    (void)embeddings;
+    if (B == 0) return GF_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward: null pointer");
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward: dy_dx and grad_inputs go together");
+    if (gridtype > 1 || interp > 1) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward: gridtype/interp must be 0 or 1");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    int rc;
+    switch (D) {
+        case 2: rc = dispatch_backward_c<2>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s); break;
+        case 3: rc = dispatch_backward_c<3>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s); break;
+        case 4: rc = dispatch_backward_c<4>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s); break;
+        case 5: rc = dispatch_backward_c<5>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s); break;
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
+    if (rc) return rc;
+    if (dy_dx) {
+        hipLaunchKernelGGL(k_grid_input_backward, dim3(gf_div_up(B * D, (uint32_t)kBlock)), dim3(kBlock), 0, s, grad, dy_dx, grad_inputs, B, D, C, L);
+        return gf_check_launch("grid_encode_backward(inputs)");
+    }
+    return GF_OK;
 }
 
 GF_EXPORT int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream) {

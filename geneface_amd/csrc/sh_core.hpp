@@ -34,6 +34,30 @@ __device__ __forceinline__ void sh4(float x, float y, float z, float (&sh)[16]) 
     sh[15] = k3a * x * (-x2 + 3.0f * y2);
 }
 
+// d sh[k] / d(x, y, z) of the basis above (what the reference's kernel_sh writes to dy_dx, shencoder.cu:122-356, for degree <= 4),
+// derived from the polynomials of sh4.
+__device__ __forceinline__ void sh4_grad(float x, float y, float z, float (&gx)[16], float (&gy)[16], float (&gz)[16]) {
+    constexpr float k1 = 0.48860251190291987f, k2 = 1.0925484305920792f, k3a = 0.59004358992664352f, k3b = 0.45704579946446572f;
+    constexpr float a6 = 0.94617469575755997f, c8 = 0.54627421529603959f, c10 = 2.8906114426405538f, c12 = 0.3731763325901154f,
+                    c14 = 1.4453057213202769f;
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { gx[k] = 0.0f; gy[k] = 0.0f; gz[k] = 0.0f; }
+    gy[1] = -k1; gz[2] = k1; gx[3] = -k1;
+    gx[4] = k2 * y; gy[4] = k2 * x;
+    gy[5] = -k2 * z; gz[5] = -k2 * y;
+    gz[6] = 2 * a6 * z;
+    gx[7] = -k2 * z; gz[7] = -k2 * x;
+    gx[8] = 2 * c8 * x; gy[8] = -2 * c8 * y;
+    gx[9] = -6 * k3a * x * y; gy[9] = 3 * k3a * (y2 - x2);
+    gx[10] = c10 * y * z; gy[10] = c10 * x * z; gz[10] = c10 * x * y;
+    gy[11] = k3b * (1 - 5 * z2); gz[11] = -10 * k3b * y * z;
+    gz[12] = c12 * (15 * z2 - 3);
+    gx[13] = k3b * (1 - 5 * z2); gz[13] = -10 * k3b * x * z;
+    gx[14] = 2 * c14 * x * z; gy[14] = -2 * c14 * y * z; gz[14] = c14 * (x2 - y2);
+    gx[15] = 3 * k3a * (y2 - x2); gy[15] = 6 * k3a * x * y;
+}
+
 // element c of the [D + 2*D*deg] frequency encoding of in[0..D):
 //   [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...], cos evaluated as sin(. + pi/2) with pi/2 rounded to fp32
 __device__ __forceinline__ float freq_element(const float* __restrict__ in, uint32_t D, uint32_t c) {

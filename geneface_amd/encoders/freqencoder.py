@@ -5,12 +5,29 @@ import torch.nn as nn
 from ..compat import _freqencoder as _backend
 
 
-def freq_encode(inputs, degree, output_dim):
-    inputs = inputs.float().contiguous()
-    B, input_dim = inputs.shape
-    outputs = torch.empty(B, output_dim, dtype=torch.float32, device=inputs.device)
-    _backend.freq_encode_forward(inputs, B, input_dim, degree, output_dim, outputs)
-    return outputs
+class _freq_encode(torch.autograd.Function):
+    """freq.py:15-53: the backward reads sin / cos back from the forward outputs."""
+
+    @staticmethod
+    def forward(ctx, inputs, degree, output_dim):
+        inputs = inputs.float().contiguous()
+        B, input_dim = inputs.shape
+        outputs = torch.empty(B, output_dim, dtype=torch.float32, device=inputs.device)
+        _backend.freq_encode_forward(inputs, B, input_dim, degree, output_dim, outputs)
+        ctx.save_for_backward(inputs, outputs)
+        ctx.dims = [B, input_dim, degree, output_dim]
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, outputs = ctx.saved_tensors
+        B, input_dim, degree, output_dim = ctx.dims
+        grad_inputs = torch.zeros_like(inputs)
+        _backend.freq_encode_backward(grad.float().contiguous(), outputs, B, input_dim, degree, output_dim, grad_inputs)
+        return grad_inputs, None, None
+
+
+freq_encode = _freq_encode.apply
 
 
 class FreqEncoder(nn.Module):

@@ -3,7 +3,7 @@
 Mirrors modules/radnerfs/encoders/gridencoder/grid.py of the reference: constructor arguments,
 parameter/buffer names (`embeddings`, `offsets`), table sizing (:113-131), init (:138-140) and the
 [-bound, bound] -> [0, 1] input remap (:149) are the same, so reference checkpoints load.
-Forward only; the lookup runs in libgeneface_hip.so and writes [B, L*C] directly.
+The lookup and its backward (table scatter + input gradient) run in libgeneface_hip.so; the forward writes [B, L*C] directly.
 """
 import numpy as np
 import torch
@@ -36,21 +36,48 @@ def grid_offsets(input_dim, num_levels=16, base_resolution=16, log2_hashmap_size
     return np.array(offsets, dtype=np.int32)
 
 
+class _grid_encode(torch.autograd.Function):
+    """grid.py:24-90.  Forward: [B, L*C] written directly (the reference writes [L,B,C] and permutes); backward: the table gradient
+    is scattered with f32 atomics, the input gradient goes through dy_dx when the inputs require one."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
+                interpolation=0):
+        inputs = inputs.float().contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        outputs = torch.empty(B, L * C, device=inputs.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
+        check(lib().gf_grid_encode_forward_blc(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
+                                               ptr(outputs), B, D, C, L, S, int(base_resolution), ptr(dy_dx, torch.float32, allow_none=True),
+                                               gridtype, int(bool(align_corners)), interpolation, current_stream(inputs.device)))
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, int(base_resolution), gridtype, interpolation]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = grad.float().view(B, L, C).permute(1, 0, 2).contiguous()   # [L, B, C], what the kernel indexes (grid.py:75)
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
+        check(lib().gf_grid_encode_backward(ptr(grad, torch.float32), ptr(inputs, torch.float32), ptr(embeddings, torch.float32),
+                                            ptr(offsets, torch.int32), ptr(grad_embeddings, torch.float32), B, D, C, L, S, H,
+                                            ptr(dy_dx, torch.float32, allow_none=True), ptr(grad_inputs, torch.float32, allow_none=True), gridtype,
+                                            int(bool(ctx.align_corners)), interpolation, current_stream(grad.device)))
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+
+
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False, interpolation=0):
     """inputs [B,D] in [0,1] -> [B, L*C] (the value `_grid_encode.apply` returns in the reference, grid.py:27-63)."""
-    if calc_grad_inputs:
-        raise NotImplementedError("grid_encode: input gradients belong to the training path (SURVEY.md 8f-2)")
-    inputs = inputs.contiguous()
-    B, D = inputs.shape
-    L = offsets.shape[0] - 1
-    C = embeddings.shape[1]
-    S = float(np.log2(per_level_scale))
-    outputs = torch.empty(B, L * C, device=inputs.device, dtype=torch.float32)
-    check(lib().gf_grid_encode_forward_blc(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
-                                           ptr(outputs), B, D, C, L, S, int(base_resolution), None, gridtype,
-                                           int(bool(align_corners)), interpolation, current_stream(inputs.device)))
-    return outputs
+    if not (torch.is_grad_enabled() and (embeddings.requires_grad or inputs.requires_grad)):
+        calc_grad_inputs = False
+    return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype, align_corners, interpolation)
 
 
 class GridEncoder(nn.Module):
@@ -84,5 +111,5 @@ class GridEncoder(nn.Module):
         inputs = (inputs + bound) / (2 * bound)
         prefix = list(inputs.shape[:-1])
         out = grid_encode(inputs.view(-1, self.input_dim), self.embeddings, self.offsets, self.per_level_scale,
-                          self.base_resolution, False, self.gridtype_id, self.align_corners, self.interp_id)
+                          self.base_resolution, inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
         return out.view(prefix + [self.output_dim])

@@ -5,14 +5,32 @@ import torch.nn as nn
 from ..compat import _shencoder as _backend
 
 
-def sh_encode(inputs, degree, calc_grad_inputs=False):
-    if calc_grad_inputs:
-        raise NotImplementedError("sh_encode: input gradients belong to the training path (SURVEY.md 8f-2)")
-    inputs = inputs.float().contiguous()
-    B, input_dim = inputs.shape
-    outputs = torch.empty(B, degree ** 2, dtype=torch.float32, device=inputs.device)
-    _backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, None)
-    return outputs
+class _sh_encode(torch.autograd.Function):
+    """sphere_harmonics.py:14-58: forward (+ dy_dx when the directions need a gradient), backward through dy_dx."""
+
+    @staticmethod
+    def forward(ctx, inputs, degree, calc_grad_inputs=False):
+        inputs = inputs.float().contiguous()
+        B, input_dim = inputs.shape
+        outputs = torch.empty(B, degree ** 2, dtype=torch.float32, device=inputs.device)
+        dy_dx = torch.empty(B, input_dim * degree ** 2, dtype=torch.float32, device=inputs.device) if calc_grad_inputs else None
+        _backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, dy_dx)
+        ctx.save_for_backward(inputs, dy_dx)
+        ctx.dims = [B, input_dim, degree]
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, dy_dx = ctx.saved_tensors
+        if dy_dx is None:
+            return None, None, None
+        B, input_dim, degree = ctx.dims
+        grad_inputs = torch.zeros_like(inputs)
+        _backend.sh_encode_backward(grad.float().contiguous(), inputs, B, input_dim, degree, dy_dx, grad_inputs)
+        return grad_inputs, None, None
+
+
+sh_encode = _sh_encode.apply
 
 
 class SHEncoder(nn.Module):
@@ -28,5 +46,5 @@ class SHEncoder(nn.Module):
     def forward(self, inputs, size=1):
         inputs = inputs / size
         prefix = list(inputs.shape[:-1])
-        out = sh_encode(inputs.reshape(-1, self.input_dim), self.degree, False)
+        out = sh_encode(inputs.reshape(-1, self.input_dim), self.degree, inputs.requires_grad)
         return out.reshape(prefix + [self.output_dim])

@@ -87,6 +87,11 @@ int gf_morton3D_dilation(const float* grid, uint32_t C, uint32_t H, float* grid_
 int gf_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
                            int align_corners, uint32_t interp, void* stream);
+/* grid_encode_backward (gridencoder.h:12, kernels gridencoder.cu:248-368).  grad [L,B,C]; grad_embeddings [sO,C] ZERO-FILLED by the
+ * caller, accumulated with f32 atomics; dy_dx [B, L*D*C] (from the forward) and grad_inputs [B,D]: both NULL or both given. */
+int gf_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets, float* grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
+                            uint32_t gridtype, int align_corners, uint32_t interp, void* stream);
 /* same arithmetic, outputs laid out [B, L*C] (what GridEncoder.forward returns after grid.py:57's permute). */
 int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
@@ -103,11 +108,17 @@ int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out_host, u
  * `_freqencoder` modules/radnerfs/encoders/freqencoder/src/bindings.cpp, freqencoder.h:7
  * ---------------------------------------------------------------------------------------------- */
 
-/* sh_encode_forward (kernel shencoder.cu:28-68).  inputs [B,3], outputs [B,degree^2]; degree 1..4; dy_dx must be NULL. */
+/* sh_encode_forward (kernel shencoder.cu:28-356).  inputs [B,3], outputs [B,degree^2]; degree 1..4; dy_dx NULL or [B,3,degree^2]. */
 int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx, void* stream);
+/* sh_encode_backward (shencoder.h:10, kernel shencoder.cu:359-383).  grad_inputs [B,3] accumulates. */
+int gf_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t degree, const float* dy_dx,
+                          float* grad_inputs, void* stream);
 
 /* freq_encode_forward (kernel freqencoder.cu:30-58).  inputs [B,D], outputs [B,C], C = D + 2*D*deg. */
 int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream);
+/* freq_encode_backward (freqencoder.h:10, kernel freqencoder.cu:63-94).  grad / outputs [B,C] -> grad_inputs [B,D]. */
+int gf_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* grad_inputs,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused frame path.  One call enqueues a whole head (and torso) pass of

@@ -130,17 +130,31 @@ class gridencoder:
         if rc == -2:
             raise RuntimeError("GridEncoding: C must be 1, 2, 4, or 8.")  # gridencoder.cu:381
 
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
+        rc = lib().orc_grid_encode_backward(_p(grad, torch.float32), _p(inputs, torch.float32), _p(embeddings, torch.float32), _p(offsets, torch.int32),
+                                            _p(grad_embeddings, torch.float32), _u(B), _u(D), _u(Cc), _u(L), _f(S), _u(H),
+                                            _p(dy_dx, torch.float32) if dy_dx is not None else _p(None),
+                                            _p(grad_inputs, torch.float32) if grad_inputs is not None else _p(None),
+                                            _u(gridtype), C.c_int(int(bool(align_corners))), _u(interp))
+        if rc != 0:
+            raise RuntimeError("GridEncoding backward: unsupported D / C")
+
 
 class shencoder:
     """`_shencoder` forward (encoders/shencoder/src/shencoder.h:9)."""
 
     @staticmethod
     def sh_encode_forward(inputs, outputs, B, D, Cc, dy_dx):
-        if dy_dx is not None:
-            raise NotImplementedError("oracle restates the SH forward only")
         rc = lib().orc_sh_encode_forward(_p(inputs, torch.float32), _p(outputs, torch.float32), _u(B), _u(D), _u(Cc))
         if rc != 0:
             raise RuntimeError("SH oracle: D must be 3 and degree in [1,4]")
+        if dy_dx is not None:
+            lib().orc_sh_encode_dy_dx(_p(inputs, torch.float32), _p(dy_dx, torch.float32), _u(B), _u(Cc))
+
+    @staticmethod
+    def sh_encode_backward(grad, inputs, B, D, Cc, dy_dx, grad_inputs):
+        lib().orc_sh_encode_backward(_p(grad, torch.float32), _p(dy_dx, torch.float32), _u(B), _u(Cc), _p(grad_inputs, torch.float32))
 
 
 class freqencoder:
@@ -149,6 +163,10 @@ class freqencoder:
     @staticmethod
     def freq_encode_forward(inputs, B, D, deg, Cc, outputs):
         lib().orc_freq_encode_forward(_p(inputs, torch.float32), _u(B), _u(D), _u(deg), _u(Cc), _p(outputs, torch.float32))
+
+    @staticmethod
+    def freq_encode_backward(grad, outputs, B, D, deg, Cc, grad_inputs):
+        lib().orc_freq_encode_backward(_p(grad, torch.float32), _p(outputs, torch.float32), _u(B), _u(D), _u(deg), _u(Cc), _p(grad_inputs, torch.float32))
 
 
 def grid_level_meta(L, S, H):

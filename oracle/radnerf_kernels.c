@@ -616,3 +616,124 @@ ORC_EXPORT void orc_composite_rays_train_backward(const float* grad_weights_sum_
         }
     }
 }
+
+
+/* =====================================================================================================
+ * Training tier, encoders: gridencoder.cu:248-368 (grid backward: scatter-add into the table + input gradient
+ * through dy_dx), shencoder.cu:122-356 (dy_dx of the degree <= 4 basis, derived from the polynomials of
+ * orc_sh_encode_forward) and :359-383 (backward), freqencoder.cu:63-94 (backward).
+ * ===================================================================================================== */
+
+/* grad [L,B,C]; grad_embeddings [sO,C] accumulated (caller zero-fills); dy_dx [B, L*D*C] and grad_inputs [B,D] may both be NULL.
+ * The CUDA kernel scatters with atomicAdd (order nondeterministic); here contributions are added in (level, b, corner) order. */
+ORC_EXPORT int orc_grid_encode_backward(const float* grad_, const float* inputs_, const float* embeddings, const int32_t* offsets,
+                                        float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        const float* dy_dx_, float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp) {
+    (void)embeddings;
+    if (D < 2 || D > ORC_MAX_D) return -1;
+    if (!(C == 1 || C == 2 || C == 4 || C == 8)) return -2;
+    for (uint32_t level = 0; level < L; level++) {
+        float* grad_grid = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const float scale = exp2f((float)level * S) * (float)H - 1.0f;
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* inputs = inputs_ + (size_t)b * D;
+            const float* grad = grad_ + (size_t)level * B * C + (size_t)b * C;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (inputs[d] < 0 || inputs[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[ORC_MAX_D];
+            uint32_t pos_grid[ORC_MAX_D];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pgl[ORC_MAX_D];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = orc_grid_index(gridtype, align_corners, D, C, 0, hashmap_size, resolution, pgl);
+                for (uint32_t ch = 0; ch < C; ch++) grad_grid[index + ch] += w * grad[ch];
+            }
+        }
+    }
+    if (dy_dx_ && grad_inputs) {   /* kernel_input_backward :343-368 */
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)B * D; t++) {
+            const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (int64_t)b * D);
+            const float* dy_dx = dy_dx_ + (size_t)b * L * D * C;
+            float result = 0;
+            for (uint32_t l = 0; l < L; l++)
+                for (uint32_t ch = 0; ch < C; ch++) result += grad_[(size_t)l * B * C + (size_t)b * C + ch] * dy_dx[l * D * C + d * C + ch];
+            grad_inputs[t] = result;
+        }
+    }
+    return 0;
+}
+
+/* d/dx, d/dy, d/dz of the 16 real SH polynomials of orc_sh_encode_forward (degree <= 4): dy_dx [B, 3, degree^2]. */
+ORC_EXPORT int orc_sh_encode_dy_dx(const float* inputs, float* dy_dx, uint32_t B, uint32_t degree) {
+    if (degree < 1 || degree > 4) return -1;
+    const uint32_t C2 = degree * degree;
+    const float k1 = 0.48860251190291987f, k2 = 1.0925484305920792f, k3a = 0.59004358992664352f, k3b = 0.45704579946446572f;
+    const float a6 = 0.94617469575755997f, c8 = 0.54627421529603959f, c10 = 2.8906114426405538f, c12 = 0.3731763325901154f,
+                c14 = 1.4453057213202769f;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        const float x = inputs[b * 3], y = inputs[b * 3 + 1], z = inputs[b * 3 + 2];
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        float g[3][16];
+        memset(g, 0, sizeof(g));
+        g[1][1] = -k1; g[2][2] = k1; g[0][3] = -k1;
+        g[0][4] = k2 * y; g[1][4] = k2 * x;
+        g[1][5] = -k2 * z; g[2][5] = -k2 * y;
+        g[2][6] = 2 * a6 * z;
+        g[0][7] = -k2 * z; g[2][7] = -k2 * x;
+        g[0][8] = 2 * c8 * x; g[1][8] = -2 * c8 * y;
+        g[0][9] = -6 * k3a * x * y; g[1][9] = 3 * k3a * (y2 - x2);
+        g[0][10] = c10 * y * z; g[1][10] = c10 * x * z; g[2][10] = c10 * x * y;
+        g[1][11] = k3b * (1 - 5 * z2); g[2][11] = -10 * k3b * y * z;
+        g[2][12] = c12 * (15 * z2 - 3);
+        g[0][13] = k3b * (1 - 5 * z2); g[2][13] = -10 * k3b * x * z;
+        g[0][14] = 2 * c14 * x * z; g[1][14] = -2 * c14 * y * z; g[2][14] = c14 * (x2 - y2);
+        g[0][15] = 3 * k3a * (y2 - x2); g[1][15] = 6 * k3a * x * y;
+        float* o = dy_dx + (size_t)b * 3 * C2;
+        for (uint32_t d = 0; d < 3; d++)
+            for (uint32_t k = 0; k < C2; k++) o[d * C2 + k] = g[d][k];
+    }
+    return 0;
+}
+
+/* shencoder.cu:359-383: grad_inputs[b][d] += sum_k grad[b][k] * dy_dx[b][d][k]   (the caller zero-fills grad_inputs) */
+ORC_EXPORT void orc_sh_encode_backward(const float* grad, const float* dy_dx, uint32_t B, uint32_t degree, float* grad_inputs) {
+    const uint32_t C2 = degree * degree;
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t d = 0; d < 3; d++) {
+            float acc = grad_inputs[b * 3 + d];
+            for (uint32_t k = 0; k < C2; k++) acc += grad[(size_t)b * C2 + k] * dy_dx[(size_t)b * 3 * C2 + d * C2 + k];
+            grad_inputs[b * 3 + d] = acc;
+        }
+}
+
+/* freqencoder.cu:63-94: d/dx of [x, sin(2^f x), cos(2^f x), ...] read off the forward OUTPUTS (cos = outputs[D + d] of the pair) */
+ORC_EXPORT void orc_freq_encode_backward(const float* grad_, const float* outputs_, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                                         float* grad_inputs) {
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t d = 0; d < D; d++) {
+            const float* grad = grad_ + (size_t)b * C;
+            const float* outputs = outputs_ + (size_t)b * C;
+            float result = grad[d];
+            grad += D; outputs += D;
+            for (uint32_t f = 0; f < deg; f++) {
+                result += scalbnf(1.0f, (int)f) * (grad[d] * outputs[D + d] - grad[D + d] * outputs[d]);
+                grad += 2 * D; outputs += 2 * D;
+            }
+            grad_inputs[(size_t)b * D + d] = result;
+        }
+}

@@ -36,7 +36,7 @@ def test_grid_encoder_vs_golden_and_oracle(ops, D, enc, interp):
     assert out_dim == 32 and np.array_equal(m.offsets.numpy(), off)
     m.embeddings.data.copy_(torch.from_numpy(table))
     m = m.to(DEV)
-    y = m(torch.from_numpy(x).to(DEV), bound=1).cpu().numpy()
+    y = m(torch.from_numpy(x).to(DEV), bound=1).detach().cpu().numpy()
     gold = ops[tag + "_y"]
     assert y.shape == gold.shape
     assert np.abs(y - gold).max() < 2e-6, np.abs(y - gold).max()   # fp32, fma vs mul+add ordering only

@@ -96,3 +96,67 @@ def test_march_rays_train_backward_vs_oracle():
     go, gdd = torch.zeros(N, 3), torch.zeros(N, 3)
     RM.march_rays_train_backward(gx, gd, rays.cpu(), deltas.detach().cpu().contiguous(), N, M, go, gdd)
     assert (ro_g.grad.cpu() - go).abs().max() < 1e-4 and (rd_g.grad.cpu() - gdd).abs().max() < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------- encoders, backward
+@pytest.mark.parametrize("D,gridtype,interp", [(3, "tiled", "linear"), (2, "tiled", "linear"), (3, "hash", "linear"), (2, "hash", "smoothstep")])
+def test_grid_encoder_autograd_vs_oracle(D, gridtype, interp):
+    """GridEncoder.forward / backward through torch autograd (grid.py:24-90): table gradient (f32-atomic scatter) and input gradient
+    against the oracle's kernels on the same inputs."""
+    from geneface_amd.encoders.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=14, desired_resolution=1024,
+                      gridtype=gridtype, interpolation=interp).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1).to(DEV))
+    B = 50_000
+    x = (torch.rand(B, D, generator=g) * 2 - 1)
+    x[:5] = 1.5                                            # outside [-bound, bound]: zero features, zero gradients
+    grad = torch.randn(B, 32, generator=g)
+    x_g = x.to(DEV).requires_grad_(True)
+    out = enc(x_g, bound=1)
+    (out * grad.to(DEV)).sum().backward()
+    # oracle on the same numbers
+    off, emb = enc.offsets.cpu(), enc.embeddings.detach().cpu()
+    S = float(torch.log2(torch.tensor(enc.per_level_scale, dtype=torch.float64)))
+    x01 = ((x + 1) / 2).contiguous()
+    o_ref, dy = torch.empty(16, B, 2), torch.empty(B, 16 * D * 2)
+    K.gridencoder.grid_encode_forward(x01, emb, off, o_ref, B, D, 2, 16, S, 16, dy, enc.gridtype_id, False, enc.interp_id)
+    assert (out.detach().cpu() - o_ref.permute(1, 0, 2).reshape(B, 32)).abs().max() < 1e-5
+    g_emb, g_in = torch.zeros_like(emb), torch.zeros(B, D)
+    K.gridencoder.grid_encode_backward(grad.view(B, 16, 2).permute(1, 0, 2).contiguous(), x01, emb, off, g_emb, B, D, 2, 16, S, 16, dy, g_in,
+                                       enc.gridtype_id, False, enc.interp_id)
+    ge = enc.embeddings.grad.cpu()
+    assert (ge - g_emb).abs().max() < 2e-4 * max(1.0, float(g_emb.abs().max()))     # accumulation order differs (atomics)
+    gi = x_g.grad.cpu() * 2                                   # d/dx of (x + bound) / (2 bound) is 1/2
+    assert (gi - g_in).abs().max() < 1e-3 * max(1.0, float(g_in.abs().max()))
+    assert not x_g.grad[:5].any()
+    # inference-style call: no graph, no dy_dx
+    with torch.no_grad():
+        assert torch.equal(enc(x.to(DEV), bound=1), out.detach())
+
+
+def test_sh_and_freq_encoder_autograd_vs_oracle():
+    from geneface_amd.encoders.freqencoder import FreqEncoder
+    from geneface_amd.encoders.shencoder import SHEncoder
+    g = torch.Generator().manual_seed(12)
+    B = 20_000
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    grad = torch.randn(B, 16, generator=g)
+    d_g = d.to(DEV).requires_grad_(True)
+    out = SHEncoder(3, 4)(d_g)
+    (out * grad.to(DEV)).sum().backward()
+    o_ref, dy, gi = torch.empty(B, 16), torch.empty(B, 3, 16), torch.zeros(B, 3)
+    K.shencoder.sh_encode_forward(d, o_ref, B, 3, 4, dy)
+    K.shencoder.sh_encode_backward(grad, d, B, 3, 4, dy, gi)
+    assert (out.detach().cpu() - o_ref).abs().max() < 1e-6 and (d_g.grad.cpu() - gi).abs().max() < 1e-5
+    x = torch.randn(B, 6, generator=g)
+    fe = FreqEncoder(6, 4)
+    gr = torch.randn(B, fe.output_dim, generator=g)
+    x_g = x.to(DEV).requires_grad_(True)
+    fo = fe(x_g)
+    (fo * gr.to(DEV)).sum().backward()
+    f_ref, gin = torch.empty(B, fe.output_dim), torch.zeros(B, 6)
+    K.freqencoder.freq_encode_forward(x, B, 6, 4, fe.output_dim, f_ref)
+    K.freqencoder.freq_encode_backward(gr, f_ref, B, 6, 4, fe.output_dim, gin)
+    assert (fo.detach().cpu() - f_ref).abs().max() < 1e-5 and (x_g.grad.cpu() - gin).abs().max() < 2e-4

@@ -126,3 +126,93 @@ def test_march_train_backward_is_the_chain_rule_of_o_plus_t_d():
         np.testing.assert_allclose(go[n].numpy(), gx[o:o + c].sum(0).numpy(), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(gdd[n].numpy(), (gx[o:o + c] * deltas[o:o + c, 1:2] + gd[o:o + c]).sum(0).numpy(), rtol=1e-5, atol=1e-5)
     assert not go[rays[:, 2] == 0].any()
+
+
+# ----------------------------------------------------------------------------------------------- encoders, backward
+def _grid_setup(D, gridtype, interp, B=4000, seed=0):
+    from geneface_amd.encoders.gridencoder import grid_offsets, per_level_scale_for
+    off = grid_offsets(D, 16, 16, 12, 512)                     # small tables: every row is hit
+    S = float(np.log2(per_level_scale_for(512, 16, 16)))
+    g = torch.Generator().manual_seed(seed)
+    emb = torch.rand(int(off[-1]), 2, generator=g) * 2 - 1
+    x = torch.rand(B, D, generator=g)
+    x[:7] = torch.tensor([1.5] + [0.5] * (D - 1))              # out-of-range points contribute nothing
+    return torch.from_numpy(off), S, emb, x, g
+
+
+def _grid_fwd(x, emb, off, S, D, gridtype, interp, dy_dx=None):
+    B = x.shape[0]
+    out = torch.empty(16, B, 2)
+    K.gridencoder.grid_encode_forward(x, emb, off, out, B, D, 2, 16, S, 16, dy_dx, gridtype, False, interp)
+    return out
+
+
+import pytest
+
+
+@pytest.mark.parametrize("D,gridtype,interp", [(3, 1, 0), (2, 1, 0), (3, 0, 0), (2, 0, 1), (3, 1, 1)])
+def test_grid_backward_is_the_adjoint_of_the_forward(D, gridtype, interp):
+    """The lookup is linear in the table: <grad, F(E + dE) - F(E)> == <grad_E, dE>; and grad_x = J^T grad with J = dy_dx, which for
+    linear interpolation is also the finite difference inside a cell."""
+    off, S, emb, x, g = _grid_setup(D, gridtype, interp)
+    B = x.shape[0]
+    grad = torch.randn(16, B, 2, generator=g)
+    dy_dx = torch.empty(B, 16 * D * 2)
+    out = _grid_fwd(x, emb, off, S, D, gridtype, interp, dy_dx)
+    g_emb, g_in = torch.zeros_like(emb), torch.zeros(B, D)
+    K.gridencoder.grid_encode_backward(grad, x, emb, off, g_emb, B, D, 2, 16, S, 16, dy_dx, g_in, gridtype, False, interp)
+    d_emb = torch.randn(emb.shape, generator=g)
+    lhs = ((_grid_fwd(x, emb + d_emb, off, S, D, gridtype, interp).double() - out.double()) * grad.double()).sum()
+    rhs = (g_emb.double() * d_emb.double()).sum()
+    assert abs(lhs - rhs) < 2e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert not g_in[:7].any()
+    want = torch.einsum("lbc,bldc->bd", grad.double(), dy_dx.view(B, 16, D, 2).double())
+    assert (g_in.double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+    if interp == 0:   # piecewise linear: a central difference that stays inside the finest cell is exact up to rounding
+        eps = 2e-5
+        sel = slice(7, 400)
+        for d in range(D):
+            xp, xm = x.clone(), x.clone()
+            xp[:, d] += eps; xm[:, d] -= eps
+            fd = (_grid_fwd(xp.clamp(0, 1), emb, off, S, D, gridtype, interp).double() - _grid_fwd(xm.clamp(0, 1), emb, off, S, D, gridtype, interp).double()) / (2 * eps)
+            jac = dy_dx.view(B, 16, D, 2)[:, :, d].permute(1, 0, 2).double()
+            # points whose +-eps neighbourhood crosses a cell face at some level are not differentiable there: compare the median
+            err = (fd[:, sel] - jac[:, sel]).abs().flatten()
+            assert err.median() < 5e-2 * max(1.0, float(jac.abs().median()))
+
+
+def test_sh_and_freq_backward_vs_autograd():
+    g = torch.Generator().manual_seed(6)
+    B = 300
+    x = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    out, dy = torch.empty(B, 16), torch.empty(B, 3, 16)
+    K.shencoder.sh_encode_forward(x, out, B, 3, 4, dy)
+    xd = x.double().requires_grad_(True)
+    X, Y, Z = xd[:, 0], xd[:, 1], xd[:, 2]
+    sh = torch.stack([torch.full_like(X, 0.28209479177387814), -0.48860251190291987 * Y, 0.48860251190291987 * Z, -0.48860251190291987 * X,
+                      1.0925484305920792 * X * Y, -1.0925484305920792 * Y * Z, 0.94617469575755997 * Z * Z - 0.31539156525251999,
+                      -1.0925484305920792 * X * Z, 0.54627421529603959 * (X * X - Y * Y), 0.59004358992664352 * Y * (-3 * X * X + Y * Y),
+                      2.8906114426405538 * X * Y * Z, 0.45704579946446572 * Y * (1 - 5 * Z * Z), 0.3731763325901154 * Z * (5 * Z * Z - 3),
+                      0.45704579946446572 * X * (1 - 5 * Z * Z), 1.4453057213202769 * Z * (X * X - Y * Y),
+                      0.59004358992664352 * X * (-X * X + 3 * Y * Y)], dim=1)
+    assert (sh.float() - out).abs().max() < 1e-6
+    grad = torch.randn(B, 16, generator=g)
+    (sh * grad.double()).sum().backward()
+    gi = torch.zeros(B, 3)
+    K.shencoder.sh_encode_backward(grad, x, B, 3, 4, dy, gi)
+    assert (gi - xd.grad.float()).abs().max() < 1e-5
+    # frequency encoding: [x, sin(2^f x), cos(2^f x)]
+    D, deg = 6, 4
+    Cc = D + 2 * D * deg
+    xin = torch.randn(B, D, generator=g)
+    fo = torch.empty(B, Cc)
+    K.freqencoder.freq_encode_forward(xin, B, D, deg, Cc, fo)
+    xq = xin.double().requires_grad_(True)
+    parts = [xq] + [f(xq * 2.0 ** k) for k in range(deg) for f in (torch.sin, torch.cos)]
+    enc = torch.cat(parts, dim=1)
+    assert (enc.float() - fo).abs().max() < 1e-5
+    gr = torch.randn(B, Cc, generator=g)
+    (enc * gr.double()).sum().backward()
+    gin = torch.zeros(B, D)
+    K.freqencoder.freq_encode_backward(gr, fo, B, D, deg, Cc, gin)
+    assert (gin - xq.grad.float()).abs().max() < 2e-4
