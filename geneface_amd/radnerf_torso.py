@@ -65,10 +65,44 @@ class RADNeRFTorso(RADNeRF):
                             align_corners=True).view(-1)
         return occ > thresh
 
+    def _render_train_torso(self, rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, force_all_rays, max_steps):
+        """radnerf_torso.py:86-198 with self.training: the (frozen) head is rendered under no_grad by the training marcher, only the
+        torso field receives gradients."""
+        with torch.no_grad():
+            prefix = rays_o.shape[:-1]
+            rays_o = rays_o.contiguous().view(-1, 3)
+            rays_d = rays_d.contiguous().view(-1, 3)
+            bg_coords = bg_coords.contiguous().view(-1, 2)
+            N, device = rays_o.shape[0], rays_o.device
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+            cond_feat = self.cal_cond_feat(cond)
+            ind_code = self.individual_embeddings[index] if self.individual_embedding_dim > 0 else None
+            weights_sum, ambient_sum, depth, image = self._march_head_train(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb,
+                                                                            force_all_rays, max_steps)
+            results = {"weights_sum": weights_sum, "ambient": ambient_sum}
+            if bg_color is None:
+                bg_color = 1
+        code = self.torso_individual_codes[index] if self.torso_individual_embedding_dim > 0 else None
+        mask = self.torso_mask(bg_coords)
+        torso_alpha = torch.zeros([N, 1], device=device)
+        torso_color = torch.zeros([N, 3], device=device)
+        if mask.any():
+            a, c, deform = self.forward_torso(bg_coords[mask], poses, code)
+            torso_alpha[mask] = a.float()
+            torso_color[mask] = c.float()
+            results["deform"] = deform
+        bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
+        results["torso_alpha_map"] = torso_alpha
+        results["torso_rgb_map"] = bg_color
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        results["rgb_map"] = image.view(*prefix, 3).clamp(0, 1)
+        results["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+        return results
+
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False,
                force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         if self.training:
-            raise NotImplementedError("RADNeRFTorso.render: the training branch is outside this round's scope (SURVEY.md 8f-2)")
+            return self._render_train_torso(rays_o, rays_d, cond, bg_coords, poses, index, dt_gamma, bg_color, perturb, force_all_rays, max_steps)
         impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_torso_fused

@@ -10,7 +10,8 @@ arithmetic (geneface_amd/csrc):
   impl="fused"  (default once built) the whole frame enqueued without host synchronisation by
                 geneface_amd/fused.py.
 
-Training (`self.training == True`) and density-grid maintenance are outside this round's scope.
+`self.training == True` takes the reference's training branch (:296-313) over the training-tier ops (march_rays_train,
+composite_rays_train, encoder backward passes); density-grid maintenance is `update_extra_state` / `mark_untrained_grid`.
 """
 import math
 import random
@@ -216,10 +217,42 @@ class NeRFRenderer(nn.Module):
             step += n_step
         return weights_sum, depth, image
 
+    def _march_head_train(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb, force_all_rays, max_steps):
+        """renderer.py:296-313: one pass over all rays (count / prefix / write marcher), the field through torch autograd (grid, SH
+        encoders and trunc_exp carry custom backward passes), differentiable compositing."""
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                nears, fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma,
+                                                                max_steps)
+        sigmas, rgbs, ambient = self(xyzs, dirs, cond_feat, ind_code)
+        sigmas = self.density_scale * sigmas
+        weights_sum, ambient_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, ambient.abs().sum(-1), deltas, rays)
+        return weights_sum, ambient_sum, depth, image
+
+    def _render_train(self, rays_o, rays_d, cond, index, dt_gamma, bg_color, perturb, force_all_rays, max_steps):
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+        nears, fars = nears.detach(), fars.detach()
+        cond_feat = self.cal_cond_feat(cond)
+        ind_code = self.individual_embeddings[index] if self.individual_embedding_dim > 0 else None
+        weights_sum, ambient_sum, depth, image = self._march_head_train(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb,
+                                                                        force_all_rays, max_steps)
+        results = {"weights_sum": weights_sum, "ambient": ambient_sum}
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        results["rgb_map"] = image.view(*prefix, 3).clamp(0, 1)
+        results["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+        return results
+
     def render(self, rays_o, rays_d, cond, bg_coords, poses, index=0, dt_gamma=0, bg_color=None, perturb=False,
                force_all_rays=False, max_steps=1024, T_thresh=1e-4, **kwargs):
         if self.training:
-            raise NotImplementedError("NeRFRenderer.render: the training branch is outside this round's scope (SURVEY.md 8f-2)")
+            return self._render_train(rays_o, rays_d, cond, index, dt_gamma, bg_color, perturb, force_all_rays, max_steps)
         impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_head_fused

@@ -1,6 +1,6 @@
 """Camera / pose helpers of the render path (torch, tiny, once per frame or per sequence).
 
-Behaviour follows modules/radnerfs/utils.py of the reference: trunc_exp :36-49 (forward = exp),
+Behaviour follows modules/radnerfs/utils.py of the reference: trunc_exp :36-49,
 nerf_matrix_to_ngp :53-60, matrix_to_euler_angles :160-199 ('XYZ'), convert_poses :263-269,
 get_bg_coords :273-278, get_rays :282-363 (full-image branch, N = -1), and
 tasks/radnerfs/dataset_utils.py:16-36 smooth_camera_path.
@@ -9,8 +9,22 @@ import numpy as np
 import torch
 
 
-def trunc_exp(x):
-    return torch.exp(x.float())
+class _trunc_exp(torch.autograd.Function):
+    """modules/radnerfs/utils.py:36-49: exp in the forward, gradient clamped to exp(clamp(x, -15, 15)) in the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x = ctx.saved_tensors[0]
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _trunc_exp.apply
 
 
 def nerf_matrix_to_ngp(pose, scale=4, offset=(0, 0, 0)):

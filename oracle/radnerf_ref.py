@@ -45,14 +45,92 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfi
     return xyzs, dirs, deltas
 
 
+class _GridEncode(torch.autograd.Function):
+    """gridencoder/grid.py:24-90 over the C kernels: [B, L*C] out, table gradient by scatter-add, input gradient through dy_dx."""
+
+    @staticmethod
+    def forward(ctx, x01, embeddings, offsets, S, base_resolution, gridtype, align_corners, interp, need_dx):
+        x01, embeddings = x01.detach().contiguous(), embeddings.detach().contiguous()
+        B, D = x01.shape
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        out = torch.empty(L, B, C)
+        dy_dx = torch.empty(B, L * D * C) if need_dx else None
+        GE.grid_encode_forward(x01, embeddings, offsets, out, B, D, C, L, S, base_resolution, dy_dx, gridtype, align_corners, interp)
+        ctx.save_for_backward(x01, embeddings, offsets, dy_dx)
+        ctx.cfg = (B, D, C, L, S, base_resolution, gridtype, align_corners, interp)
+        return out.permute(1, 0, 2).reshape(B, L * C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x01, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, align_corners, interp = ctx.cfg
+        g = grad.contiguous().view(B, L, C).permute(1, 0, 2).contiguous()
+        g_emb = torch.zeros_like(embeddings)
+        g_in = torch.zeros(B, D) if dy_dx is not None else None
+        GE.grid_encode_backward(g, x01, embeddings, offsets, g_emb, B, D, C, L, S, H, dy_dx, g_in, gridtype, align_corners, interp)
+        return g_in, g_emb, None, None, None, None, None, None, None
+
+
 def grid_encode(x01, embeddings, offsets, per_level_scale, base_resolution, gridtype, align_corners, interp):
-    x01 = x01.contiguous()
-    B, D = x01.shape
-    L, C = offsets.shape[0] - 1, embeddings.shape[1]
-    out = torch.empty(L, B, C)
-    GE.grid_encode_forward(x01, embeddings.contiguous(), offsets, out, B, D, C, L, float(np.log2(per_level_scale)), base_resolution,
-                           None, gridtype, align_corners, interp)
-    return out.permute(1, 0, 2).reshape(B, L * C)
+    need_graph = torch.is_grad_enabled() and (x01.requires_grad or embeddings.requires_grad)
+    return _GridEncode.apply(x01, embeddings, offsets, float(np.log2(per_level_scale)), base_resolution, gridtype, align_corners, interp,
+                             need_graph and x01.requires_grad)
+
+
+class _TruncExp(torch.autograd.Function):
+    """modules/radnerfs/utils.py:36-49"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
+
+
+class _FreqEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, degree):
+        x = x.detach().contiguous()
+        B, D = x.shape
+        C = D + 2 * D * degree
+        out = torch.empty(B, C)
+        FQ.freq_encode_forward(x, B, D, degree, C, out)
+        ctx.save_for_backward(out)
+        ctx.cfg = (B, D, degree, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        B, D, degree, C = ctx.cfg
+        g_in = torch.zeros(B, D)
+        FQ.freq_encode_backward(grad.contiguous(), ctx.saved_tensors[0], B, D, degree, C, g_in)
+        return g_in, None
+
+
+class _CompositeTrain(torch.autograd.Function):
+    """raymarching.py:286-342 over the C kernels (T_thresh 1e-4)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, ambient, deltas, rays, T_thresh):
+        sigmas, rgbs, ambient = sigmas.detach().contiguous(), rgbs.detach().contiguous(), ambient.detach().contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        ws, amb, dep, img = torch.empty(N), torch.empty(N), torch.empty(N), torch.empty(N, 3)
+        RM.composite_rays_train_forward(sigmas, rgbs, ambient, deltas, rays, M, N, T_thresh, ws, amb, dep, img)
+        ctx.save_for_backward(sigmas, rgbs, ambient, deltas, rays, ws, amb, img)
+        ctx.cfg = (M, N, T_thresh)
+        return ws, amb, dep, img
+
+    @staticmethod
+    def backward(ctx, g_ws, g_amb, g_dep, g_img):
+        sigmas, rgbs, ambient, deltas, rays, ws, amb, img = ctx.saved_tensors
+        M, N, T_thresh = ctx.cfg
+        gs, gc, ga = torch.zeros(M), torch.zeros(M, 3), torch.zeros(M)
+        RM.composite_rays_train_backward(g_ws.contiguous(), g_amb.contiguous(), g_img.contiguous(), sigmas, rgbs, ambient, deltas, rays, ws, amb, img,
+                                         M, N, T_thresh, gs, gc, ga)
+        return gs, gc, ga, None, None, None
 
 
 def sh_encode(d, degree=4):
@@ -63,12 +141,7 @@ def sh_encode(d, degree=4):
 
 
 def freq_encode(x, degree):
-    x = x.contiguous()
-    B, D = x.shape
-    C = D + 2 * D * degree
-    out = torch.empty(B, C)
-    FQ.freq_encode_forward(x, B, D, degree, C, out)
-    return out
+    return _FreqEncode.apply(x, degree)
 
 
 # ----------------------------------------------------------------------------- small networks
@@ -122,7 +195,7 @@ def head_field(sd, hp, position, direction, cond_feat, ind_code):
     ambient_feat = grid_encode((ambient_pos + 1) / 2, sd["ambient_embedder.embeddings"], sd["ambient_embedder.offsets"], pls2, 16,
                                gt, False, ip)
     h = mlp(sd, "sigma_net", torch.cat([pos_feat, ambient_feat], dim=-1), hp["num_layers_sigma"])
-    sigma = torch.exp(h[..., 0])
+    sigma = _TruncExp.apply(h[..., 0])
     parts = [sh_encode(direction), h[..., 1:]]
     if ind_code is not None:
         parts.append(ind_code.reshape(1, -1).repeat(M, 1))
@@ -346,4 +419,60 @@ def mark_untrained_grid(hp, density_grid, poses, intrinsic, S=64):
                 head += S
     out = density_grid.clone()
     out[count == 0] = -1
+    return out
+
+
+# ----------------------------------------------------------------------------- training branch
+def render_train(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, index=0, mean_count=-1, noises=None, force_all_rays=True):
+    """NeRFRenderer.render / RADNeRFTorso.render with self.training (renderer.py:296-313, radnerf_torso.py:93-198): differentiable
+    w.r.t. every tensor of `sd` that requires grad.  Returns the result dict (+ the marcher's `rays` and point count)."""
+    dt_gamma, max_steps = hp["dt_gamma"], hp["max_steps"]
+    prefix = rays_o.shape[:-1]
+    rays_o = rays_o.contiguous().view(-1, 3).float()
+    rays_d = rays_d.contiguous().view(-1, 3).float()
+    N = rays_o.shape[0]
+    cascade = 1 + math.ceil(math.log2(hp["bound"]))
+    nears, fars = near_far_from_aabb(rays_o, rays_d, sd["aabb_train"], hp["min_near"])
+
+    def head():
+        cond_feat = cal_cond_feat(sd, hp, cond)
+        ind_code = sd["individual_embeddings"][index] if hp["individual_embedding_dim"] > 0 else None
+        M = N * max_steps if (force_all_rays or mean_count <= 0) else mean_count + (128 - mean_count % 128)
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        rays, counter = torch.empty(N, 3, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
+        RM.march_rays_train(rays_o, rays_d, sd["density_bitfield"], float(hp["bound"]), dt_gamma, max_steps, N, cascade, hp["grid_size"], M,
+                            nears, fars, xyzs, dirs, deltas, rays, counter, torch.zeros(N) if noises is None else noises)
+        if force_all_rays or mean_count <= 0:
+            m = counter[0].item()
+            m += 128 - m % 128
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        sigmas, rgbs, ambient = head_field(sd, hp, xyzs, dirs, cond_feat, ind_code)
+        ws, amb, dep, img = _CompositeTrain.apply(sigmas, rgbs, ambient.abs().sum(-1), deltas.contiguous(), rays, 1e-4)
+        return ws, amb, dep, img, rays, counter
+
+    if torso:
+        with torch.no_grad():
+            weights_sum, ambient_sum, depth, image, rays, counter = head()
+    else:
+        weights_sum, ambient_sum, depth, image, rays, counter = head()
+    out = {"weights_sum": weights_sum, "ambient": ambient_sum, "rays": rays, "n_points": int(counter[0])}
+    if bg_color is None:
+        bg_color = 1
+    if torso:
+        bg_coords = bg_coords.contiguous().view(-1, 2)
+        G = hp["grid_size"]
+        occ = F.grid_sample(sd["density_grid_torso"].view(1, 1, G, G), bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
+        mask = occ > min(hp["density_thresh_torso"], 0)
+        torso_alpha, torso_color = torch.zeros(N, 1), torch.zeros(N, 3)
+        if mask.any():
+            code = sd["torso_individual_codes"][index] if hp["torso_individual_embedding_dim"] > 0 else None
+            a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code)
+            torso_alpha = torso_alpha.masked_scatter(mask.unsqueeze(-1), a)
+            torso_color = torso_color.masked_scatter(mask.unsqueeze(-1).expand(-1, 3), c)
+            out["deform"] = deform
+        bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
+        out["torso_alpha_map"], out["torso_rgb_map"] = torso_alpha, bg_color
+    image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+    out["rgb_map"] = image.view(*prefix, 3).clamp(0, 1)
+    out["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
     return out

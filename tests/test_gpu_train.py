@@ -160,3 +160,54 @@ def test_sh_and_freq_encoder_autograd_vs_oracle():
     K.freqencoder.freq_encode_forward(x, B, 6, 4, fe.output_dim, f_ref)
     K.freqencoder.freq_encode_backward(gr, f_ref, B, 6, 4, fe.output_dim, gin)
     assert (fo.detach().cpu() - f_ref).abs().max() < 1e-5 and (x_g.grad.cpu() - gin).abs().max() < 2e-4
+
+
+# ----------------------------------------------------------------------------------------------- training branch of render()
+@pytest.mark.parametrize("torso", [False, True])
+def test_render_training_branch_gradients_vs_oracle(torso):
+    """model.train(); model.render(...) takes the reference's training branch (renderer.py:296-313 / radnerf_torso.py:93-198): one
+    loss, one backward, every parameter gradient against the oracle's differentiable restatement on the CPU."""
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(torso)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    g = torch.Generator().manual_seed(8)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=g)
+    # oracle
+    sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith(("aabb", "density")) else v) for k, v in sd.items()}
+    ref = R.render_train(sd_g, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
+    _loss(ref, target).backward()
+    # GPU
+    model = (RADNeRFTorso if torso else RADNeRF)(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    to = lambda t: t.to(DEV)
+    out = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                       bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    assert (out["rgb_map"].detach().cpu() - ref["rgb_map"].detach()).abs().max() < 5e-4
+    assert (out["weights_sum"].detach().cpu() - ref["weights_sum"].detach()).abs().max() < 5e-4
+    _loss(out, to(target)).backward()
+    assert int(model.step_counter[0, 0]) == ref["n_points"] and model.local_step == 1
+    checked = 0
+    for name, p in model.named_parameters():
+        gr = sd_g[name].grad
+        if gr is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name      # head frozen under no_grad in the torso model
+            continue
+        assert p.grad is not None, name
+        # fp32 on both sides, different summation orders, exp() of the density head in between; and a sample whose ambient coordinate
+        # sits within rounding of a cell face of the 2048-level 2-D grid takes its (piecewise constant) dy_dx from the neighbouring cell
+        # on one side only -- so: tight in the L2 sense, loose on the single worst entry
+        diff = (p.grad.cpu() - gr).double()
+        l2 = float(diff.norm() / gr.double().norm().clamp(min=1e-20))
+        worst = float(diff.abs().max()) / max(float(gr.abs().max()), 1e-12)
+        assert l2 < 1e-2 and worst < 0.1, (name, l2, worst)
+        checked += 1
+    assert checked >= (6 if torso else 20)
+    # eval() switches back to the inference branch (fused kernels)
+    model.eval()
+    with torch.no_grad():
+        ev = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                          bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    assert "weights_sum" not in ev and ev["rgb_map"].shape == out["rgb_map"].shape

@@ -216,3 +216,44 @@ def test_sh_and_freq_backward_vs_autograd():
     gin = torch.zeros(B, D)
     K.freqencoder.freq_encode_backward(gr, fo, B, D, deg, Cc, gin)
     assert (gin - xq.grad.float()).abs().max() < 2e-4
+
+
+# ----------------------------------------------------------------------------------------------- training branch
+def _train_setup(torso, size=20, idx=1):
+    hp, sd = model_fixture(torso)
+    fi = frame_inputs(sequence(4, size, size), idx)
+    return hp, sd, fi
+
+
+def _loss(out, target):
+    return ((out["rgb_map"] - target) ** 2).mean() + 1e-3 * out["weights_sum"].mean() + 1e-4 * out["ambient"].mean()
+
+
+@pytest.mark.parametrize("torso", [False, True])
+def test_render_train_gradients_match_finite_differences(torso):
+    """The oracle's training branch (march_rays_train -> field -> composite_rays_train through custom autograd over the C kernels):
+    directional derivatives of the loss along random directions of a few weight tensors against central differences."""
+    hp, sd, fi = _train_setup(torso)
+    names = (["torso_canonicial_net.net.2.weight", "torso_deform_net.net.0.weight", "torso_embedder.embeddings"] if torso else
+             ["color_net.net.1.weight", "sigma_net.net.1.weight", "ambient_net.net.2.weight", "position_embedder.embeddings"])
+    g = torch.Generator().manual_seed(7)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=g)
+
+    def run(sd_):
+        return R.render_train(sd_, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
+
+    sd_g = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    out = run(sd_g)
+    assert out["n_points"] > 0
+    loss = _loss(out, target)
+    loss.backward()
+    for k in names:
+        grad = sd_g[k].grad
+        assert grad is not None and torch.isfinite(grad).all() and grad.abs().max() > 0, k
+        direction = torch.randn(sd[k].shape, generator=g)
+        direction /= direction.norm()
+        eps = 2e-3 * max(1.0, float(sd[k].abs().mean())) if "embeddings" not in k else 1e-2
+        lp = _loss(run({**sd, k: sd[k] + eps * direction}), target).item()
+        lm = _loss(run({**sd, k: sd[k] - eps * direction}), target).item()
+        fd, an = (lp - lm) / (2 * eps), float((grad * direction).sum())
+        assert abs(fd - an) <= 0.08 * max(abs(fd), abs(an)) + 2e-6, (k, fd, an)
