@@ -147,51 +147,78 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
     grad_inputs[t] = result;
 }
 
-// gridencoder.cu:248-339: one lane per (point, level); every corner's share of the output gradient is scattered into the table
-// with hardware f32 atomics (the accumulation order, hence the last bits, vary from run to run exactly as in the reference).
+// gridencoder.cu:248-339: every corner's share of the output gradient is scatter-added into the table (f32 atomics: the accumulation
+// order, hence the last bits, vary from run to run exactly as in the reference).  A workgroup owns kGbChunk points of ONE level.
+// Coarse levels are where the reference's kernel serialises -- a million points over a 17 x 17 table is ~14 000 atomic adds per
+// row -- so a level whose table fits the workgroup's 64 KiB of LDS is accumulated there first (ds_add_f32) and flushed with one
+// global atomic per touched entry; larger (fine, sparsely hit) levels scatter straight to memory.
+constexpr uint32_t kGbChunk = 4096;
+constexpr uint32_t kGbLdsFloats = 16384;
+
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kBlock) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                           const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
                                                           gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
-    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float tab[kGbLdsFloats];
     const uint32_t level = blockIdx.y;
-    if (b >= B) return;
-    float x[D];
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
-        if (x[d] < 0 || x[d] > 1) return;
-    }
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const bool in_lds = hashmap_size * C <= kGbLdsFloats;   // workgroup-uniform
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += kBlock) tab[i] = 0.0f;
+        __syncthreads();
+    }
     const float scale = lv.scale[level];
     const uint32_t resolution = lv.resolution[level];
-    float g[C];
-#pragma unroll
-    for (uint32_t c = 0; c < C; c++) g[c] = grad[((size_t)level * B + b) * C + c];
-    float pos[D];
-    uint32_t pos_grid[D];
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        pos[d] = __builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
-        const float fl = floorf(pos[d]);
-        pos_grid[d] = (uint32_t)fl;
-        pos[d] -= fl;
-        if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
-    }
     float* table = grad_grid + (size_t)off * C;
-#pragma unroll
-    for (uint32_t corner = 0; corner < (1u << D); corner++) {
-        float w = 1.0f;
-        uint32_t pl[D];
+    const uint32_t b0 = blockIdx.x * kGbChunk, b1 = b0 + kGbChunk < B ? b0 + kGbChunk : B;
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kBlock) {
+        float x[D];
+        bool oob = false;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
-            if ((corner & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
-            else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+            x[d] = inputs[(size_t)b * D + d];
+            oob |= (x[d] < 0 || x[d] > 1);
         }
-        const uint32_t row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+        if (oob) continue;
+        float g[C];
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
+        for (uint32_t c = 0; c < C; c++) g[c] = grad[((size_t)level * B + b) * C + c];
+        float pos[D];
+        uint32_t pos_grid[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            pos[d] = __builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+            const float fl = floorf(pos[d]);
+            pos_grid[d] = (uint32_t)fl;
+            pos[d] -= fl;
+            if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+        }
+#pragma unroll
+        for (uint32_t corner = 0; corner < (1u << D); corner++) {
+            float w = 1.0f;
+            uint32_t pl[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((corner & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
+                else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
+            }
+            const uint32_t row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+            if (in_lds) {
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) atomicAdd(&tab[row * C + c], w * g[c]);
+            } else {
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += kBlock) {
+            const float v = tab[i];
+            if (v != 0.0f) unsafeAtomicAdd(table + i, v);
+        }
     }
 }
 
@@ -211,7 +238,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __r
 template <uint32_t D>
 int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, const int* offsets, float* grad_grid, uint32_t B,
                         const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
-    const dim3 grid(gf_div_up(B, (uint32_t)kBlock), lv.L), block(kBlock);
+    const dim3 grid(gf_div_up(B, kGbChunk), lv.L), block(kBlock);
     switch (C) {
         case 1: hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
         case 2: hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;

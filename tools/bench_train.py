@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Training-step rate of the RAD-NeRF head on one MI355X (secondary measurement).
+
+A step = what RADNeRFTask._training_step does around the model (tasks/radnerfs/radnerf.py:185-216): every 16 steps
+`update_extra_state`, then `render` in training mode on n_rays = 65536 rays of one frame (base.yaml:55), MSE + regularisers,
+backward, Adam.  The only number the reference publishes for this path is "~6 h for the head on an RTX 3090 Ti"
+(docs/train_models/train_models.md:91) for max_updates = 250 000 (base.yaml:64), i.e. ~11.6 steps/s.
+Synthetic fixture (no dataset offline): the rate, not the loss, is what is measured."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--n-rays", type=int, default=65536)
+    args = ap.parse_args()
+    import torch
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd import utils
+    from geneface_amd.radnerf import RADNeRF
+
+    dev = torch.device("cuda", 0)
+    hp = HP.may_hparams(False)
+    sd = S.make_state_dict(hp, False)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    seq = S.make_sequence(8, 512, 512, hp)
+    poses = torch.from_numpy(seq["poses"]).to(dev)
+    cond = torch.from_numpy(seq["cond_wins"]).to(dev)
+    model.conds = cond[:, cond.shape[1] // 2]                      # [T, cond_win, C] for update_extra_state's random window
+    bg = torch.from_numpy(seq["bg_img"]).to(dev).view(1, -1, 3)
+    bgc = utils.get_bg_coords(512, 512, dev)
+    target = torch.rand(1, 512 * 512, 3, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def step(i):
+        if i % hp["update_extra_interval"] == 0:
+            model.update_extra_state()
+        f = i % len(poses)
+        rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], 512, 512, -1)
+        sel = torch.randint(0, 512 * 512, (args.n_rays,), device=dev, generator=g)
+        out = model.render(rays["rays_o"][:, sel], rays["rays_d"][:, sel], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel],
+                           perturb=True, force_all_rays=False, **hp)
+        loss = ((out["rgb_map"] - target[:, sel]) ** 2).mean() + 1e-3 * out["ambient"].mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rate = args.steps / dt
+    print(json.dumps({"metric": "RAD-NeRF head training steps/s (n_rays 65536, fp32, Adam, grid update every 16 steps)", "value": rate,
+                      "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
+                      "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
+                      "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()
