@@ -2,8 +2,8 @@
 
 Compiles oracle/radnerf_kernels.c with gcc into oracle/_build/liboracle_radnerf.so.
 The output directory is git-ignored but travels to the GPU box with the snapshot.
-There is no oracle/_ref: the reference's kernels are CUDA sources (no nvcc here), so the
-real reference cannot be compiled in this image ("Oracle").
+The real reference kernels are built separately by oracle/refbuild/build_ref.py into oracle/_ref/
+(hipcc reads the CUDA sources as they are); they need a GPU to run, this file's output does not.
 """
 import os
 import subprocess

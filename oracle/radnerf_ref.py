@@ -21,15 +21,30 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+import contextlib
+
 from . import kernels as K
 
 RM, GE, SH, FQ = K.raymarching_face, K.gridencoder, K.shencoder, K.freqencoder
 
 
+@contextlib.contextmanager
+def kernel_backend(modules):
+    """Runs the restatement over another set of the four extension modules -- oracle/ref_kernels.py's build of the reference's
+    own kernels for gfx950 (then the tensors live on the GPU) -- instead of the C restatement.  Same positional signatures."""
+    global RM, GE, SH, FQ
+    saved = (RM, GE, SH, FQ)
+    RM, GE, SH, FQ = modules
+    try:
+        yield
+    finally:
+        RM, GE, SH, FQ = saved
+
+
 # ----------------------------------------------------------------------------- op wrappers
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
     N = rays_o.shape[0]
-    nears, fars = torch.empty(N), torch.empty(N)
+    nears, fars = torch.empty(N, device=rays_o.device), torch.empty(N, device=rays_o.device)
     RM.near_far_from_aabb(rays_o.contiguous(), rays_d.contiguous(), aabb.contiguous(), N, min_near, nears, fars)
     return nears, fars
 
@@ -38,8 +53,9 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfi
     M = n_alive * n_step
     if align > 0:
         M += align - (M % align)
-    xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
-    noises = torch.zeros(n_alive)  # perturb=False at inference
+    dev = rays_o.device
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    noises = torch.zeros(n_alive, device=dev)  # perturb=False at inference
     RM.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bitfield, nears, fars,
                   xyzs, dirs, deltas, noises)
     return xyzs, dirs, deltas
@@ -53,8 +69,8 @@ class _GridEncode(torch.autograd.Function):
         x01, embeddings = x01.detach().contiguous(), embeddings.detach().contiguous()
         B, D = x01.shape
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
-        out = torch.empty(L, B, C)
-        dy_dx = torch.empty(B, L * D * C) if need_dx else None
+        out = torch.empty(L, B, C, device=x01.device)
+        dy_dx = torch.empty(B, L * D * C, device=x01.device) if need_dx else None
         GE.grid_encode_forward(x01, embeddings, offsets, out, B, D, C, L, S, base_resolution, dy_dx, gridtype, align_corners, interp)
         ctx.save_for_backward(x01, embeddings, offsets, dy_dx)
         ctx.cfg = (B, D, C, L, S, base_resolution, gridtype, align_corners, interp)
@@ -66,7 +82,7 @@ class _GridEncode(torch.autograd.Function):
         B, D, C, L, S, H, gridtype, align_corners, interp = ctx.cfg
         g = grad.contiguous().view(B, L, C).permute(1, 0, 2).contiguous()
         g_emb = torch.zeros_like(embeddings)
-        g_in = torch.zeros(B, D) if dy_dx is not None else None
+        g_in = torch.zeros(B, D, device=grad.device) if dy_dx is not None else None
         GE.grid_encode_backward(g, x01, embeddings, offsets, g_emb, B, D, C, L, S, H, dy_dx, g_in, gridtype, align_corners, interp)
         return g_in, g_emb, None, None, None, None, None, None, None
 
@@ -96,7 +112,7 @@ class _FreqEncode(torch.autograd.Function):
         x = x.detach().contiguous()
         B, D = x.shape
         C = D + 2 * D * degree
-        out = torch.empty(B, C)
+        out = torch.empty(B, C, device=x.device)
         FQ.freq_encode_forward(x, B, D, degree, C, out)
         ctx.save_for_backward(out)
         ctx.cfg = (B, D, degree, C)
@@ -105,7 +121,7 @@ class _FreqEncode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         B, D, degree, C = ctx.cfg
-        g_in = torch.zeros(B, D)
+        g_in = torch.zeros(B, D, device=grad.device)
         FQ.freq_encode_backward(grad.contiguous(), ctx.saved_tensors[0], B, D, degree, C, g_in)
         return g_in, None
 
@@ -135,7 +151,7 @@ class _CompositeTrain(torch.autograd.Function):
 
 def sh_encode(d, degree=4):
     d = d.contiguous()
-    out = torch.empty(d.shape[0], degree * degree)
+    out = torch.empty(d.shape[0], degree * degree, device=d.device)
     SH.sh_encode_forward(d, out, d.shape[0], 3, degree, None)
     return out
 
@@ -226,7 +242,7 @@ def _count_composited(n_alive, n_step, T_thresh, ws0, sigmas, deltas):
     schedule needs; `n_valid` (everything marched) is what the reference's schedule evaluates."""
     M = n_alive * n_step
     s, dt = sigmas[:M].view(n_alive, n_step), deltas[:M, 0].view(n_alive, n_step)
-    ws, live, cnt = ws0.clone(), torch.ones(n_alive, dtype=torch.bool), 0
+    ws, live, cnt = ws0.clone(), torch.ones(n_alive, dtype=torch.bool, device=ws0.device), 0
     for k in range(n_step):
         valid = live & (dt[:, k] != 0)
         T = 1 - ws
@@ -241,8 +257,9 @@ def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh,
     cascade = 1 + math.ceil(math.log2(hp["bound"]))
     nears, fars = near_far_from_aabb(rays_o, rays_d, sd["aabb_infer"], hp["min_near"])
     ind_code = sd["individual_embeddings"][0] if hp["individual_embedding_dim"] > 0 else None
-    weights_sum, depth, image = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
-    rays_alive = torch.arange(N, dtype=torch.int32)
+    dev = rays_o.device
+    weights_sum, depth, image = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+    rays_alive = torch.arange(N, dtype=torch.int32, device=dev)
     rays_t = nears.clone()
     step = 0
     while step < max_steps:
@@ -282,7 +299,7 @@ def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_
             G = hp["grid_size"]
             occ = F.grid_sample(sd["density_grid_torso"].view(1, 1, G, G), bg_coords.view(1, -1, 1, 2), align_corners=True).view(-1)
             mask = occ > min(hp["density_thresh_torso"], 0)  # mean_density_torso is 0 after a fresh load
-            torso_alpha, torso_color = torch.zeros(N, 1), torch.zeros(N, 3)
+            torso_alpha, torso_color = torch.zeros(N, 1, device=rays_o.device), torch.zeros(N, 3, device=rays_o.device)
             if mask.any():
                 code = sd["torso_individual_codes"][0] if hp["torso_individual_embedding_dim"] > 0 else None
                 a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code)

@@ -61,3 +61,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_reference_kernel_build_exports_the_reference_api():
+    """oracle/_ref (the reference's CUDA sources built for gfx950, GPU-side checker): when present, each module loads on CPU and
+    exports exactly the functions the reference's pybind glue defines; the compat modules of the product carry the same names."""
+    import pytest
+    from oracle import ref_kernels
+    if not ref_kernels.available("fast"):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    import geneface_amd.compat._freqencoder as cf
+    import geneface_amd.compat._gridencoder as cg
+    import geneface_amd.compat._raymarching_face as cr
+    import geneface_amd.compat._shencoder as cs
+    expect = {0: ["packbits", "near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "morton3D_dilation", "march_rays_train",
+                  "march_rays_train_backward", "composite_rays_train_forward", "composite_rays_train_backward", "march_rays", "composite_rays"],
+              1: ["grid_encode_forward", "grid_encode_backward", "grad_total_variation"],
+              2: ["sh_encode_forward", "sh_encode_backward"], 3: ["freq_encode_forward", "freq_encode_backward"]}
+    for contract in ("fast", "off"):
+        if not ref_kernels.available(contract):
+            continue
+        mods = ref_kernels.load(contract)
+        for i, compat in enumerate((cr, cg, cs, cf)):
+            for name in expect[i]:
+                assert callable(getattr(mods[i], name)), (contract, i, name)
+                assert callable(getattr(compat, name)), (i, name)
