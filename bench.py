@@ -63,8 +63,30 @@ def cpu_baseline(hp, sd, seq, n_frames, torso=True):
     for i in range(1, 1 + n_frames):
         one(i)
     dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_frames} {'head+torso' if torso else 'head-only'} {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
+    out = {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_frames} {'head+torso' if torso else 'head-only'} {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
+    out["legacy_nerf"] = legacy_nerf_baseline(seq)
+    return out
+
+
+def legacy_nerf_baseline(seq, rays=4096):
+    """Baseline B2: the reference's only pure-PyTorch renderer, the vanilla Lm3dNeRF it replaced
+    (64 + 128 samples per ray, two 8x256 MLPs, chunk 2048), restated in oracle/legacy_nerf_ref.py, random weights; a bounded
+    sample of rays of one 512x512 frame, extrapolated to the frame.  Context only: a different model from the hot path."""
+    import torch
+    from oracle import legacy_nerf_ref as LN
+    H, W = seq["H"], seq["W"]
+    fx, _, cx, cy = (float(v) for v in seq["intrinsics"])
+    w = LN.make_weights(0)
+    c2w = torch.tensor([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 0.6]], dtype=torch.float32)
+    bg, cond = torch.from_numpy(seq["bg_img"]).view(H, W, 3), torch.zeros(64)
+    LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)            # warm-up
+    t0 = time.perf_counter()
+    LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=rays)
+    dt = time.perf_counter() - t0
+    s_per_frame = dt / rays * H * W
+    return {"value": 1.0 / s_per_frame, "unit": "frames/s", "s_per_frame": s_per_frame, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{rays} of {H * W} rays of one frame (2 chunks of 2048), extrapolated; published anchor ~28.8 s/frame on an RTX 2080 Ti"}
 
 
 def main():

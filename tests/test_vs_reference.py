@@ -135,3 +135,32 @@ def test_landmark_postprocess_matches_reference_entry_point():
     for i, s in enumerate(samples):
         assert np.allclose(s["cond"].numpy()[0], norm[i], atol=1e-6)
         assert np.allclose(s["cond_wins"].numpy(), wins[i], atol=1e-6)
+
+
+def test_legacy_nerf_baseline_matches_reference_pure_torch_path():
+    """Baseline B2: oracle/legacy_nerf_ref.py against the reference's own Lm3dNeRF + render_dynamic_face on identical weights and
+    identical random draws (both consume torch's global generator in the same order)."""
+    from oracle import legacy_nerf_ref as LN
+    refshim.install()
+    with refshim.cpu_mode():
+        from modules.nerfs.commons.volume_rendering import render_dynamic_face
+        from modules.nerfs.lm3d_nerf.lm3d_nerf import Lm3dNeRF
+        torch.manual_seed(3)
+        model = Lm3dNeRF({"cond_dim": 64, "hidden_size": 256, "use_window_cond": True, "cond_win_size": 1, "smo_win_size": 5, "with_att": True}).eval()
+        w = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("model_")}
+        mine = LN.make_weights(0)
+        assert set(w) == set(mine) and all(w[k].shape == mine[k].shape for k in w)       # same parameter names and shapes
+        H = W = 20
+        focal, cx, cy = 60.0, 10.0, 10.0
+        c2w = torch.tensor([[1, 0, 0, 0.02], [0, 1, 0, -0.01], [0, 0, 1, 0.6]], dtype=torch.float32)
+        g = torch.Generator().manual_seed(8)
+        bg, cond = torch.rand(H, W, 3, generator=g), torch.randn(64, generator=g)
+        rays_o, rays_d = LN.get_rays(H, W, focal, c2w, cx, cy)
+        with torch.no_grad():
+            torch.manual_seed(5)
+            ref = render_dynamic_face(H, W, focal, cx, cy, chunk=2048, rays_o=rays_o, rays_d=rays_d, bc_rgb=bg, cond=cond, near=0.3, far=0.9,
+                                      network_fn=model, N_samples=64, N_importance=128)[0]
+            torch.manual_seed(5)
+            out = LN.render(w, H, W, focal, cx, cy, c2w, bg, cond)
+    assert out.shape == (H * W, 3)
+    assert (out - ref.reshape(-1, 3)).abs().max().item() < 1e-6
