@@ -51,6 +51,41 @@ class AudioAttNet(nn.Module):
         return torch.sum(y * x, dim=0)
 
 
+_TALL = 1 << 16      # rows from which the weight gradient is worth splitting
+
+
+class _linear_tall(torch.autograd.Function):
+    """y = x W^T for a tall x [B, I] (B ~ 10^6 samples of a training batch).  Forward and dX are ordinary GEMMs.  dW = dY^T x reduces
+    over B into an [O, I] <= 129 x 148 output: as one GEMM that is a few dozen output tiles, i.e. a few dozen of 256 CUs busy for 2 ms
+    per layer (rocprofv3: 40 % of a training step).  Split the reduction instead: S batched [O, B/S] x [B/S, I] products fill the
+    chip, followed by a sum over S (S * O * I floats)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        if torch.is_autocast_enabled():                       # what nn.Linear does under autocast: 16-bit operands, fp32 accumulate
+            dt = torch.get_autocast_dtype("cuda")
+            x, w = x.to(dt), w.to(dt)
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            B, O, I = x.shape[0], g.shape[1], x.shape[1]
+            S = max(1, B // 4096)
+            rows = B // S
+            main = S * rows
+            x = x.contiguous()
+            gw = torch.bmm(g[:main].view(S, rows, O).transpose(1, 2), x[:main].view(S, rows, I)).sum(0, dtype=torch.float32)
+            if main < B:
+                gw = gw + (g[main:].t() @ x[main:]).float()
+        return gx, gw
+
+
 class MLP(nn.Module):
     def __init__(self, dim_in, dim_out, dim_hidden, num_layers):
         super().__init__()
@@ -61,7 +96,10 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for l, layer in enumerate(self.net):
-            x = layer(x)
+            if x.dim() == 2 and x.shape[0] >= _TALL and torch.is_grad_enabled() and (x.requires_grad or layer.weight.requires_grad):
+                x = _linear_tall.apply(x, layer.weight)
+            else:
+                x = layer(x)
             if l != self.num_layers - 1:
                 x = F.relu(x, inplace=True)
         return x

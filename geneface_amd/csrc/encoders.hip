@@ -147,32 +147,42 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
     grad_inputs[t] = result;
 }
 
-// gridencoder.cu:248-339: every corner's share of the output gradient is scatter-added into the table (f32 atomics: the accumulation
-// order, hence the last bits, vary from run to run exactly as in the reference).  A workgroup owns kGbChunk points of ONE level.
-// Coarse levels are where the reference's kernel serialises -- a million points over a 17 x 17 table is ~14 000 atomic adds per
-// row -- so a level whose table fits the workgroup's 64 KiB of LDS is accumulated there first (ds_add_f32) and flushed with one
-// global atomic per touched entry; larger (fine, sparsely hit) levels scatter straight to memory.
-constexpr uint32_t kGbChunk = 4096;
-constexpr uint32_t kGbLdsFloats = 16384;
+// gridencoder.cu:248-339: every corner's share of the output gradient is scatter-added into the table (f32 adds: the accumulation
+// order, hence the last bits, vary from run to run exactly as in the reference).
+// The reference issues one global atomic per (point, level, corner, channel): 268 M for a training batch of 1 M points, and this
+// chip retires scattered f32 atomics at ~21 G/s however they are spread (tools/atomic_probe.hip), on top of the serialisation on the
+// coarse levels (a million points over a 17^3 table).  Here the TABLE is partitioned instead of the points: a workgroup owns
+// kGbLdsFloats / C consecutive rows of one level, keeps them in 128 KiB of LDS (one workgroup per CU, 1024 lanes), streams a slice
+// of the points, evaluates every corner and accumulates the ones that land in its rows with ds_add_f32; at the end each touched
+// entry costs ONE global atomic.  Points are re-read once per partition (<= kGbMaxParts, out of L2), index arithmetic is repeated
+// -- both cheap next to the atomics they replace: <= slices x table entries instead of points x corners x channels.
+// A level too large for kGbMaxParts partitions (log2_hashmap_size > 17 at C = 2) falls back to direct global atomics.
+constexpr uint32_t kGbThreads = 1024;
+constexpr uint32_t kGbLdsFloats = 32768;
+constexpr uint32_t kGbMaxParts = 8;
 
 template <uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(kBlock) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
-                                                          const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
-                                                          gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+__global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                              const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
+                                                              gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
     __shared__ float tab[kGbLdsFloats];
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = blockIdx.z, part = blockIdx.y;
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-    const bool in_lds = hashmap_size * C <= kGbLdsFloats;   // workgroup-uniform
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += kBlock) tab[i] = 0.0f;
-        __syncthreads();
-    }
+    constexpr uint32_t rows_per_part = kGbLdsFloats / C;
+    const uint32_t nparts = (hashmap_size + rows_per_part - 1) / rows_per_part;
+    const bool direct = nparts > kGbMaxParts;                      // workgroup-uniform
+    if (direct ? part != 0 : part >= nparts) return;
+    const uint32_t row0 = direct ? 0u : part * rows_per_part;
+    const uint32_t nrows = direct ? 0u : (hashmap_size - row0 < rows_per_part ? hashmap_size - row0 : rows_per_part);
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) tab[i] = 0.0f;
+    __syncthreads();
     const float scale = lv.scale[level];
     const uint32_t resolution = lv.resolution[level];
     float* table = grad_grid + (size_t)off * C;
-    const uint32_t b0 = blockIdx.x * kGbChunk, b1 = b0 + kGbChunk < B ? b0 + kGbChunk : B;
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kBlock) {
+    const uint32_t per = (B + gridDim.x - 1) / gridDim.x;
+    const uint32_t b0 = blockIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kGbThreads) {
         float x[D];
         bool oob = false;
 #pragma unroll
@@ -204,21 +214,22 @@ __global__ void __launch_bounds__(kBlock) k_grid_backward(const float* __restric
                 else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
             }
             const uint32_t row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-            if (in_lds) {
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) atomicAdd(&tab[row * C + c], w * g[c]);
-            } else {
+            if (direct) {
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
+            } else {
+                const uint32_t r = row - row0;                     // rows below row0 wrap to huge values
+                if (r < nrows) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) atomicAdd(&tab[r * C + c], w * g[c]);
+                }
             }
         }
     }
-    if (in_lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += kBlock) {
-            const float v = tab[i];
-            if (v != 0.0f) unsafeAtomicAdd(table + i, v);
-        }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) {
+        const float v = tab[i];
+        if (v != 0.0f) unsafeAtomicAdd(table + (size_t)row0 * C + i, v);
     }
 }
 
@@ -238,7 +249,10 @@ __global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __r
 template <uint32_t D>
 int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, const int* offsets, float* grad_grid, uint32_t B,
                         const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
-    const dim3 grid(gf_div_up(B, kGbChunk), lv.L), block(kBlock);
+    // slices of the points: enough workgroups to fill the chip twice over, few enough that the per-slice flush stays small
+    uint32_t slices = B / 131072u;
+    slices = slices < 1u ? 1u : (slices > 16u ? 16u : slices);
+    const dim3 grid(slices, kGbMaxParts, lv.L), block(kGbThreads);
     switch (C) {
         case 1: hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;
         case 2: hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp); break;

@@ -9,6 +9,7 @@ class _freq_encode(torch.autograd.Function):
     """freq.py:15-53: the backward reads sin / cos back from the forward outputs."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, inputs, degree, output_dim):
         inputs = inputs.float().contiguous()
         B, input_dim = inputs.shape
@@ -19,6 +20,7 @@ class _freq_encode(torch.autograd.Function):
         return outputs
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, outputs = ctx.saved_tensors
         B, input_dim, degree, output_dim = ctx.dims

@@ -41,6 +41,7 @@ class _grid_encode(torch.autograd.Function):
     is scattered with f32 atomics, the input gradient goes through dy_dx when the inputs require one."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # the reference keeps fp16 tables under autocast (grid.py:43); fp32 here
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
                 interpolation=0):
         inputs = inputs.float().contiguous()
@@ -59,6 +60,7 @@ class _grid_encode(torch.autograd.Function):
         return outputs
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims

@@ -9,6 +9,7 @@ class _sh_encode(torch.autograd.Function):
     """sphere_harmonics.py:14-58: forward (+ dy_dx when the directions need a gradient), backward through dy_dx."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, inputs, degree, calc_grad_inputs=False):
         inputs = inputs.float().contiguous()
         B, input_dim = inputs.shape
@@ -20,6 +21,7 @@ class _sh_encode(torch.autograd.Function):
         return outputs
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, dy_dx = ctx.saved_tensors
         if dy_dx is None:

@@ -90,6 +90,7 @@ def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, we
 # ----------------------------------------------------------------------------------------------------------------------
 class _march_rays_train(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
                 align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
         """-> xyzs [M,3], dirs [M,3], deltas [M,2] (dt, t), rays i32 [N,3] (ray, point offset, point count); see raymarching.py:189-208.
@@ -123,6 +124,7 @@ class _march_rays_train(torch.autograd.Function):
         return xyzs, dirs, deltas, rays
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_xyzs, grad_dirs, grad_deltas, grad_rays):
         rays, deltas = ctx.saved_tensors
         N, M = rays.shape[0], grad_xyzs.shape[0]
@@ -138,6 +140,7 @@ march_rays_train = _march_rays_train.apply
 
 class _composite_rays_train(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, sigmas, rgbs, ambient, deltas, rays, T_thresh=1e-4):
         """-> weights_sum [N], ambient_sum [N], depth [N], image [N,3] (raymarching.py:289-302)."""
         sigmas, rgbs, ambient = _f32(sigmas).contiguous(), _f32(rgbs).contiguous(), _f32(ambient).contiguous()
@@ -154,6 +157,7 @@ class _composite_rays_train(torch.autograd.Function):
         return weights_sum, ambient_sum, depth, image
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_weights_sum, grad_ambient_sum, grad_depth, grad_image):
         # grad_depth is not propagated, as in the reference (raymarching.py:322)
         sigmas, rgbs, ambient, deltas, rays, weights_sum, ambient_sum, depth, image = ctx.saved_tensors

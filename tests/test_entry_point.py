@@ -131,3 +131,22 @@ def test_png_writer_roundtrip(tmp_path):
         np.testing.assert_array_equal(decode_rgb8(open(tmp_path / "imgs" / f"{i:05d}.png", "rb").read()), f)
     with pytest.raises(ValueError):
         encode_rgb8(np.zeros((4, 4), dtype=np.uint8))
+
+
+def test_orbit_camera_pose_and_intrinsics():
+    """radnerf_gui.py:21-82: pose = rot @ translate(-radius) - centre; intrinsics from fovy; update_pose inverts pose."""
+    from geneface_amd.gui import OrbitCamera
+    cam = OrbitCamera(512, 512, r=3.35, fovy=21.24)
+    p = cam.pose
+    assert np.allclose(p[:3, :3], [[0, -1, 0], [0, 0, -1], [1, 0, 0]]) and np.allclose(p[:3, 3], [0, 3.35, 0], atol=1e-6)
+    f = cam.intrinsics
+    assert abs(f[0] - 256 / np.tan(np.deg2rad(21.24) / 2)) < 1e-6 and f[2] == 256 and f[3] == 256
+    cam.orbit(300, -120)
+    cam.scale(2)
+    q = cam.pose
+    assert abs(np.linalg.norm(q[:3, 3]) - 3.35 * 1.1 ** -2) < 1e-5 and np.allclose(q[:3, :3] @ q[:3, :3].T, np.eye(3), atol=1e-6)
+    other = OrbitCamera(512, 512)
+    other.update_pose(q)
+    assert np.allclose(other.pose, q, atol=1e-5)
+    other.update_intrinsics([1365.3, 1365.3, 256, 256])
+    assert abs(other.fovy - 21.24) < 0.01 and other.W == 512

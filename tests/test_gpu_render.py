@@ -358,3 +358,36 @@ def test_edge_thresholds_and_step_scale():
         out = m.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
                        bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, T_thresh=0.05, **hp)
         check(out, ref, True)
+
+
+def test_viewer_path_downscale_and_accumulation_vs_oracle():
+    """a free orbit-camera view rendered at half resolution and resized (tasks/radnerfs/radnerf.py:333-380), then the
+    viewer's spp accumulation (radnerf_gui.py:222-229).  Oracle: the same rays through radnerf_ref.render + the same resize."""
+    import torch.nn.functional as F
+    from geneface_amd import gui
+    hp, sd, model = build(True, "fused")
+    seq = sequence(4, 128, 128)
+    cam = gui.OrbitCamera(128, 128, r=3.35, fovy=21.24)
+    cam.update_intrinsics(seq["intrinsics"])
+    cam.orbit(150, 60)
+    cond = torch.from_numpy(seq["cond_wins"][1])
+    bg = torch.from_numpy(seq["bg_img"]).view(1, -1, 3)
+    out = gui.test_gui_with_editable_data(model, hp, cam.pose, cam.intrinsics, 128, 128, cond, 0, bg, 1, 0.5, DEV)
+    assert out["image"].shape == (128, 128, 3) and out["depth"].shape == (128, 128)
+    pose = torch.from_numpy(cam.pose).unsqueeze(0)
+    ro, rd = R.get_rays(pose, cam.intrinsics * 0.5, 64, 64)
+    bg64 = F.interpolate(bg.view(1, 128, 128, 3).permute(0, 3, 1, 2), size=(64, 64), mode="bilinear").permute(0, 2, 3, 1).reshape(1, -1, 3)
+    ref = R.render(sd, hp, ro, rd, cond, R.get_bg_coords(64, 64), R.convert_poses(pose), bg64, True)
+    img = F.interpolate(ref["rgb_map"].view(1, 64, 64, 3).permute(0, 3, 1, 2), size=(128, 128), mode="bilinear").permute(0, 2, 3, 1)[0]
+    assert (torch.from_numpy(out["image"]) - img).abs().max().item() < RGB_ATOL
+    dep = F.interpolate(ref["depth_map"].view(1, 1, 64, 64), size=(128, 128), mode="nearest")[0, 0]
+    assert (torch.from_numpy(out["depth"]) - dep).abs().max().item() < 2e-3
+    v = gui.Viewer(model, dict(hp, gui_max_spp=3), 128, 128, cond_features=torch.from_numpy(seq["cond_wins"][:, 2]), bg_color=bg, device=DEV)
+    v.cam = cam
+    first = v.test_step().copy()
+    for _ in range(4):
+        buf = v.test_step()
+    assert v.spp == 3 and np.abs(buf - first).max() < 1e-6            # deterministic renderer: the running mean is the frame
+    cam.orbit(40, 0)
+    v.need_update = True
+    assert np.abs(v.test_step() - first).max() > 1e-3 and v.spp == 1

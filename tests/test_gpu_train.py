@@ -211,3 +211,36 @@ def test_render_training_branch_gradients_vs_oracle(torso):
         ev = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
                           bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
     assert "weights_sum" not in ev and ev["rgb_map"].shape == out["rgb_map"].shape
+
+
+def test_training_branch_under_fp16_autocast():
+    """The May config trains with amp: true (lm3d_radnerf.yaml:5; utils/commons/trainer.py wraps the step in autocast).  The ops keep
+    the reference's custom_fwd(cast_inputs=float32) semantics: the nn.Linear layers run in fp16, every HIP op in fp32, one GradScaler
+    step leaves finite gradients and the image stays within fp16 noise of the fp32 run."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    ref = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+        loss = _loss(out, target)
+    assert out["rgb_map"].dtype == torch.float32                                  # compositing is forced to fp32
+    assert (out["rgb_map"].detach() - ref["rgb_map"].detach()).abs().max() < 3e-2
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    n = 0
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+            n += 1
+    assert n >= 20 and scaler.get_scale() >= 1024.0                               # no inf/nan step was skipped

@@ -20,6 +20,14 @@ for s in $STEPS; do
                GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip$lib.so timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/ab_$V.txt
              done
            done ;;
+    abm:*) # several experiment libraries against the product one, interleaved: abm:<v1>,<v2>,...
+           VS=${s#abm:}
+           for rep in 1 2 3; do
+             for lib in "" $(echo $VS | tr ',' ' '); do
+               L=$REPO/geneface_amd/csrc/libgeneface_hip${lib:+_$lib}.so
+               GF_HIP_LIB=$L timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/abm.txt
+             done
+           done ;;
     trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     tracev:*) V=${s#tracev:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 300 python tools/trace_head.py > $OUT/trace_$V.txt 2>&1; grep -E "phase ms|lifetime|round =" $OUT/trace_$V.txt ;;
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
