@@ -27,6 +27,7 @@ BYTES_PER_HEAD_SAMPLE = 1_536    # fp32 table gathers: 16 levels * (8 + 4 corner
 BYTES_PER_TORSO_PIXEL = 512
 BYTES_PER_RAY = 56
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense MFMA peak for f32 inputs
+PEAK_F16_MFMA_TFLOPS = 2516.6    # dense f16 / bf16 peak (the --fast line; that kernel is VALU / gather bound, not MFMA bound)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--no-overlap", action="store_true", help="one stream: frames do not overlap (per-kernel profiling runs)")
+    ap.add_argument("--fast", action="store_true", help="secondary line: the 'fast' parity tier of BASELINE.md section 4 (f16 MFMA operands and "
+                                                        "activations, fp32 accumulate); the default line is fp32")
     ap.add_argument("--head-only", action="store_true", help="BASELINE.json configs[1]: May lm3d_radnerf head-only (default: configs[2], head+torso)")
     return ap.parse_args()
 
@@ -132,6 +135,8 @@ def main():
     if rank == 0:
         model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
+    if args.fast:
+        model.render_precision = "fast"
     broadcast_model_(model, src=0)  # the only collective (RCCL): one flattened weight buffer
     pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl, overlap=not args.no_overlap)
 
@@ -156,13 +161,13 @@ def main():
 
         roofline = None
         if rank == 0:
-            roofline = measure_roofline(pipe, impl, Wm, min(args.profile_frames, K))
+            roofline = measure_roofline(pipe, impl, Wm, min(args.profile_frames, K), PEAK_F16_MFMA_TFLOPS if args.fast else PEAK_F32_MFMA_TFLOPS)
 
     if rank == 0:
         line = {
             "metric": "rendered 512x512 fps (head+torso)" if torso else "rendered 512x512 fps (head only)", "value": world * K / dt, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 operands / f32 accumulate (fast tier)" if args.fast else "f32", "data": "synthetic",
             "config": {"workload": (f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
                                     f"(BASELINE.json configs[2])" if torso else
                                     f"May lm3d_radnerf head-only {args.size}x{args.size}, {K} frames per GPU (BASELINE.json configs[1])")
@@ -198,12 +203,12 @@ def pmc_traffic():
     return None, None
 
 
-def measure_roofline(pipe, impl, first, n_frames):
+def measure_roofline(pipe, impl, first, n_frames, peak=None):
     """Dominant-kernel roofline from live HIP-event timing of that kernel's launches (outside the fps region)."""
     import torch
     if impl == "fused":
         from geneface_amd.fused import profile_frames
-        r = profile_frames(pipe, first, n_frames, FLOP_PER_HEAD_SAMPLE, PEAK_F32_MFMA_TFLOPS)
+        r = profile_frames(pipe, first, n_frames, FLOP_PER_HEAD_SAMPLE, peak or PEAK_F32_MFMA_TFLOPS)
         r["traffic"], r["traffic_source"] = pmc_traffic()
         r["algorithmic_bytes_per_launch"] = r["samples_per_frame"] * BYTES_PER_HEAD_SAMPLE / 2 if r.get("samples_per_frame") else None
         return r

@@ -74,6 +74,21 @@ constexpr uint32_t HS_COLBIAS = 768;   // [128]     W_color0[:, 144:148] @ indiv
 constexpr uint32_t HS_TOTAL = 896;
 constexpr uint32_t HP_TOTAL = HP_SMALL + HS_TOTAL;
 
+// ---------------- packed head weights, fast path (f16 MFMA operands, fp32 accumulate; BASELINE.md section 4 "fast") ----------------
+// Same ownership (wave w = output features [32w, 32w+32)), one v_mfma_f32_32x32x16_f16 per group and tile:
+//   stream16[w][g][lane][i]  (i = 0..7)  =  half( W[row0 + 32w + (lane&31)][col0 + 16u + 8*(lane>>5) + i] )
+// lane half h supplies input features 16u + 8h + 0..7: eight consecutive halves of a sample's f16 activation row (one ds_read_b128).
+constexpr uint32_t H16_AMB1 = 0;               // 2 groups (K = 32): ambient L1 over the 3-D grid features
+constexpr uint32_t H16_AMB2 = H16_AMB1 + 2;    // 8
+constexpr uint32_t H16_SIG1A = H16_AMB2 + 8;   // 2: density L1, 3-D grid columns (the features stay in their own LDS buffer)
+constexpr uint32_t H16_SIG1B = H16_SIG1A + 2;  // 2: density L1, 2-D grid columns
+constexpr uint32_t H16_SIG2 = H16_SIG1B + 2;   // 8
+constexpr uint32_t H16_SIG3 = H16_SIG2 + 8;    // 8
+constexpr uint32_t H16_COL1S = H16_SIG3 + 8;   // 1 (SH, K = 16)
+constexpr uint32_t H16_COL1G = H16_COL1S + 1;  // 8
+constexpr uint32_t H16_TOTAL = H16_COL1G + 8;  // 39 groups = 39 KiB per wave and round
+constexpr uint32_t HP16_HALVES = 4 * H16_TOTAL * 64 * 8;   // the VALU rows / constant bias stay fp32 (HP_SMALL of the fp32 pack)
+
 // ---------------- packed torso weights (floats) ----------------
 // MFMA streams as above with NOB out-blocks.  Frequency-encoded pixel coordinate enc(x) has 42 entries, padded to 48:
 // lane half h supplies enc index 24h + t (t < 24; indices >= 42 are zero on both sides).

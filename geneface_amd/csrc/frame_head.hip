@@ -75,6 +75,7 @@ struct HeadArgs {
     const float* pos_table; const int* pos_offsets;
     const float* amb_table; const int* amb_offsets;
     const float* head_pack; const float* amb_bias;
+    const uint16_t* head_pack16;   // fast path only
     const float* rays_o; const float* rays_d; const float* far_occ;
     float* rays_t; float* weights_sum; float* depth; float* image;
     const int* queue;   // phase 0: hit list, phase 1: survivor list
@@ -454,6 +455,227 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     GF_STAMP(36);
 }
 
+// ---------------------------------------------------------------------------------------------------- fast path (f16 operands)
+// Same decomposition as field_round, with the activations of the round kept as f16 in the first 34 KiB of H (rows of
+// 128 + 8 halves: 272 B, again 16 B apart in bank space), the weights streamed as f16 and one v_mfma_f32_32x32x16_f16 per group
+// (K = 16) and tile.  Accumulation, biases, the three VALU layers' sums, exp / tanh / sigmoid and the compositor stay fp32.
+// This is the arithmetic of the reference under torch autocast / model.half() (its training and viewer paths,
+// tasks/radnerfs/radnerf.py:359, inference/nerfs/radnerf_gui.py:604-605); BASELINE.md section 4 sets its parity bar (PSNR >= 40 dB).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+constexpr int kHS16 = 136;            // halves per activation row
+constexpr int kFS16 = 72;             // halves per row of the 3-D feature buffer (32 used; 144 B: rows 16 B apart in bank space)
+static_assert((kPass * kHS16 + kPass * kFS16) * 2 <= kPass * kHS * 4, "f16 activations + 3-D features fit the fp32 activation buffer");
+constexpr int kWAhead16 = 4;          // A-operand FIFO depth: one group is only NT x 32 cycles of MFMA
+struct WPipe16 { float4 q[kWAhead16]; };
+
+template <int G>
+__device__ __forceinline__ half8 wpipe16_take(const WPipe16& wp) {
+    return __builtin_bit_cast(half8, wp.q[G % kWAhead16]);
+}
+template <int G>
+__device__ __forceinline__ void wpipe16_refill(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16) {
+    if constexpr (G + kWAhead16 < (int)gf::H16_TOTAL) wp.q[G % kWAhead16] = load_group(Ws, G + kWAhead16, lane16);
+}
+
+// Hb = &H16[lane & 31][8 * (lane >> 5)]: tile t is 32 rows further, group u sixteen halves further.
+template <int NT, int G0, int U, int u, int RS>
+__device__ __forceinline__ void obw16_step(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4],
+                                           const half8 (&b)[NT]) {
+    if constexpr (u < U) {
+        half8 bn[NT];
+        if constexpr (u + 1 < U) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) bn[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS + 16 * (u + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const half8 a = wpipe16_take<G0 + u>(wp);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+        wpipe16_refill<G0 + u>(wp, Ws, lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        obw16_step<NT, G0, U, u + 1, RS>(wp, Ws, lane16, Hb, acc, bn);
+    }
+}
+template <int NT, int G0, int U, int RS = kHS16>
+__device__ __forceinline__ void obw16_mfma(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4]) {
+    half8 b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS);
+    __builtin_amdgcn_sched_barrier(0);
+    obw16_step<NT, G0, U, 0, RS>(wp, Ws, lane16, Hb, acc, b);
+}
+
+// Hw = &H16[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves (one ds_write_b64)
+template <int NT, bool RELU>
+__device__ __forceinline__ void obw16_store(_Float16* Hw, const floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+            const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<half4*>(Hw + t * 32 * kHS16 + 8 * q) = h;
+        }
+}
+
+template <int NOUT>
+__device__ __forceinline__ void rows_from_lds16(const _Float16* Hrow, const float* rows, int half, float (&res)[NOUT]) {
+    float sum[NOUT];
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) sum[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const half8 x = *reinterpret_cast<const half8*>(Hrow + 64 * half + 8 * i);
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) {
+            const float4 w0 = *reinterpret_cast<const float4*>(rows + c * 128 + 64 * half + 8 * i);
+            const float4 w1 = *reinterpret_cast<const float4*>(rows + c * 128 + 64 * half + 8 * i + 4);
+            sum[c] = __builtin_fmaf(w0.x, (float)x[0], sum[c]);
+            sum[c] = __builtin_fmaf(w0.y, (float)x[1], sum[c]);
+            sum[c] = __builtin_fmaf(w0.z, (float)x[2], sum[c]);
+            sum[c] = __builtin_fmaf(w0.w, (float)x[3], sum[c]);
+            sum[c] = __builtin_fmaf(w1.x, (float)x[4], sum[c]);
+            sum[c] = __builtin_fmaf(w1.y, (float)x[5], sum[c]);
+            sum[c] = __builtin_fmaf(w1.z, (float)x[6], sum[c]);
+            sum[c] = __builtin_fmaf(w1.w, (float)x[7], sum[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) res[c] = sum[c] + __shfl_xor(sum[c], 32);
+}
+
+__device__ __forceinline__ void store16h(_Float16* dst, const float (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[i] = (_Float16)f[8 * q + i];
+        reinterpret_cast<half8*>(dst)[q] = h;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t sI = (uint32_t)(wave * 32 + j);
+    const bool tile_on = wave < NT;
+    const bool valid = sI < Mv;
+    const uint32_t sC = valid ? sI : (uint32_t)(wave * 32);
+    const uint32_t raw = tile_on ? s.d2r[sC] : 0u;
+    _Float16* H16 = reinterpret_cast<_Float16*>(s.H);
+    _Float16* Hrow = H16 + sI * kHS16;
+    const _Float16* Hb = H16 + j * kHS16 + 8 * half;
+    _Float16* Hw = H16 + j * kHS16 + 32 * wave + 4 * half;
+    const char* Ws = reinterpret_cast<const char*>(a.head_pack16) + (size_t)wave * gf::H16_TOTAL * 1024;   // wave-uniform
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
+    // the 3-D grid features keep their own buffer (LDS is plentiful at f16), so density L1 runs as ONE K = 64 layer after the ambient
+    // net and a single accumulator set suffices
+    _Float16* F3 = H16 + kPass * kHS16;
+    _Float16* Frow = F3 + sI * kFS16;
+    const _Float16* Fb = F3 + j * kFS16 + 8 * half;
+    floatx16 A[4];
+    WPipe16 wp;
+#pragma unroll
+    for (int g = 0; g < kWAhead16; g++) wp.q[g] = load_group(Ws, g, lane16);
+
+    // ---- 3-D grid features -> F3[:, 0:32]
+    if (tile_on) {
+        const float b2 = 2 * a.bound;
+        const float x3[3] = {(s.sx[raw] + a.bound) / b2, (s.sy[raw] + a.bound) / b2, (s.sz[raw] + a.bound) / b2};
+        float pf[16];
+        gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
+        store16h(Frow + 16 * half, pf);
+    }
+    __syncthreads();
+    // ---- ambient L1 (cond_feat folded into the bias)
+    obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
+    obw16_mfma<NT, gf::H16_AMB1, 2, kFS16>(wp, Ws, lane16, Fb, A);
+    obw16_store<NT, true>(Hw, A);          // H is not read by this layer: no barrier before the write-back
+    __syncthreads();
+    // ---- ambient L2
+    obw_zero<NT>(A);
+    obw16_mfma<NT, gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    obw16_store<NT, true>(Hw, A);
+    __syncthreads();
+    // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 0:32]
+    if (tile_on) {
+        float ambient[2];
+        rows_from_lds16<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+        const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
+        float af[16];
+        gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
+        store16h(Hrow + 16 * half, af);
+    }
+    __syncthreads();
+    // ---- density L1: [3-D features (F3) | 2-D features (H)]
+    obw_zero<NT>(A);
+    obw16_mfma<NT, gf::H16_SIG1A, 2, kFS16>(wp, Ws, lane16, Fb, A);
+    obw16_mfma<NT, gf::H16_SIG1B, 2>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    obw16_store<NT, true>(Hw, A);
+    __syncthreads();
+    // ---- density L2
+    obw_zero<NT>(A);
+    obw16_mfma<NT, gf::H16_SIG2, 8>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    obw16_store<NT, true>(Hw, A);
+    __syncthreads();
+    // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
+    float sigma = 0.0f;
+    if (tile_on) {
+        float h0[1];
+        rows_from_lds16<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+        sigma = expf(h0[0]);
+    }
+    obw_zero<NT>(A);
+    obw16_mfma<NT, gf::H16_SIG3, 8>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    obw16_store<NT, false>(Hw, A);
+    __syncthreads();
+    // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
+    obw_bias<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
+    {
+        half8 shb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            uint32_t d = (uint32_t)(t * 32 + j);
+            d = d < Mv ? d : Mv - 1u;
+            const uint32_t slot = s.rrank[d];
+            float sh[16];
+            gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+#pragma unroll
+            for (int i = 0; i < 8; i++) shb[t][i] = (_Float16)(half ? sh[8 + i] : sh[i]);
+        }
+        const half8 w8 = wpipe16_take<gf::H16_COL1S>(wp);
+#pragma unroll
+        for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8, shb[t], A[t], 0, 0, 0);
+        wpipe16_refill<gf::H16_COL1S>(wp, Ws, lane16);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    obw16_mfma<NT, gf::H16_COL1G, 8>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    obw16_store<NT, true>(Hw, A);
+    __syncthreads();
+    // ---- colour L2 + sigmoid
+    if (tile_on) {
+        float c[3];
+        rows_from_lds16<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+        if (valid && half == 0) {
+            s.sx[raw] = sigma;
+            s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
+            s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
+            s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
+        }
+    }
+    __syncthreads();
+}
+
+template <bool FAST>
 __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
@@ -617,10 +839,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             __syncthreads();   // dense map published
             GF_STAMP(6);
             const uint32_t nt = (Mv + 31) / 32;
-            if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
-            else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);
-            else if (nt == 2) field_round<2>(a, s, Mv, wave, lane);
-            else field_round<1>(a, s, Mv, wave, lane);
+            if constexpr (FAST) {
+                if (nt == 4) field_round16<4>(a, s, Mv, wave, lane);
+                else if (nt == 3) field_round16<3>(a, s, Mv, wave, lane);
+                else if (nt == 2) field_round16<2>(a, s, Mv, wave, lane);
+                else field_round16<1>(a, s, Mv, wave, lane);
+            } else {
+                if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
+                else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);
+                else if (nt == 2) field_round<2>(a, s, Mv, wave, lane);
+                else field_round<1>(a, s, Mv, wave, lane);
+            }
         }
 
         // ------------------------------------------------------------------ C. composite, retire
@@ -791,6 +1020,8 @@ int check_frame(const gf_frame_t* f) {
     if (f->max_steps == 0 || f->cascade == 0 || f->grid_size == 0 || f->grid_size > 1024) return gf_set_error(GF_ERR_INVALID, "frame: bad marcher configuration");
     if (f->max_steps > gf::kMaxSteps) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u needs the op-by-op path", gf::kMaxSteps);
     if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "frame: gridtype/interp must be 0 or 1");
+    if (f->precision > 1) return gf_set_error(GF_ERR_INVALID, "frame: precision must be 0 (fp32) or 1 (fast)");
+    if (f->precision == 1 && !f->head_pack16) return gf_set_error(GF_ERR_INVALID, "frame: precision = 1 needs head_pack16");
     return GF_OK;
 }
 
@@ -836,11 +1067,14 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.spans = g_span_buf;
 #endif
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_phase), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+    const bool fast = f->precision == 1;
+    ha.head_pack16 = f->head_pack16;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fast]) {
+        const void* fn = fast ? reinterpret_cast<const void*>(k_head_phase<true>) : reinterpret_cast<const void*>(k_head_phase<false>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
             return gf_set_error(GF_ERR_HIP, "frame: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set = true;
+        attr_set[fast] = true;
     }
     // persistent grid: 2 workgroups per CU x 256 CUs, never more workgroups than pools' worth of rays
     const uint32_t pools = gf_div_up(N, (uint32_t)kPool);
@@ -852,7 +1086,8 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
         ha.phase = phase;
         ha.queue = phase ? w.alive_a : w.alive_b;
         if (ev) (void)hipEventRecord(ev[2 * phase], s);
-        hipLaunchKernelGGL(k_head_phase, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        if (fast) hipLaunchKernelGGL(k_head_phase<true>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        else hipLaunchKernelGGL(k_head_phase<false>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
         if (ev) (void)hipEventRecord(ev[2 * phase + 1], s);
     }
     return gf_check_launch("render_head");

@@ -67,6 +67,35 @@ GF_EXPORT int gf_head_pack(const float* amb0, const float* amb1, const float* am
     return GF_OK;
 }
 
+// Fast path: the same eight matrices as f16 MFMA A-operand streams (layout: frame.hpp, H16_*).  out_halves [gf_head_pack16_halves()]
+// receives IEEE binary16 bit patterns (round to nearest even).  The VALU rows and the identity bias are taken from gf_head_pack().
+GF_EXPORT uint32_t gf_head_pack16_halves(void) { return gf::HP16_HALVES; }
+
+GF_EXPORT int gf_head_pack16(const float* amb0, const float* amb1, const float* sig0, const float* sig1, const float* sig2, const float* col0,
+                             uint16_t* out_halves) {
+    using namespace gf;
+    if (!amb0 || !amb1 || !sig0 || !sig1 || !sig2 || !col0 || !out_halves) return gf_set_error(GF_ERR_INVALID, "head_pack16: null pointer");
+    memset(out_halves, 0, sizeof(uint16_t) * HP16_HALVES);
+    auto layer = [&](uint32_t g0, uint32_t groups, const float* W, uint32_t ld, uint32_t row0, uint32_t col0) {
+        for (uint32_t w = 0; w < 4; w++)
+            for (uint32_t u = 0; u < groups; u++)
+                for (uint32_t l = 0; l < 64; l++)
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const _Float16 h = (_Float16)W[(size_t)(row0 + 32 * w + (l & 31u)) * ld + col0 + 16 * u + 8 * (l >> 5) + i];
+                        memcpy(out_halves + (((size_t)w * H16_TOTAL + g0 + u) * 64 + l) * 8 + i, &h, sizeof(uint16_t));
+                    }
+    };
+    layer(H16_AMB1, 2, amb0, 96, 0, 0);
+    layer(H16_AMB2, 8, amb1, 128, 0, 0);
+    layer(H16_SIG1A, 2, sig0, 64, 0, 0);
+    layer(H16_SIG1B, 2, sig0, 64, 0, 32);
+    layer(H16_SIG2, 8, sig1, 128, 0, 0);
+    layer(H16_SIG3, 8, sig2, 128, 1, 0);
+    layer(H16_COL1S, 1, col0, 148, 0, 0);
+    layer(H16_COL1G, 8, col0, 148, 0, 16);
+    return GF_OK;
+}
+
 // Axis-aligned world-space box around every occupied cell of the Morton-ordered occupancy bitfield (HOST pointer):
 // cell (x,y,z) of cascade c covers ((v + {0,1}) / H * 2 - 1) * min(2^c, bound) per axis (raymarching.cu:883-892).  A sample
 // position outside this box lies in an unoccupied cell at every cascade, so the marcher can never emit a sample beyond

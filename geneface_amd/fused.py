@@ -30,8 +30,8 @@ class GfFrame(C.Structure):
         ("occ_aabb", _f32 * 6), ("_pad1", _f32 * 2),
         ("pos_table", _vp), ("pos_offsets", _vp), ("amb_table", _vp), ("amb_offsets", _vp),
         ("pos_S", _f32), ("amb_S", _f32),
-        ("base_res", _u32), ("gridtype", _u32), ("interp", _u32), ("_pad2", _u32),
-        ("head_pack", _vp), ("amb_bias", _vp),
+        ("base_res", _u32), ("gridtype", _u32), ("interp", _u32), ("precision", _u32),
+        ("head_pack", _vp), ("head_pack16", _vp), ("amb_bias", _vp),
         ("torso_pack", _vp), ("torso_bias", _vp), ("torso_table", _vp), ("torso_offsets", _vp), ("torso_occ", _vp), ("bg_coords", _vp),
         ("torso_S", _f32), ("torso_thresh", _f32), ("torso_shrink", _f32), ("_pad3", _f32),
         ("bg_color", _vp), ("out_rgb", _vp), ("out_depth", _vp), ("out_rgb8", _vp), ("out_torso_alpha", _vp),
@@ -85,6 +85,7 @@ class FusedState:
                              _hp(_np(s[1].weight)), _hp(_np(s[2].weight)), _hp(_np(c[0].weight)), _hp(_np(c[1].weight)),
                              _hp(ind) if ind is not None else None, _hp(pack)))
         self.head_pack = torch.from_numpy(pack).to(dev)
+        self._head_pack16 = None            # fast path: packed on first use (pack16)
         # ambient L1's cond_feat columns, rows in accumulator-layout order: amb_bias = W_cond @ cond_feat per frame
         self.W_cond = a[0].weight.detach()[self.perm.to(dev), 32:].contiguous()
 
@@ -113,6 +114,17 @@ class FusedState:
             self.torso_S = float(np.log2(model.torso_embedder.per_level_scale))
         self._ws = {}
         self.cond = self._build_cond(model)
+
+    def pack16(self, model):
+        """f16 A-operand streams of the head's six MFMA layers (gf_frame_t.precision = 1, the "fast" parity tier)."""
+        if self._head_pack16 is None:
+            L = lib()
+            a, s, c = model.ambient_net.net, model.sigma_net.net, model.color_net.net
+            out = np.empty(L.gf_head_pack16_halves(), dtype=np.uint16)
+            check(L.gf_head_pack16(_hp(_np(a[0].weight)), _hp(_np(a[1].weight)), _hp(_np(s[0].weight)), _hp(_np(s[1].weight)),
+                                   _hp(_np(s[2].weight)), _hp(_np(c[0].weight)), _hp(out)))
+            self._head_pack16 = torch.from_numpy(out.view(np.int16)).to(self.device)
+        return self._head_pack16
 
     def _build_cond(self, model):
         """gf_cond_t with every weight pointer filled in (None when the encoder is not the AudioNet + AudioAttNet pair the
@@ -227,6 +239,11 @@ def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_th
     f.pos_S, f.amb_S = st.pos_S, st.amb_S
     f.base_res, f.gridtype, f.interp = st.base_res, st.gridtype, st.interp
     f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
+    precision = getattr(model, "render_precision", "fp32")
+    if precision not in ("fp32", "fast"):
+        raise ValueError(f"render_precision must be 'fp32' or 'fast', got {precision!r}")
+    f.precision = 1 if precision == "fast" else 0
+    f.head_pack16 = st.pack16(model).data_ptr() if precision == "fast" else None
     f.bg_color = ptr(bg, torch.float32)
     f.out_rgb, f.out_depth = ptr(out_rgb), ptr(out_depth)
     f.out_rgb8 = ptr(out_rgb8, torch.uint8) if out_rgb8 is not None else None

@@ -36,6 +36,10 @@ class NeRFRenderer(nn.Module):
     #: kernels cover (no perturbation, max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
     #: the GPU through libgeneface_hip.so; neither has a CPU fallback.
     render_impl = "auto"
+    #: arithmetic of the fused head field: "fp32" (strict parity: everything in fp32, the offline inference path of the reference) or
+    #: "fast" (f16 MFMA operands and activations, fp32 accumulation -- what the reference computes under autocast / model.half(), its
+    #: training and viewer paths; BASELINE.md section 4 "fast": PSNR >= 40 dB, <= 1 LSB on >= 99.9 % of uint8 pixels).
+    render_precision = "fp32"
 
     def __init__(self, hparams):
         super().__init__()

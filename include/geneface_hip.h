@@ -146,8 +146,11 @@ typedef struct gf_frame_t {
     const float* pos_table;  const int32_t* pos_offsets;   /* position_embedder.embeddings / offsets (3-D, 16x2) */
     const float* amb_table;  const int32_t* amb_offsets;   /* ambient_embedder.embeddings / offsets  (2-D, 16x2) */
     float pos_S, amb_S;         /* log2(per_level_scale) of each grid */
-    uint32_t base_res, gridtype, interp, _pad2;
+    uint32_t base_res, gridtype, interp;
+    uint32_t precision;         /* 0: fp32 everywhere (strict parity).  1: "fast" -- f16 MFMA operands and activations, fp32 accumulate
+                                   (what the reference's autocast / .half() viewer path computes); needs head_pack16 */
     const float* head_pack;     /* device copy of gf_head_pack() output */
+    const uint16_t* head_pack16;/* device copy of gf_head_pack16() output, or NULL when precision == 0 */
     const float* amb_bias;      /* [128] ambient_net.net.0.weight[:, 32:96] @ cond_feat, rows permuted by gf_clayout_perm */
     /* torso field (radnerf_torso.py:20-49); torso_pack == NULL renders the head only */
     const float* torso_pack;    /* device copy of gf_torso_pack() output */
@@ -212,6 +215,10 @@ int gf_clayout_perm(uint32_t* perm128_host);
 int gf_head_pack(const float* amb0_host, const float* amb1_host, const float* amb2_host, const float* sig0_host,
                  const float* sig1_host, const float* sig2_host, const float* col0_host, const float* col1_host,
                  const float* ind_code_host, float* out_host);
+/* fast path (gf_frame_t.precision = 1): the six MFMA layers of the head as f16 A-operand streams (binary16 bit patterns) */
+uint32_t gf_head_pack16_halves(void);
+int gf_head_pack16(const float* amb0_host, const float* amb1_host, const float* sig0_host, const float* sig1_host,
+                   const float* sig2_host, const float* col0_host, uint16_t* out_halves_host);
 /* HOST pointers: torso_deform_net / torso_canonicial_net weights */
 int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_host, const float* c0_host,
                   const float* c1_host, const float* c2_host, float* out_host);

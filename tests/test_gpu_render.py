@@ -391,3 +391,27 @@ def test_viewer_path_downscale_and_accumulation_vs_oracle():
     cam.orbit(40, 0)
     v.need_update = True
     assert np.abs(v.test_step() - first).max() > 1e-3 and v.spp == 1
+
+
+def test_fast_precision_tier_vs_oracle():
+    """BASELINE.md section 4, "fast": f16 MFMA operands and activations with fp32 accumulation (the reference's autocast / .half()
+    arithmetic) against the fp32 oracle: PSNR >= 40 dB on the float image, <= 1 LSB on >= 99.9 % of the uint8 pixels."""
+    hp, sd, model = build(True, "fused")
+    fi = frame_inputs(sequence(4, 256, 256), 2)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True)
+    strict = render_gpu(model, hp, fi)["rgb_map"].cpu()
+    model.render_precision = "fast"
+    out = render_gpu(model, hp, fi)
+    rgb, rgb_ref = out["rgb_map"].cpu(), ref["rgb_map"]
+    p = psnr(rgb, rgb_ref)
+    u8 = (rgb * 255).to(torch.uint8).int() - (rgb_ref * 255).to(torch.uint8).int()
+    within = (u8.abs() <= 1).float().mean().item()
+    err = (rgb - rgb_ref).abs().max().item()
+    print(f"fast tier: PSNR {p:.1f} dB, max|drgb| {err:.2e}, uint8 within 1 LSB {within * 100:.3f} %")
+    assert p >= 40.0 and within >= 0.999, (p, within, err)
+    assert (out["depth_map"].cpu() - ref["depth_map"]).abs().max().item() < 2e-2
+    assert (strict - rgb_ref).abs().max().item() < RGB_ATOL            # the default stays the strict fp32 path
+    assert (rgb - strict).abs().max().item() > 0                        # and the fast path really is a different kernel
+    with pytest.raises(ValueError):
+        model.render_precision = "bf8"
+        render_gpu(model, hp, fi)
