@@ -465,7 +465,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 constexpr int kHS16 = 136;            // halves per activation row
 constexpr int kFS16 = 72;             // halves per row of the 3-D feature buffer (32 used; 144 B: rows 16 B apart in bank space)
-static_assert((kPass * kHS16 + kPass * kFS16) * 2 <= kPass * kHS * 4, "f16 activations + 3-D features fit the fp32 activation buffer");
+static_assert((kPass * kHS16 + kPass * kFS16 + kPool * 16) * 2 <= kPass * kHS * 4, "f16 activations + 3-D features + SH table fit the fp32 activation buffer");
 constexpr int kWAhead16 = 4;          // A-operand FIFO depth: one group is only NT x 32 cycles of MFMA
 struct WPipe16 { float4 q[kWAhead16]; };
 
@@ -577,6 +577,15 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     _Float16* F3 = H16 + kPass * kHS16;
     _Float16* Frow = F3 + sI * kFS16;
     const _Float16* Fb = F3 + j * kFS16 + 8 * half;
+    // SH(dir) is a property of the ray: one evaluation per pool slot and round (owner lanes) instead of one per sample and tile; the colour
+    // layer's SH operand is then a plain 16-byte LDS read
+    _Float16* SHT = F3 + kPass * kFS16;
+    if (wave * 64 + lane < kPool) {
+        const int slot = wave * 64 + lane;
+        float sh[16];
+        gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+        store16h(SHT + slot * 16, sh);
+    }
     floatx16 A[4];
     WPipe16 wp;
 #pragma unroll
@@ -590,41 +599,62 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16h(Frow + 16 * half, pf);
     }
+    GF_STAMP(7);
     __syncthreads();
+    GF_STAMP(8);
     // ---- ambient L1 (cond_feat folded into the bias)
     obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
     obw16_mfma<NT, gf::H16_AMB1, 2, kFS16>(wp, Ws, lane16, Fb, A);
+    GF_STAMP(9);
+    GF_STAMP(10);
     obw16_store<NT, true>(Hw, A);          // H is not read by this layer: no barrier before the write-back
+    GF_STAMP(11);
     __syncthreads();
+    GF_STAMP(12);
     // ---- ambient L2
     obw_zero<NT>(A);
     obw16_mfma<NT, gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(13);
     __syncthreads();
+    GF_STAMP(14);
     obw16_store<NT, true>(Hw, A);
+    GF_STAMP(15);
     __syncthreads();
+    GF_STAMP(16);
     // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 0:32]
     if (tile_on) {
         float ambient[2];
         rows_from_lds16<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
-        const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
+        // (tanh(v) + 1) / 2 = 1 / (1 + exp(-2 v))
+        const float x2[2] = {1.0f / (1.0f + __expf(-2.0f * ambient[0])), 1.0f / (1.0f + __expf(-2.0f * ambient[1]))};
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16h(Hrow + 16 * half, af);
     }
+    GF_STAMP(17);
     __syncthreads();
+    GF_STAMP(18);
     // ---- density L1: [3-D features (F3) | 2-D features (H)]
     obw_zero<NT>(A);
     obw16_mfma<NT, gf::H16_SIG1A, 2, kFS16>(wp, Ws, lane16, Fb, A);
     obw16_mfma<NT, gf::H16_SIG1B, 2>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(19);
     __syncthreads();
+    GF_STAMP(20);
     obw16_store<NT, true>(Hw, A);
+    GF_STAMP(21);
     __syncthreads();
+    GF_STAMP(22);
     // ---- density L2
     obw_zero<NT>(A);
     obw16_mfma<NT, gf::H16_SIG2, 8>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(23);
     __syncthreads();
+    GF_STAMP(24);
     obw16_store<NT, true>(Hw, A);
+    GF_STAMP(25);
     __syncthreads();
+    GF_STAMP(26);
     // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
     float sigma = 0.0f;
     if (tile_on) {
@@ -634,9 +664,13 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     }
     obw_zero<NT>(A);
     obw16_mfma<NT, gf::H16_SIG3, 8>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(27);
     __syncthreads();
+    GF_STAMP(28);
     obw16_store<NT, false>(Hw, A);
+    GF_STAMP(29);
     __syncthreads();
+    GF_STAMP(30);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
     obw_bias<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
     {
@@ -646,10 +680,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
             uint32_t d = (uint32_t)(t * 32 + j);
             d = d < Mv ? d : Mv - 1u;
             const uint32_t slot = s.rrank[d];
-            float sh[16];
-            gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
-#pragma unroll
-            for (int i = 0; i < 8; i++) shb[t][i] = (_Float16)(half ? sh[8 + i] : sh[i]);
+            shb[t] = *reinterpret_cast<const half8*>(SHT + slot * 16 + 8 * half);
         }
         const half8 w8 = wpipe16_take<gf::H16_COL1S>(wp);
 #pragma unroll
@@ -658,9 +689,13 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         __builtin_amdgcn_sched_barrier(0);
     }
     obw16_mfma<NT, gf::H16_COL1G, 8>(wp, Ws, lane16, Hb, A);
+    GF_STAMP(31);
     __syncthreads();
+    GF_STAMP(32);
     obw16_store<NT, true>(Hw, A);
+    GF_STAMP(33);
     __syncthreads();
+    GF_STAMP(34);
     // ---- colour L2 + sigmoid
     if (tile_on) {
         float c[3];
@@ -672,7 +707,9 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
             s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
         }
     }
+    GF_STAMP(35);
     __syncthreads();
+    GF_STAMP(36);
 }
 
 template <bool FAST>

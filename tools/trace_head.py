@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frame", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--fast", action="store_true", help="trace the f16 fast-tier kernel (render_precision='fast')")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -56,6 +57,8 @@ def main():
     model = RADNeRFTorso(hp)
     model.load_state_dict(S.make_state_dict(hp, True), strict=True)
     model = model.to(dev).eval()
+    if args.fast:
+        model.render_precision = "fast"
     pipe = FramePipeline(model, hp, seq, dev, impl="fused")
     L = lib()
     L.gf_trace_dims.restype = C.c_uint32
