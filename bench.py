@@ -83,12 +83,24 @@ def legacy_nerf_baseline(seq, rays=4096):
     w = LN.make_weights(0)
     c2w = torch.tensor([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 0.6]], dtype=torch.float32)
     bg, cond = torch.from_numpy(seq["bg_img"]).view(H, W, 3), torch.zeros(64)
-    LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)            # warm-up
+    # 2048-ray chunks of 256-wide layers do not scale to a whole two-socket host: time one chunk at a few thread counts, keep the best
+    all_threads = torch.get_num_threads()
+    best_t, best_dt = all_threads, None
+    for t in sorted({all_threads, min(all_threads, 32), min(all_threads, 16)}, reverse=True):
+        torch.set_num_threads(t)
+        LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)        # warm-up at this thread count
+        t0 = time.perf_counter()
+        LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)
+        d = time.perf_counter() - t0
+        if best_dt is None or d < best_dt:
+            best_t, best_dt = t, d
+    torch.set_num_threads(best_t)
     t0 = time.perf_counter()
     LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=rays)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
     s_per_frame = dt / rays * H * W
-    return {"value": 1.0 / s_per_frame, "unit": "frames/s", "s_per_frame": s_per_frame, "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": 1.0 / s_per_frame, "unit": "frames/s", "s_per_frame": s_per_frame, "cores": best_t, "kind": "port",
             "sample": f"{rays} of {H * W} rays of one frame (2 chunks of 2048), extrapolated; published anchor ~28.8 s/frame on an RTX 2080 Ti"}
 
 

@@ -415,3 +415,57 @@ def test_fast_precision_tier_vs_oracle():
     with pytest.raises(ValueError):
         model.render_precision = "bf8"
         render_gpu(model, hp, fi)
+
+
+def _fast_model(torso, sd=None):
+    hp, sd0, model = build(torso, "fused")
+    if sd is not None:
+        model.load_state_dict(sd, strict=True)
+        from geneface_amd import fused
+        fused.invalidate(model)
+    model.render_precision = "fast"
+    return hp, (sd if sd is not None else sd0), model
+
+
+def _check_fast(out, ref, min_psnr=40.0):
+    rgb, rgb_ref = out["rgb_map"].cpu().reshape(ref["rgb_map"].shape), ref["rgb_map"]
+    assert psnr(rgb, rgb_ref) >= min_psnr, psnr(rgb, rgb_ref)
+    u8 = (rgb * 255).to(torch.uint8).int() - (rgb_ref * 255).to(torch.uint8).int()
+    assert (u8.abs() <= 1).float().mean().item() >= 0.999
+
+
+@pytest.mark.parametrize("torso", [False, True])
+@pytest.mark.parametrize("size,idx", [(64, 1), (96, 3)])
+def test_fast_tier_golden_frames(torso, size, idx):
+    """The fast tier on the committed golden frames (generated by the reference's own Python), head-only and head+torso."""
+    hp, sd, model = _fast_model(torso)
+    fi = frame_inputs(sequence(4, size, size), idx)
+    gold = np.load(os.path.join(GOLD, f"frame_{'torso' if torso else 'head'}_{size}.npz"))
+    out = render_gpu(model, hp, fi)
+    _check_fast(out, {"rgb_map": torch.from_numpy(gold["rgb_map"])})
+
+
+def test_fast_tier_edge_cases():
+    """Empty and full occupancy, ragged ray counts, a long sample budget: the fast kernel shares the pools / schedule code with the
+    strict one, but its LDS carve (f16 activations, 3-D feature buffer, SH table) is its own."""
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 64, 64), 0)
+    empty = dict(sd, density_bitfield=torch.zeros_like(sd["density_bitfield"]))
+    _, _, m = _fast_model(True, empty)
+    out = render_gpu(m, hp, fi)
+    ref = R.render(empty, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True)
+    assert (out["rgb_map"].cpu() - ref["rgb_map"]).abs().max().item() < 2e-5 and float(out["depth_map"].abs().max()) == 0.0
+    hp_h, sd_h = model_fixture(False)
+    full = dict(sd_h, density_bitfield=torch.full_like(sd_h["density_bitfield"], 255))
+    fi48 = frame_inputs(sequence(4, 48, 48), 2)
+    for ms in (4, 16, 64):
+        hpm = dict(hp_h, max_steps=ms)
+        _, _, m = _fast_model(False, full)
+        ref = R.render(full, hpm, fi48["rays_o"], fi48["rays_d"], fi48["cond"], fi48["bg_coords"], fi48["pose6"], fi48["bg"], False)
+        _check_fast(render_gpu(m, hpm, fi48), ref, min_psnr=38.0)     # dense fog: every sample contributes, f16 noise accumulates
+    idx = torch.linspace(0, 64 * 64 - 1, 37 * 5).long()
+    fi_r = dict(fi, rays_o=fi["rays_o"][:, idx].contiguous(), rays_d=fi["rays_d"][:, idx].contiguous(),
+                bg_coords=fi["bg_coords"][:, idx].contiguous(), bg=fi["bg"][:, idx].contiguous())
+    _, _, m = _fast_model(True)
+    ref = R.render(sd, hp, fi_r["rays_o"], fi_r["rays_d"], fi_r["cond"], fi_r["bg_coords"], fi_r["pose6"], fi_r["bg"], True)
+    _check_fast(render_gpu(m, hp, fi_r), ref)

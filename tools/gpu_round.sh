@@ -13,6 +13,8 @@ for s in $STEPS; do
     test)  timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest.log; tail -3 $OUT/pytest.log ;;
     testv:*) V=${s#testv:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_$V.log; tail -3 $OUT/pytest_$V.log ;;
     bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
+    benchfast) timeout 600 python bench.py --fast --no-cpu-baseline > $OUT/bench_fast.json 2> $OUT/bench_fast.err; cat $OUT/bench_fast.json
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_fast -o k --output-format csv -- python $REPO/bench.py --fast --steps 30 --warmup 5 --no-cpu-baseline --no-overlap > $OUT/prof_fast.log 2>&1); head -6 $OUT/prof_fast/k_kernel_stats.csv | cut -c1-160 ;;
     ab:*)  # A/B of an experiment library against the product one, interleaved, short benches: ab:<variant>
            V=${s#ab:}
            for rep in 1 2 3; do
