@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--no-overlap", action="store_true", help="one stream: frames do not overlap (per-kernel profiling runs)")
+    ap.add_argument("--png-frames", type=int, default=48, help="frames of the extra leg that also writes every frame as PNG (0 = skip)")
     ap.add_argument("--fast", action="store_true", help="secondary line: the 'fast' parity tier of BASELINE.md section 4 (f16 MFMA operands and "
                                                         "activations, fp32 accumulate); the default line is fp32")
     ap.add_argument("--head-only", action="store_true", help="BASELINE.json configs[1]: May lm3d_radnerf head-only (default: configs[2], head+torso)")
@@ -189,6 +190,8 @@ def main():
                        "frames_in_flight": 1 if (args.no_overlap or impl != "fused") else 2},
             "roofline": roofline,
         }
+        if args.png_frames > 0 and world == 1:
+            line["with_png"] = png_leg(pipe, Wm, min(args.png_frames, K))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(hp, sd, seq, args.cpu_frames, torso)
         else:
@@ -197,6 +200,31 @@ def main():
     if world > 1:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+
+
+def png_leg(pipe, first, n):
+    """the rate with the PNG files of base_nerf_infer.py:97-101 written as well (worker threads, zlib level 1, off the
+    render thread; a tmpfs directory).  Reported beside `value`, never inside it."""
+    import shutil
+    import tempfile
+    import torch
+    from geneface_amd.png import FrameWriter
+    out_dir = tempfile.mkdtemp(prefix="gf_png_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    workers = min(32, os.cpu_count() or 4)
+    try:
+        writer = FrameWriter(out_dir, workers=workers)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i, frame in pipe.stream(range(first, first + n)):
+                writer.submit(i, frame)
+        writer.close()
+        dt = time.perf_counter() - t0
+        nbytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    return {"value": n / dt, "unit": "frames/s", "frames": n, "png_workers": workers, "png_MB_per_frame": nbytes / n / 1e6,
+            "note": "render + D2H + PNG encode/write on worker threads (FramePipeline.stream keeps two frames in flight)"}
 
 
 def pmc_traffic():

@@ -120,6 +120,24 @@ class FramePipeline:
             self._events[slot] = ev
         return self._pinned[slot]
 
+    def stream(self, indices):
+        """Frame loop with the pipeline kept full: yields (i, uint8 [H,W,3] numpy view of the pinned buffer) once frame i has reached
+        host memory, while the following frames are already enqueued.  The view is only valid until the next iteration (the slot is
+        reused): consumers copy it or hand it to an encoder that does (png.FrameWriter.submit)."""
+        pending, depth = [], len(self._pinned)
+        for i in indices:
+            buf = self.render_frame(i)
+            pending.append((i, buf, self._events[(self._slot - 1) % depth]))
+            if len(pending) == depth:          # the oldest slot is the next one to be reused: drain it first
+                j, b, ev = pending.pop(0)
+                if ev is not None:
+                    ev.synchronize()
+                yield j, b.numpy()
+        for j, b, ev in pending:
+            if ev is not None:
+                ev.synchronize()
+            yield j, b.numpy()
+
     def wait(self, frame: torch.Tensor = None):
         """Block until every enqueued frame (or all work) has reached pinned host memory."""
         for ev in self._events:

@@ -120,23 +120,11 @@ class LM3d_RADNeRFInfer:
         lo, hi = shard_range(T, rank, world_size)
         pipe = FramePipeline(self.model, self.hparams, seq, self.device, frames=(lo, hi), impl="fused" if self.device.type == "cuda" else None)
         out = np.empty((hi - lo, self.dataset.H, self.dataset.W, 3), dtype=np.uint8)
-        pending = []
         with torch.no_grad():
-            for k in range(hi - lo):
-                pending.append((k, pipe.render_frame(k), pipe._events[(pipe._slot - 1) % len(pipe._pinned)]))
-                if len(pending) == len(pipe._pinned):     # the oldest pinned slot is about to be reused: drain it
-                    j, buf, ev = pending.pop(0)
-                    if ev is not None:
-                        ev.synchronize()
-                    out[j] = buf.numpy()
-                    if writer is not None:
-                        writer.submit(lo + j, out[j])
-            for j, buf, ev in pending:
-                if ev is not None:
-                    ev.synchronize()
-                out[j] = buf.numpy()
+            for k, frame in pipe.stream(range(hi - lo)):
+                out[k] = frame
                 if writer is not None:
-                    writer.submit(lo + j, out[j])
+                    writer.submit(lo + k, out[k])
         return out
 
     def infer_once(self, inp: dict):
