@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--n-rays", type=int, default=65536)
+    ap.add_argument("--amp", action="store_true", help="fp16 autocast + GradScaler, as the May config trains (lm3d_radnerf.yaml:5 amp: true)")
     args = ap.parse_args()
     import torch
     from geneface_amd import hparams as HP
@@ -43,6 +44,7 @@ def main():
     target = torch.rand(1, 512 * 512, 3, device=dev)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
     g = torch.Generator(device=dev).manual_seed(0)
+    scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
 
     def step(i):
         if i % hp["update_extra_interval"] == 0:
@@ -50,12 +52,14 @@ def main():
         f = i % len(poses)
         rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], 512, 512, -1)
         sel = torch.randint(0, 512 * 512, (args.n_rays,), device=dev, generator=g)
-        out = model.render(rays["rays_o"][:, sel], rays["rays_d"][:, sel], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel],
-                           perturb=True, force_all_rays=False, **hp)
-        loss = ((out["rgb_map"] - target[:, sel]) ** 2).mean() + 1e-3 * out["ambient"].mean()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            out = model.render(rays["rays_o"][:, sel], rays["rays_d"][:, sel], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel],
+                               perturb=True, force_all_rays=False, **hp)
+            loss = ((out["rgb_map"] - target[:, sel]) ** 2).mean() + 1e-3 * out["ambient"].mean()
         opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
         return out
 
     for i in range(args.warmup):
@@ -67,7 +71,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rate = args.steps / dt
-    print(json.dumps({"metric": "RAD-NeRF head training steps/s (n_rays 65536, fp32, Adam, grid update every 16 steps)", "value": rate,
+    print(json.dumps({"metric": f"RAD-NeRF head training steps/s (n_rays {args.n_rays}, {'fp16 autocast' if args.amp else 'fp32'}, Adam, grid update every 16 steps)", "value": rate,
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
