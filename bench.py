@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-frames", type=int, default=8)
+    ap.add_argument("--in-flight", type=int, default=0, help="frames enqueued concurrently on separate streams (fused path); 0 = the pipeline's default")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: frames do not overlap (per-kernel profiling runs)")
     ap.add_argument("--png-frames", type=int, default=48, help="frames of the extra leg that also writes every frame as PNG (0 = skip)")
     ap.add_argument("--fast", action="store_true", help="secondary line: the 'fast' parity tier of BASELINE.md section 4 (f16 MFMA operands and "
@@ -151,7 +152,7 @@ def main():
     if args.fast:
         model.render_precision = "fast"
     broadcast_model_(model, src=0)  # the only collective (RCCL): one flattened weight buffer
-    pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl, overlap=not args.no_overlap)
+    pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl, overlap=not args.no_overlap, in_flight=args.in_flight or None)
 
     def barrier():
         if world > 1:
@@ -187,7 +188,7 @@ def main():
                                    + f"; frame-sharded over {world} GPU(s)",
                        "impl": impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
                        "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}",
-                       "frames_in_flight": 1 if (args.no_overlap or impl != "fused") else 2},
+                       "frames_in_flight": pipe.in_flight if impl == "fused" else 1},
             "roofline": roofline,
         }
         if args.png_frames > 0 and world == 1:
@@ -224,7 +225,7 @@ def png_leg(pipe, first, n):
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
     return {"value": n / dt, "unit": "frames/s", "frames": n, "png_workers": workers, "png_MB_per_frame": nbytes / n / 1e6,
-            "note": "render + D2H + PNG encode/write on worker threads (FramePipeline.stream keeps two frames in flight)"}
+            "note": "render + D2H + PNG encode/write on worker threads (FramePipeline.stream keeps the pipeline full)"}
 
 
 def pmc_traffic():

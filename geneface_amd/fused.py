@@ -380,9 +380,10 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
 class _PipeBuffers:
     def __init__(self, pipe):
         dev, N = pipe.device, pipe.H * pipe.W
-        self.rgb = [torch.empty(N, 3, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.depth = [torch.empty(N, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.rgb8 = [torch.empty(pipe.H, pipe.W, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        slots = max(2, getattr(pipe, "in_flight", 2))
+        self.rgb = [torch.empty(N, 3, dtype=torch.float32, device=dev) for _ in range(slots)]
+        self.depth = [torch.empty(N, dtype=torch.float32, device=dev) for _ in range(slots)]
+        self.rgb8 = [torch.empty(pipe.H, pipe.W, 3, dtype=torch.uint8, device=dev) for _ in range(slots)]
         self.bg = pipe.bg.reshape(N, 3).contiguous()
         self.bg_coords = pipe.bg_coords.reshape(N, 2).contiguous()
         self.poses_host = pipe.poses.cpu().numpy()

@@ -52,7 +52,8 @@ class FramePipeline:
     cond_wins [T,smo,win,C], poses [T,4,4] (ngp axes, already smoothed), intrinsics [4], bg_img [H*W,3], H, W.
     """
 
-    def __init__(self, model, hp: dict, seq: dict, device, frames=None, impl: str = None, pinned_outputs: int = 2, overlap: bool = True):
+    def __init__(self, model, hp: dict, seq: dict, device, frames=None, impl: str = None, pinned_outputs: int = None, overlap: bool = True,
+                 in_flight: int = None):
         self.model, self.hp, self.device = model, hp, torch.device(device)
         self.H, self.W = int(seq["H"]), int(seq["W"])
         self.impl = impl or model.render_impl
@@ -65,17 +66,23 @@ class FramePipeline:
         self.intrinsics = [float(v) for v in seq["intrinsics"]]
         self.bg = torch.from_numpy(np.ascontiguousarray(seq["bg_img"])).float().view(1, -1, 3).to(dev)
         self.bg_coords = utils.get_bg_coords(self.H, self.W, dev)
+        # frames enqueued concurrently (streams, frame slots, host buffers).  Measured optimum on MI355X: three for the strict fp32
+        # head kernel (its persistent grid drains slowly: 701 -> 724 fps over two), two for the fast tier (more only adds contention)
+        if in_flight is None:
+            in_flight = 2 if getattr(model, "render_precision", "fp32") == "fast" else 3
+        self.in_flight = max(1, int(in_flight)) if overlap else 1
+        pinned_outputs = pinned_outputs or max(2, self.in_flight)
         self._pinned = [torch.empty(self.H, self.W, 3, dtype=torch.uint8).pin_memory() for _ in range(pinned_outputs)] \
             if dev.type == "cuda" else [torch.empty(self.H, self.W, 3, dtype=torch.uint8)]
         self._events = [None] * len(self._pinned)
         self._slot = 0
-        # fused path: consecutive frames alternate between two side streams (and two frame slots), so frame i+1 overlaps the
+        # fused path: consecutive frames rotate over `in_flight` side streams (and as many frame slots), so frame i+1 overlaps the
         # tail of frame i; each stream is in order, and the pinned-buffer events order the host reads
         self._streams = None
         if dev.type == "cuda" and self.impl == "fused":
             # overlap=False keeps every frame on ONE side stream: kernels of consecutive frames never share the GPU, which is
             # what per-kernel profiling (rocprofv3 durations, HIP-event timing) wants; throughput runs use two
-            self._streams = [torch.cuda.Stream(dev) for _ in range(2 if overlap else 1)]
+            self._streams = [torch.cuda.Stream(dev) for _ in range(self.in_flight)]
             for st in self._streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
 
@@ -105,7 +112,7 @@ class FramePipeline:
         if self.impl == "fused":
             from .fused import render_frame_fused
             with torch.cuda.stream(self._streams[slot % len(self._streams)]):
-                rgb8 = render_frame_fused(self, i, slot % 2)
+                rgb8 = render_frame_fused(self, i, slot % max(2, self.in_flight))
                 self._pinned[slot].copy_(rgb8, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()

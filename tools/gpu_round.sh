@@ -35,7 +35,7 @@ for s in $STEPS; do
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
     prof)  # one frame in flight: per-kernel durations are those of the kernel alone (what bench.py's roofline leg times)
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-overlap > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160
-           # the default command (two frames in flight: durations include the time a kernel shares the GPU with its neighbour frame)
+           # the default command (three frames in flight: durations include the time a kernel shares the GPU with its neighbour frame)
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_overlap -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof_overlap.log 2>&1); head -4 $OUT/prof_overlap/k_kernel_stats.csv | cut -c1-160 ;;
     pmc)   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmc_sq -o sq --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_sq.log 2>&1)
            (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_fetch.log 2>&1)
