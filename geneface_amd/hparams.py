@@ -58,3 +58,67 @@ def set_hparams(new: dict) -> dict:
     hparams.clear()
     hparams.update(new)
     return hparams
+
+
+# ----------------------------------------------------------------------------------------------- yaml chain
+def _merge(old: dict, new: dict):
+    """Nested dicts merge key by key, everything else is replaced (utils/commons/hparams.py:17-22)."""
+    for k, v in new.items():
+        if isinstance(v, dict) and isinstance(old.get(k), dict):
+            _merge(old[k], v)
+        else:
+            old[k] = v
+
+
+def load_config(config_fn: str, hparams_str: str = "", root: str = None) -> dict:
+    """Resolve one of the reference's experiment files (egs/datasets/videos/<id>/lm3d_radnerf(_torso).yaml) the way
+    `set_hparams(config=..., hparams_str=...)` does (utils/commons/hparams.py:51-107): depth-first `base_config` inheritance with
+    every file visited once, later files overriding earlier ones, then the command-line style overrides "a=1,b.c=2,d=[1 1 1]"
+    (typed after the value they replace).  `base_config` entries are relative to the working directory of the reference
+    (`root`, default: the current directory) or, when they start with '.', to the file that names them."""
+    import os
+
+    import yaml
+    root = root or os.getcwd()
+    seen = set()
+
+    def resolve(path):
+        return path if os.path.isabs(path) else os.path.join(root, path)
+
+    def load(fn):
+        full = resolve(fn)
+        if not os.path.exists(full):
+            return {}
+        with open(full) as f:
+            cfg = yaml.safe_load(f) or {}
+        seen.add(fn)
+        if "base_config" not in cfg:
+            return cfg
+        bases = cfg["base_config"] if isinstance(cfg["base_config"], list) else [cfg["base_config"]]
+        out = {}
+        for b in bases:
+            if b.startswith("."):
+                b = os.path.normpath(os.path.join(os.path.dirname(fn), b))
+            if b not in seen:
+                _merge(out, load(b))
+        _merge(out, cfg)
+        return out
+
+    hp = load(config_fn)
+    if not hp:
+        raise FileNotFoundError(f"config {resolve(config_fn)!r} not found or empty")
+    if hparams_str:
+        import ast
+        for item in hparams_str.split(","):
+            k, v = item.split("=")
+            v = v.strip("'\" ")
+            node = hp
+            *parents, leaf = k.split(".")
+            for p in parents:
+                node = node[p]
+            old = node[leaf]
+            if v in ("True", "False") or isinstance(old, (bool, list, dict)):
+                node[leaf] = ast.literal_eval(v.replace(" ", ",") if isinstance(old, list) else v)
+            else:
+                node[leaf] = type(old)(v)
+    return hp

@@ -153,6 +153,11 @@ class LM3d_RADNeRFInfer:
         return frames
 
     @classmethod
-    def example_run(cls, inp: dict, hparams: dict = None, **kw):
-        from .hparams import may_hparams
-        return cls(hparams or may_hparams(True), **kw).infer_once(inp)
+    def example_run(cls, inp: dict, hparams: dict = None, config: str = None, hparams_str: str = "", config_root: str = None, **kw):
+        """base_nerf_infer.py:271-300.  `config` is one of the reference's experiment files (e.g.
+        egs/datasets/videos/May/lm3d_radnerf_torso.yaml, resolved through its `base_config` chain with `--hparams`-style overrides in
+        `hparams_str`); without one the May values built into geneface_amd.hparams are used."""
+        from .hparams import load_config, may_hparams
+        if hparams is None:
+            hparams = load_config(config, hparams_str, root=config_root) if config else may_hparams(True)
+        return cls(hparams, **kw).infer_once(inp)

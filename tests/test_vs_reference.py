@@ -164,3 +164,28 @@ def test_legacy_nerf_baseline_matches_reference_pure_torch_path():
             out = LN.render(w, H, W, focal, cx, cy, c2w, bg, cond)
     assert out.shape == (H * W, 3)
     assert (out - ref.reshape(-1, 3)).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("cfg", ["egs/datasets/videos/May/lm3d_radnerf_torso.yaml", "egs/datasets/videos/May/lm3d_radnerf.yaml",
+                                 "egs/datasets/videos/Obama2/lm3d_radnerf_torso.yaml", "egs/datasets/videos/Obama/radnerf.yaml"])
+def test_yaml_chain_loader_matches_reference_set_hparams(cfg):
+    """geneface_amd.hparams.load_config against the reference's own set_hparams on its experiment files (two identities, landmark-
+    and audio-driven), with and without command-line style overrides."""
+    import os
+    from geneface_amd import hparams as HP
+    refshim.install()
+    from utils.commons.hparams import set_hparams as ref_set
+    cwd = os.getcwd()
+    os.chdir(refshim.REFERENCE_ROOT)                      # the reference resolves base_config against its working directory
+    try:
+        for over in ("", "max_steps=24,dt_gamma=0.01,with_att=False,camera_offset=[0 0 1]"):
+            ref = ref_set(config=cfg, hparams_str=over, print_hparams=False, global_hparams=False)
+            ours = HP.load_config(cfg, over, root=refshim.REFERENCE_ROOT)
+            ours.update({"infer": False, "debug": False, "validate": False, "exp_name": ""})     # run-mode flags set_hparams adds from argv
+            assert ours == ref, {k: (ours.get(k), ref.get(k)) for k in set(ours) | set(ref) if ours.get(k) != ref.get(k)}
+    finally:
+        os.chdir(cwd)
+    may = HP.load_config("egs/datasets/videos/May/lm3d_radnerf_torso.yaml", root=refshim.REFERENCE_ROOT)
+    for k, v in HP.may_hparams(True).items():
+        if k in may:
+            assert may[k] == v, (k, may[k], v)
