@@ -21,5 +21,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                                         current_stream(grad.device)))
 
 
-def grad_total_variation(*a, **k):
-    raise NotImplementedError("_gridencoder.grad_total_variation: no caller in GeneFace (SURVEY.md 2.2B)")
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+    check(lib().gf_grad_total_variation(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(grad, torch.float32),
+                                        ptr(offsets, torch.int32), float(weight), B, D, C, L, float(S), H, gridtype, int(align_corners),
+                                        current_stream(inputs.device)))

@@ -81,5 +81,5 @@ def composite_rays_train_backward(grad_weights_sum, grad_ambient_sum, grad_image
                                                  ptr(grad_ambient, _F), current_stream(sigmas.device)))
 
 
-def sph_from_ray(*a, **k):
-    raise NotImplementedError("_raymarching_face.sph_from_ray: no call site in GeneFace (SURVEY.md 2.2A)")
+def sph_from_ray(rays_o, rays_d, radius, N, coords):
+    check(lib().gf_sph_from_ray(ptr(rays_o, _F), ptr(rays_d, _F), radius, N, ptr(coords, _F), current_stream(rays_o.device)))

@@ -265,6 +265,70 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     }
 }
 
+// gridencoder.cu:505-596: normalised total-variation gradient around the lattice node each input falls on, accumulated into grad.
+// One lane per (point, level); the table differences are a handful of gathers, the accumulation one f32 atomic per channel.
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBlock) k_grad_tv(const float* __restrict__ inputs, const float* __restrict__ embeddings, float* __restrict__ grad,
+                                                    const int* __restrict__ offsets, float weight, uint32_t B, gf::GridLevels lv, uint32_t gridtype,
+                                                    bool align_corners) {
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x, level = blockIdx.y;
+    if (b >= B) return;
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0 || x[d] > 1);
+    }
+    if (oob) return;
+    const uint32_t off = (uint32_t)offsets[level], hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const float* table = embeddings + (size_t)off * C;
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)floorf(__builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f));
+    float centre[C], results[C], idelta[C];
+    const uint32_t row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pg);
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) { centre[c] = table[(size_t)row * C + c]; results[c] = 0.0f; idelta[c] = 0.0f; }
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur = pg[d];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (side == 0 ? cur < resolution : cur > 0) {
+                pg[d] = side == 0 ? cur + 1 : cur - 1;
+                const uint32_t r2 = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pg);
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    const float g = centre[c] - table[(size_t)r2 * C + c];
+                    results[c] += g;
+                    idelta[c] += g * g;
+                }
+            }
+        }
+        pg[d] = cur;
+    }
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(grad + ((size_t)off + row) * C + c, w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f)));
+}
+
+template <uint32_t D>
+int dispatch_tv_c(uint32_t C, const float* inputs, const float* embeddings, float* grad, const int* offsets, float weight, uint32_t B,
+                  const gf::GridLevels& lv, uint32_t gridtype, bool ac, hipStream_t s) {
+    const dim3 grid(gf_div_up(B, (uint32_t)kBlock), lv.L), block(kBlock);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grad_tv<D, 1>), grid, block, 0, s, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac); break;
+        case 2: hipLaunchKernelGGL((k_grad_tv<D, 2>), grid, block, 0, s, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac); break;
+        case 4: hipLaunchKernelGGL((k_grad_tv<D, 4>), grid, block, 0, s, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac); break;
+        case 8: hipLaunchKernelGGL((k_grad_tv<D, 8>), grid, block, 0, s, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac); break;
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+    return gf_check_launch("grad_total_variation");
+}
+
 // gridencoder.cu:343-368
 __global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __restrict__ grad, const float* __restrict__ dy_dx,
                                                                 float* __restrict__ grad_inputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
@@ -416,6 +480,24 @@ GF_EXPORT int gf_grid_encode_backward(const float* grad, const float* inputs, co
         return gf_check_launch("grid_encode_backward(inputs)");
     }
     return GF_OK;
+}
+
+GF_EXPORT int gf_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets, float weight, uint32_t B,
+                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!inputs || !embeddings || !grad || !offsets) return gf_set_error(GF_ERR_INVALID, "grad_total_variation: null pointer");
+    if (gridtype > 1) return gf_set_error(GF_ERR_INVALID, "grad_total_variation: gridtype must be 0 or 1");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grad_total_variation: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: return dispatch_tv_c<2>(C, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac, s);
+        case 3: return dispatch_tv_c<3>(C, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac, s);
+        case 4: return dispatch_tv_c<4>(C, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac, s);
+        case 5: return dispatch_tv_c<5>(C, inputs, embeddings, grad, offsets, weight, B, lv, gridtype, ac, s);
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
 }
 
 GF_EXPORT int gf_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs, void* stream) {

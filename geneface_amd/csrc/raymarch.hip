@@ -133,6 +133,30 @@ GF_EXPORT int gf_near_far_from_aabb(const float* rays_o, const float* rays_d, co
     return gf_check_launch("near_far_from_aabb");
 }
 
+// raymarching.cu:161-198: where the ray leaves the sphere |x| = radius, as (polar, azimuth) angles scaled to [-1, 1] (y up)
+__global__ void __launch_bounds__(kBlock) k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius, uint32_t N,
+                                                         float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[(size_t)n * 3], oy = rays_o[(size_t)n * 3 + 1], oz = rays_o[(size_t)n * 3 + 2];
+    const float dx = rays_d[(size_t)n * 3], dy = rays_d[(size_t)n * 3 + 1], dz = rays_d[(size_t)n * 3 + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;   // half of the linear coefficient
+    const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * C)) / A;   // the far root
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float rpi = 0.3183098861837907f;
+    coords[(size_t)n * 2] = 2 * atan2f(sqrtf(x * x + z * z), y) * rpi - 1;
+    coords[(size_t)n * 2 + 1] = atan2f(z, x) * rpi;
+}
+
+GF_EXPORT int gf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    if (N == 0) return GF_OK;
+    if (!rays_o || !rays_d || !coords) return gf_set_error(GF_ERR_INVALID, "sph_from_ray: null pointer");
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(gf_div_up(N, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), rays_o, rays_d, radius, N, coords);
+    return gf_check_launch("sph_from_ray");
+}
+
 GF_EXPORT int gf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                             const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                             uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,

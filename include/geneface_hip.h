@@ -36,6 +36,10 @@ int gf_device_count(void);
 int gf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                           float* nears, float* fars, void* stream);
 
+/* sph_from_ray (raymarching.h:8, kernel raymarching.cu:161-198).  coords [N,2] = (polar, azimuth) of the ray's far intersection
+ * with the sphere of `radius`, scaled to [-1,1].  No caller in GeneFace; exported for completeness of the seam. */
+int gf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream);
+
 /* march_rays (raymarching.h:19, kernel raymarching.cu:828-929).  rays_alive i32[>=n_alive], rays_t/nears/fars [N],
  * grid u8[C*H^3/8], xyzs/dirs [n_alive*n_step,3] and deltas [n_alive*n_step,2] ZERO-FILLED by the caller, noises [n_alive]. */
 int gf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
@@ -92,6 +96,10 @@ int gf_grid_encode_forward(const float* inputs, const float* embeddings, const i
 int gf_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int32_t* offsets, float* grad_embeddings,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
                             uint32_t gridtype, int align_corners, uint32_t interp, void* stream);
+/* grad_total_variation (gridencoder.h:14, kernel gridencoder.cu:505-596).  grad [sO,C] is ACCUMULATED into (f32 atomics): the
+ * normalised total-variation gradient of the table around the lattice node every input [B,D] in [0,1] falls on, times weight/(2D). */
+int gf_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets, float weight, uint32_t B,
+                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream);
 /* same arithmetic, outputs laid out [B, L*C] (what GridEncoder.forward returns after grid.py:57's permute). */
 int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,

@@ -70,6 +70,10 @@ class raymarching_face:
                                  _p(image, torch.float32))
 
     @staticmethod
+    def sph_from_ray(rays_o, rays_d, radius, N, coords):
+        lib().orc_sph_from_ray(_p(rays_o, torch.float32), _p(rays_d, torch.float32), _f(radius), _u(N), _p(coords, torch.float32))
+
+    @staticmethod
     def packbits(grid, N, density_thresh, bitfield):
         lib().orc_packbits(_p(grid, torch.float32), _u(N), _f(density_thresh), _p(bitfield, torch.uint8))
 
@@ -139,6 +143,14 @@ class gridencoder:
                                             _u(gridtype), C.c_int(int(bool(align_corners))), _u(interp))
         if rc != 0:
             raise RuntimeError("GridEncoding backward: unsupported D / C")
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L, S, H, gridtype, align_corners):
+        rc = lib().orc_grad_total_variation(_p(inputs, torch.float32), _p(embeddings, torch.float32), _p(grad, torch.float32),
+                                            _p(offsets, torch.int32), _f(weight), _u(B), _u(D), _u(Cc), _u(L), _f(S), _u(H), _u(gridtype),
+                                            C.c_int(int(bool(align_corners))))
+        if rc != 0:
+            raise RuntimeError("GridEncoding total variation: unsupported D / C")
 
 
 class shencoder:

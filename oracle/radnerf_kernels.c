@@ -108,6 +108,25 @@ ORC_EXPORT void orc_near_far_from_aabb(const float* rays_o, const float* rays_d,
     }
 }
 
+/* ---- raymarching.cu:161-198 kernel_sph_from_ray: far intersection with the sphere |x| = radius -> (theta, phi) in [-1, 1] ---- */
+ORC_EXPORT void orc_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords) {
+    const float RPI = 0.3183098861837907f;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = dx * dx + dy * dy + dz * dz;
+        const float B = ox * dx + oy * dy + oz * dz;
+        const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+        const float t = (-B + sqrtf(B * B - A * C)) / A;
+        const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+        const float theta = atan2f(sqrtf(x * x + z * z), y);
+        const float phi = atan2f(z, x);
+        coords[n * 2] = 2 * theta * RPI - 1;
+        coords[n * 2 + 1] = phi * RPI;
+    }
+}
+
 /* ---- raymarching.cu:214-226 kernel_morton3D ---- */
 ORC_EXPORT void orc_morton3D(const int32_t* coords, uint32_t N, int32_t* indices) {
     for (uint32_t n = 0; n < N; n++)
@@ -290,6 +309,50 @@ static inline uint32_t orc_grid_index(uint32_t gridtype, int align_corners, uint
     }
     if (gridtype == 0 && stride > hashmap_size) index = orc_fast_hash(pos_grid, D);
     return (index % hashmap_size) * C + ch;
+}
+
+/* gridencoder.cu:505-596 kernel_grad_tv: normalised total-variation gradient of the table around the node each input falls on,
+ * accumulated into grad (the caller's gradient buffer).  One (point, level) pair per iteration, sequential: the reference's
+ * atomics make the order arbitrary. */
+ORC_EXPORT int orc_grad_total_variation(const float* inputs_, const float* embeddings, float* grad_, const int32_t* offsets, float weight,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                        int align_corners) {
+    if (D < 2 || D > ORC_MAX_D) return -1;
+    if (!(C == 1 || C == 2 || C == 4 || C == 8)) return -2;
+    for (uint32_t level = 0; level < L; level++) {
+        const float* grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+        float* grad = grad_ + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const float scale = exp2f((float)level * S) * (float)H - 1.0f;
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* inputs = inputs_ + (size_t)b * D;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) oob |= (inputs[d] < 0 || inputs[d] > 1);
+            if (oob) continue;
+            uint32_t pos_grid[ORC_MAX_D];
+            for (uint32_t d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(fmaf(inputs[d], scale, align_corners ? 0.0f : 0.5f));   /* fused, like the forward */
+            float results[ORC_MAX_C] = {0}, idelta[ORC_MAX_C] = {0};
+            const uint32_t index = orc_grid_index(gridtype, align_corners, D, C, 0, hashmap_size, resolution, pos_grid);
+            const float w = weight / (float)(2 * D);
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t cur = pos_grid[d];
+                if (cur < resolution) {
+                    pos_grid[d] = cur + 1;
+                    const uint32_t ir = orc_grid_index(gridtype, align_corners, D, C, 0, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) { const float g = grid[index + ch] - grid[ir + ch]; results[ch] += g; idelta[ch] += g * g; }
+                }
+                if (cur > 0) {
+                    pos_grid[d] = cur - 1;
+                    const uint32_t il = orc_grid_index(gridtype, align_corners, D, C, 0, hashmap_size, resolution, pos_grid);
+                    for (uint32_t ch = 0; ch < C; ch++) { const float g = grid[index + ch] - grid[il + ch]; results[ch] += g; idelta[ch] += g * g; }
+                }
+                pos_grid[d] = cur;
+            }
+            for (uint32_t ch = 0; ch < C; ch++) grad[index + ch] += w * results[ch] * (1.0f / sqrtf(idelta[ch] + 1e-9f));
+        }
+    }
+    return 0;
 }
 
 /* gridencoder.cu:88-244 kernel_grid (forward, optional dy_dx).

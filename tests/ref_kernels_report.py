@@ -171,7 +171,26 @@ def cases():
         return {"i:counts": torch.from_numpy(cnt), "i:counter": counter, "xyzs": xs, "dirs": ds, "deltas": des, "ws": ws, "amb": am, "depth": dep, "image": img,
                 "g_sig": gs, "g_rgb": gc, "g_amb": ga, "g_ro": go, "g_rd": gdd}
 
-    return {"near_far": near_far, "march1": march(1), "march2": march(2), "march8": march(8), "maintenance": maintenance,
+    def sph_from_ray(m, dev):
+        RM = m[0]
+        c = torch.empty(N, 2, device=dev)
+        RM.sph_from_ray(ro.to(dev), rd.to(dev), 3.0, N, c)
+        return {"coords": c}
+
+    def grad_tv(D, gridtype, table, off, B=1 << 16):
+        x = torch.rand(B, D, generator=torch.Generator().manual_seed(31 + D))
+        x[:5] = -0.25
+
+        def run(m, dev):
+            GE = m[1]
+            gr = torch.zeros(table.shape, device=dev)
+            GE.grad_total_variation(x.to(dev), table.to(dev), gr, off.to(dev), 1e-2, B, D, 2, 16, S3, 16, gridtype, False)
+            return {"g_tv": gr}
+        return run
+
+    return {"sph_from_ray": sph_from_ray, "grad_tv3_tiled": grad_tv(3, 1, pe, po), "grad_tv2_tiled": grad_tv(2, 1, ae, ao),
+            "grad_tv3_hash": grad_tv(3, 0, he, hm.offsets),
+            "near_far": near_far, "march1": march(1), "march2": march(2), "march8": march(8), "maintenance": maintenance,
             "grid3_tiled_lin": grid_fwd(3, 1, 0, pe, po), "grid2_tiled_lin": grid_fwd(2, 1, 0, ae, ao),
             "grid3_hash_smooth": grid_fwd(3, 0, 1, he, hm.offsets), "sh": sh, "freq": freq, "train": train}
 

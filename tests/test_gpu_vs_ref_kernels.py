@@ -35,6 +35,8 @@ REL_TOL = {
     ("freq", "out"): 1e-4,          # the reference calls the hardware sin/cos approximation (__sinf/__cosf); oracle and product use sinf/cosf
     ("freq", "g_in"): 1e-4,
     ("sh", "g_in"): 1e-6,
+    ("sph_from_ray", "coords"): 2e-6,
+    ("grad", "g_tv"): 2e-5,         # float atomics; every contribution is a normalised difference of order weight / (2 D)
 }
 OFF_FACTOR = 400.0                  # smoothstep dy_dx cancels catastrophically without fma: the reference's two builds differ by 3e-4 relative
 
@@ -50,7 +52,7 @@ def report():
 
 
 def _tol(case, name, contract):
-    fam = "grid" if case.startswith("grid") else case
+    fam = "grid" if case.startswith("grid") else ("grad" if case.startswith("grad_tv") else case)
     t = REL_TOL.get((fam, name), 2e-6)
     return t * (OFF_FACTOR if contract == "off" else 1.0)
 

@@ -175,3 +175,44 @@ def test_march_respects_occupancy_and_budget(oracle_lib):
     v4 = d4[..., 0] > 0
     assert torch.all(v4[:, 1:] <= v4[:, :-1])
     assert torch.all((d4[:, 1:, 1] > d4[:, :-1, 1]) | ~v4[:, 1:])
+
+
+def test_sph_from_ray_known_answers():
+    """raymarching.cu:161-198: far intersection with the sphere, y up.  From the origin along +y: theta = 0 -> -1; along +x: theta = pi/2 -> 0,
+    phi = 0; along +z: phi = pi/2 -> 0.5; along -x: phi = pi -> 1.  A shifted origin moves the hit point, not the formula."""
+    import math
+    from oracle import kernels as K
+    o = torch.zeros(5, 3)
+    d = torch.tensor([[0, 1, 0], [1, 0, 0], [0, 0, 1], [-1, 1e-12, 0], [0.6, 0.0, 0.8]], dtype=torch.float32)
+    c = torch.empty(5, 2)
+    K.raymarching_face.sph_from_ray(o, d, 2.0, 5, c)
+    assert abs(c[0, 0] + 1) < 1e-6
+    assert abs(c[1, 0]) < 1e-6 and abs(c[1, 1]) < 1e-6
+    assert abs(c[2, 0]) < 1e-6 and abs(c[2, 1] - 0.5) < 1e-6
+    assert abs(c[3, 1] - 1) < 1e-6
+    assert abs(c[4, 1] - math.atan2(0.8, 0.6) / math.pi) < 1e-6
+    o2 = torch.tensor([[0.5, 0.0, 0.0]])
+    c2 = torch.empty(1, 2)
+    K.raymarching_face.sph_from_ray(o2, torch.tensor([[0.0, 0.0, 1.0]]), 1.0, 1, c2)      # hits (0.5, 0, sqrt(.75))
+    assert abs(c2[0, 1] - math.atan2(math.sqrt(0.75), 0.5) / math.pi) < 1e-6 and abs(c2[0, 0]) < 1e-6
+
+
+def test_grad_total_variation_known_answers():
+    """gridencoder.cu:505-596 on a 1-level dense 2-D grid (resolution 4 -> 5 x 5 nodes, C = 1): a table linear in x has left/right
+    differences that cancel in the interior and a one-sided difference at the border; the result is normalised by the RMS of the
+    differences, so only signs and the weight / (2 D) factor remain."""
+    from oracle import kernels as K
+    L, D, C, H = 1, 2, 1, 4                         # scale = 2^0 * 4 - 1 = 3, resolution = 4
+    offsets = torch.tensor([0, 32], dtype=torch.int32)             # 25 nodes rounded up to 32
+    table = torch.zeros(32, 1)
+    for y in range(5):
+        for x in range(5):
+            table[x + y * 5, 0] = float(x)
+    grad = torch.zeros(32, 1)
+    pts = torch.tensor([[0.5, 0.5], [0.0, 0.5], [1.0, 0.5]])       # nodes (2,2), (0,2), (3,2): floor(x * 3 + 0.5)
+    K.gridencoder.grad_total_variation(pts, table, grad, offsets, 4.0, 3, D, C, L, 0.0, H, 1, False)
+    g = grad.view(-1)
+    assert abs(g[2 + 2 * 5]) < 1e-6                                 # interior: (2 - 3) + (2 - 1) = 0
+    assert abs(g[0 + 2 * 5] - (-1.0)) < 1e-5                        # left border: only the right neighbour, (0 - 1) / |.| * 4 / 4
+    assert abs(g[3 + 2 * 5]) < 1e-6                                 # node 3 of 0..4 still has both neighbours
+    assert abs(float(g.abs().sum()) - 1.0) < 1e-5
