@@ -1,27 +1,59 @@
 """Drop-in for the reference's pybind module `_gridencoder`
-(modules/radnerfs/encoders/gridencoder/src/bindings.cpp:5-9)."""
+(modules/radnerfs/encoders/gridencoder/src/bindings.cpp:5-9).
+
+dtype: the reference dispatches on the table's scalar type (AT_DISPATCH_FLOATING_TYPES_AND_HALF) and its wrapper hands the backend HALF
+tables, outputs, dy_dx and gradients whenever autocast is on (grid.py:41-44, the May config's `amp: true` on the training and viewer
+paths); inputs stay float.  The library computes in fp32 only, so half tensors are converted at this seam: same call, same in-place
+semantics, fp32 arithmetic inside (at least as accurate as the half kernels; the table gradient in particular is accumulated in fp32
+instead of with half atomics).
+"""
 import torch
 
 from ..lib import check, current_stream, lib, ptr
 
+_F = torch.float32
+
+
+def _f32(t):
+    return t if t is None or t.dtype == _F else t.float()
+
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
-    if embeddings.dtype != torch.float32:
-        raise RuntimeError("grid_encode_forward: only float32 embeddings are built (reference inference is fp32)")
-    check(lib().gf_grid_encode_forward(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
-                                       ptr(outputs, torch.float32), B, D, C, L, float(S), H,
-                                       ptr(dy_dx, torch.float32, allow_none=True), gridtype, int(bool(align_corners)), interp,
+    if embeddings.dtype not in (_F, torch.float16):
+        raise RuntimeError(f"grid_encode_forward: embeddings must be float32 or float16, got {embeddings.dtype}")
+    half = embeddings.dtype != _F
+    out = torch.empty(outputs.shape, dtype=_F, device=outputs.device) if half else outputs
+    dx = (torch.empty(dy_dx.shape, dtype=_F, device=dy_dx.device) if half else dy_dx) if dy_dx is not None else None
+    x, e = _f32(inputs).contiguous(), _f32(embeddings)     # named: a converted copy must outlive the launch
+    check(lib().gf_grid_encode_forward(ptr(x, _F), ptr(e, _F), ptr(offsets, torch.int32), ptr(out, _F),
+                                       B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True), gridtype, int(bool(align_corners)), interp,
                                        current_stream(inputs.device)))
+    if half:
+        outputs.copy_(out)
+        if dy_dx is not None:
+            dy_dx.copy_(dx)
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
-    check(lib().gf_grid_encode_backward(ptr(grad, torch.float32), ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(offsets, torch.int32),
-                                        ptr(grad_embeddings, torch.float32), B, D, C, L, float(S), H, ptr(dy_dx, torch.float32, allow_none=True),
-                                        ptr(grad_inputs, torch.float32, allow_none=True), gridtype, int(bool(align_corners)), interp,
-                                        current_stream(grad.device)))
+    half = grad_embeddings.dtype != _F
+    g_emb = torch.zeros(grad_embeddings.shape, dtype=_F, device=grad_embeddings.device) if half else grad_embeddings
+    g_in = (torch.zeros(grad_inputs.shape, dtype=_F, device=grad_inputs.device) if grad_inputs.dtype != _F else grad_inputs) \
+        if grad_inputs is not None else None
+    g, x, e, dx = _f32(grad).contiguous(), _f32(inputs).contiguous(), _f32(embeddings), _f32(dy_dx)
+    check(lib().gf_grid_encode_backward(ptr(g, _F), ptr(x, _F), ptr(e, _F),
+                                        ptr(offsets, torch.int32), ptr(g_emb, _F), B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True),
+                                        ptr(g_in, _F, allow_none=True), gridtype, int(bool(align_corners)), interp, current_stream(grad.device)))
+    if half:
+        grad_embeddings.add_(g_emb)           # the reference accumulates into the caller's (zero-filled) buffer
+    if grad_inputs is not None and g_in is not grad_inputs:
+        grad_inputs.copy_(g_in)
 
 
 def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
-    check(lib().gf_grad_total_variation(ptr(inputs, torch.float32), ptr(embeddings, torch.float32), ptr(grad, torch.float32),
-                                        ptr(offsets, torch.int32), float(weight), B, D, C, L, float(S), H, gridtype, int(align_corners),
-                                        current_stream(inputs.device)))
+    half = grad.dtype != _F
+    g = torch.zeros(grad.shape, dtype=_F, device=grad.device) if half else grad
+    x, e = _f32(inputs).contiguous(), _f32(embeddings)
+    check(lib().gf_grad_total_variation(ptr(x, _F), ptr(e, _F), ptr(g, _F), ptr(offsets, torch.int32),
+                                        float(weight), B, D, C, L, float(S), H, gridtype, int(align_corners), current_stream(inputs.device)))
+    if half:
+        grad.add_(g)

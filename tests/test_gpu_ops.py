@@ -214,3 +214,36 @@ def test_fused_lookup_equals_generic_operator(D, desired, gridtype, interp):
     torch.cuda.synchronize()
     assert (out - ref).abs().max().item() <= 1e-6
     assert B > 2_000_000   # the wrap cases were generated
+
+
+def test_grid_encoder_seam_accepts_half_tables_like_the_reference_under_autocast():
+    """grid.py:41-44 hands the backend half tables / outputs / dy_dx / gradients under autocast (the May config's amp: true).  The compat
+    module converts at the seam and computes in fp32; checked against the fp32 call, and against the reference's own half kernels when
+    oracle/_ref is present."""
+    from geneface_amd.compat import _gridencoder
+    hp, sd = model_fixture(False)
+    B = 20000
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, generator=g).to(DEV)
+    emb, off = sd["position_embedder.embeddings"].to(DEV), sd["position_embedder.offsets"].to(DEV)
+    S = float(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    o32, d32 = torch.empty(16, B, 2, device=DEV), torch.empty(B, 96, device=DEV)
+    _gridencoder.grid_encode_forward(x, emb, off, o32, B, 3, 2, 16, S, 16, d32, 1, False, 0)
+    eh = emb.half()
+    o16, d16 = torch.empty(16, B, 2, device=DEV, dtype=torch.float16), torch.empty(B, 96, device=DEV, dtype=torch.float16)
+    _gridencoder.grid_encode_forward(x, eh, off, o16, B, 3, 2, 16, S, 16, d16, 1, False, 0)
+    assert (o16.float() - o32).abs().max() < 2e-3 and torch.isfinite(d16).all()
+    grad = torch.randn(16, B, 2, generator=g).to(DEV)
+    ge32, gi32 = torch.zeros_like(emb), torch.zeros(B, 3, device=DEV)
+    _gridencoder.grid_encode_backward(grad, x, emb, off, ge32, B, 3, 2, 16, S, 16, d32, gi32, 1, False, 0)
+    ge16, gi16 = torch.zeros_like(eh), torch.zeros(B, 3, device=DEV, dtype=torch.float16)
+    _gridencoder.grid_encode_backward(grad.half(), x, eh, off, ge16, B, 3, 2, 16, S, 16, d16, gi16, 1, False, 0)
+    assert (ge16.float() - ge32).abs().max() < 2e-2 * max(1.0, float(ge32.abs().max()))
+    assert (gi16.float() - gi32).abs().max() < 2e-2 * max(1.0, float(gi32.abs().max()))
+    from oracle import ref_kernels
+    if ref_kernels.available("fast"):
+        GE = ref_kernels.load("fast")[1]
+        r16 = torch.empty(16, B, 2, device=DEV, dtype=torch.float16)
+        GE.grid_encode_forward(x, eh, off, r16, B, 3, 2, 16, S, 16, None, 1, False, 0)
+        torch.cuda.synchronize()
+        assert (o16.float() - r16.float()).abs().max() < 4e-3          # the reference rounds every corner product to half
