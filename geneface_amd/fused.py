@@ -195,7 +195,13 @@ class FusedState:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             off = lib().gf_frame_ctrl_offset(n_rays)
             ctrl = buf[off:off + 4 * lib().gf_frame_ctrl_words()].view(torch.int32)
+            # a viewer with dynamic resolution asks for many ray counts: keep the most recent few (frames in flight use <= 4 slots of
+            # ONE size, each allocated and used on its own stream, so a dropped buffer is only recycled behind its last launch)
+            while len(self._ws) >= 12:
+                self._ws.pop(next(iter(self._ws)))
             self._ws[key] = (buf, ctrl)
+        else:
+            self._ws[key] = self._ws.pop(key)      # most recently used last
         return self._ws[key]
 
 
