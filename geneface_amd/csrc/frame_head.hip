@@ -479,44 +479,53 @@ __device__ __forceinline__ void wpipe16_refill(WPipe16& wp, const char* __restri
 }
 
 // Hb = &H16[lane & 31][8 * (lane >> 5)]: tile t is 32 rows further, group u sixteen halves further.
-template <int NT, int G0, int U, int u, int RS>
+// The tile count nt (1..4, wave-uniform, an SGPR) is a RUN-TIME bound here, unlike the strict path's NT template parameter: one
+// instantiation means one instruction selection for every fp32 -> f16 conversion and fma, so a sample's result does not depend on
+// how full the round it happens to land in is.  (With four instantiations the frames differed from run to run in a few
+// hundredths of a percent of the pixels: the dynamic ray queue decides which instantiation evaluates which sample.)
+template <int G0, int U, int u, int RS>
 __device__ __forceinline__ void obw16_step(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4],
-                                           const half8 (&b)[NT]) {
+                                           const half8 (&b)[4], int nt) {
     if constexpr (u < U) {
-        half8 bn[NT];
+        half8 bn[4];
         if constexpr (u + 1 < U) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) bn[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS + 16 * (u + 1));
+            for (int t = 0; t < 4; t++)
+                if (t < nt) bn[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS + 16 * (u + 1));
             __builtin_amdgcn_sched_barrier(0);
         }
         const half8 a = wpipe16_take<G0 + u>(wp);
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; t++)
+            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
         wpipe16_refill<G0 + u>(wp, Ws, lane16);
         __builtin_amdgcn_sched_barrier(0);
-        obw16_step<NT, G0, U, u + 1, RS>(wp, Ws, lane16, Hb, acc, bn);
+        obw16_step<G0, U, u + 1, RS>(wp, Ws, lane16, Hb, acc, bn, nt);
     }
 }
-template <int NT, int G0, int U, int RS = kHS16>
-__device__ __forceinline__ void obw16_mfma(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4]) {
-    half8 b[NT];
+template <int G0, int U, int RS = kHS16>
+__device__ __forceinline__ void obw16_mfma(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4], int nt) {
+    half8 b[4];
 #pragma unroll
-    for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS);
+    for (int t = 0; t < 4; t++)
+        if (t < nt) b[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS);
     __builtin_amdgcn_sched_barrier(0);
-    obw16_step<NT, G0, U, 0, RS>(wp, Ws, lane16, Hb, acc, b);
+    obw16_step<G0, U, 0, RS>(wp, Ws, lane16, Hb, acc, b, nt);
 }
 
 // Hw = &H16[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves (one ds_write_b64)
-template <int NT, bool RELU>
-__device__ __forceinline__ void obw16_store(_Float16* Hw, const floatx16 (&acc)[4]) {
+template <bool RELU>
+__device__ __forceinline__ void obw16_store(_Float16* Hw, const floatx16 (&acc)[4], int nt) {
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int t = 0; t < 4; t++)
+        if (t < nt) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-            if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-            const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            *reinterpret_cast<half4*>(Hw + t * 32 * kHS16 + 8 * q) = h;
+            for (int q = 0; q < 4; q++) {
+                float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+                const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<half4*>(Hw + t * 32 * kHS16 + 8 * q) = h;
+            }
         }
 }
 
@@ -556,11 +565,10 @@ __device__ __forceinline__ void store16h(_Float16* dst, const float (&f)[16]) {
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
+__device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
-    const bool tile_on = wave < NT;
+    const bool tile_on = wave < nt;
     const bool valid = sI < Mv;
     const uint32_t sC = valid ? sI : (uint32_t)(wave * 32);
     const uint32_t raw = tile_on ? s.d2r[sC] : 0u;
@@ -603,21 +611,21 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(8);
     // ---- ambient L1 (cond_feat folded into the bias)
-    obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
-    obw16_mfma<NT, gf::H16_AMB1, 2, kFS16>(wp, Ws, lane16, Fb, A);
+    obw_bias<4>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
+    obw16_mfma<gf::H16_AMB1, 2, kFS16>(wp, Ws, lane16, Fb, A, nt);
     GF_STAMP(9);
     GF_STAMP(10);
-    obw16_store<NT, true>(Hw, A);          // H is not read by this layer: no barrier before the write-back
+    obw16_store<true>(Hw, A, nt);          // H is not read by this layer: no barrier before the write-back
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
     // ---- ambient L2
-    obw_zero<NT>(A);
-    obw16_mfma<NT, gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A);
+    obw_zero<4>(A);
+    obw16_mfma<gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(13);
     __syncthreads();
     GF_STAMP(14);
-    obw16_store<NT, true>(Hw, A);
+    obw16_store<true>(Hw, A, nt);
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
@@ -635,23 +643,23 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(18);
     // ---- density L1: [3-D features (F3) | 2-D features (H)]
-    obw_zero<NT>(A);
-    obw16_mfma<NT, gf::H16_SIG1A, 2, kFS16>(wp, Ws, lane16, Fb, A);
-    obw16_mfma<NT, gf::H16_SIG1B, 2>(wp, Ws, lane16, Hb, A);
+    obw_zero<4>(A);
+    obw16_mfma<gf::H16_SIG1A, 2, kFS16>(wp, Ws, lane16, Fb, A, nt);
+    obw16_mfma<gf::H16_SIG1B, 2>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(19);
     __syncthreads();
     GF_STAMP(20);
-    obw16_store<NT, true>(Hw, A);
+    obw16_store<true>(Hw, A, nt);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
     // ---- density L2
-    obw_zero<NT>(A);
-    obw16_mfma<NT, gf::H16_SIG2, 8>(wp, Ws, lane16, Hb, A);
+    obw_zero<4>(A);
+    obw16_mfma<gf::H16_SIG2, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(23);
     __syncthreads();
     GF_STAMP(24);
-    obw16_store<NT, true>(Hw, A);
+    obw16_store<true>(Hw, A, nt);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -662,21 +670,21 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         rows_from_lds16<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
         sigma = expf(h0[0]);
     }
-    obw_zero<NT>(A);
-    obw16_mfma<NT, gf::H16_SIG3, 8>(wp, Ws, lane16, Hb, A);
+    obw_zero<4>(A);
+    obw16_mfma<gf::H16_SIG3, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(27);
     __syncthreads();
     GF_STAMP(28);
-    obw16_store<NT, false>(Hw, A);
+    obw16_store<false>(Hw, A, nt);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
-    obw_bias<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
+    obw_bias<4>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
     {
-        half8 shb[NT];
+        half8 shb[4];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
+        for (int t = 0; t < 4; t++) {
             uint32_t d = (uint32_t)(t * 32 + j);
             d = d < Mv ? d : Mv - 1u;
             const uint32_t slot = s.rrank[d];
@@ -684,15 +692,16 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         }
         const half8 w8 = wpipe16_take<gf::H16_COL1S>(wp);
 #pragma unroll
-        for (int t = 0; t < NT; t++) A[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8, shb[t], A[t], 0, 0, 0);
+        for (int t = 0; t < 4; t++)
+            if (t < nt) A[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8, shb[t], A[t], 0, 0, 0);
         wpipe16_refill<gf::H16_COL1S>(wp, Ws, lane16);
         __builtin_amdgcn_sched_barrier(0);
     }
-    obw16_mfma<NT, gf::H16_COL1G, 8>(wp, Ws, lane16, Hb, A);
+    obw16_mfma<gf::H16_COL1G, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(31);
     __syncthreads();
     GF_STAMP(32);
-    obw16_store<NT, true>(Hw, A);
+    obw16_store<true>(Hw, A, nt);
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
@@ -877,10 +886,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             GF_STAMP(6);
             const uint32_t nt = (Mv + 31) / 32;
             if constexpr (FAST) {
-                if (nt == 4) field_round16<4>(a, s, Mv, wave, lane);
-                else if (nt == 3) field_round16<3>(a, s, Mv, wave, lane);
-                else if (nt == 2) field_round16<2>(a, s, Mv, wave, lane);
-                else field_round16<1>(a, s, Mv, wave, lane);
+                field_round16(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
             } else {
                 if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
                 else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);

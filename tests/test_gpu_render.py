@@ -469,3 +469,30 @@ def test_fast_tier_edge_cases():
     _, _, m = _fast_model(True)
     ref = R.render(sd, hp, fi_r["rays_o"], fi_r["rays_d"], fi_r["cond"], fi_r["bg_coords"], fi_r["pose6"], fi_r["bg"], True)
     _check_fast(render_gpu(m, hp, fi_r), ref)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
+def test_frames_in_flight_do_not_interfere(in_flight, precision):
+    """Several frames enqueued on separate streams share the model, the packed weights and the tables but nothing else (one workspace,
+    one set of output buffers and one pinned host buffer per slot).  A pattern of four different frames rendered five times over through
+    FramePipeline.stream must reproduce, bit for bit, what each frame gives alone."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(True, "fused")
+    model.render_precision = precision
+    seq = sequence(4, 160, 160)
+    solo = FramePipeline(model, hp, seq, DEV, impl="fused", overlap=False)
+    want = []
+    for i in range(4):
+        f = solo.render_frame(i)
+        solo.wait()
+        want.append(f.clone())
+    assert not torch.equal(want[0], want[1])
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused", in_flight=in_flight)
+    order = [0, 1, 2, 3, 3, 1, 0, 2] * 5
+    got = 0
+    for (i, frame), k in zip(pipe.stream(order), order):
+        assert i == k
+        assert np.array_equal(frame, want[k].numpy()), (in_flight, precision, got)
+        got += 1
+    assert got == len(order)
