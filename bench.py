@@ -108,7 +108,6 @@ def legacy_nerf_baseline(seq, rays=4096):
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
 

@@ -8,7 +8,6 @@ stream with no host synchronisation (the reference's loop, renderer.py:316-351, 
 Per-model state (packed weights, fold matrices, workspace) is built once and cached on the module.
 """
 import ctypes as C
-import math
 
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ The GPU bench launches the same code with backend nccl (= RCCL); nothing here ne
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

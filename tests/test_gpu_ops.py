@@ -177,7 +177,6 @@ def test_fused_lookup_equals_generic_operator(D, desired, gridtype, interp):
     """grid_core.hpp::encode8 (what the fused head kernel evaluates: per-level strides / mask / hash flag instead of the
     generic stride walk + integer modulo) against the generic operator on 2 M random points PLUS points constructed to sit
     in the last row of a wrapped level, where the x-neighbour wraps to row 0 (index & mask == mask)."""
-    import ctypes as C
     from geneface_amd.encoders.gridencoder import grid_offsets, per_level_scale_for
     from geneface_amd.lib import check, current_stream, lib, ptr
     L, Hres, log2 = 16, 16, 16

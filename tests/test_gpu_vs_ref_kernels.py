@@ -17,7 +17,6 @@ import json
 import os
 
 import pytest
-import torch
 
 import ref_kernels_report as RR
 from oracle import ref_kernels

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import frame_inputs, model_fixture, sequence
+from helpers import model_fixture, sequence
 from oracle import radnerf_ref as R
 from oracle import refshim
 
