@@ -22,6 +22,14 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch=
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 
 
+# Per-file flags.  frame_head.hip is built WITHOUT the SLP vectoriser, i.e. without packed-FP32 VALU instructions (v_pk_fma_f32 /
+# v_pk_mul_f32): in k_head_phase<true> the low half of one v_pk_fma_f32 of the 2-D grid lookup -- the one fed by a broadcast-form
+# v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,1] -- intermittently lost its product in lanes 32..63 whenever two workgroups shared a CU
+# (tools/fast_diag.py).  Scalar FMAs compute the same values (the packed form was only ever two independent FMAs) at the
+# same measured frame rate (fp32 719 vs 717 fps, fast tier 1890 vs 1845 fps, interleaved A/B on one box).
+PER_FILE = {"frame_head.hip": ("-fno-slp-vectorize",)}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.cpp")))
 
@@ -35,7 +43,8 @@ def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
     newest = max(os.path.getmtime(p) for p in [src, __file__, *headers()])
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC, *COMMON, *extra, "-x", "hip", "-c", src, "-o", obj, "-I", HERE, "-I", os.path.join(HERE, "..", "..", "include")]
+    cmd = [HIPCC, *COMMON, *PER_FILE.get(os.path.basename(src), ()), *extra, "-x", "hip", "-c", src, "-o", obj, "-I", HERE,
+           "-I", os.path.join(HERE, "..", "..", "include")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

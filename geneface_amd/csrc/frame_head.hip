@@ -69,6 +69,24 @@ static unsigned long long* g_span_buf = nullptr;
 #define GF_STAMP(i) do { } while (0)
 #endif
 
+// ---- optional per-sample record (built only with -DGF_DIAG into libgeneface_hip_diag.so; see tools/fast_diag.py) ----
+// One record per composited sample, keyed by (ray, cumulative sample index): lets two renders of the same frame be compared
+// quantity by quantity (marcher -> grid features -> ambient -> density -> colour -> compositor inputs).
+#ifdef GF_DIAG
+constexpr int kDiagWords = 60;
+// 0 sigma 1 r 2 g 3 b 4 dt 5 t_after 6 tag 7 workgroup 8 round 9 dense index 10 Mv 11 n_pool<<8|n
+// 12 ambient0 13 ambient1 14 h0 15 x 16 checksum(3-D features as stored) 17 checksum(2-D features as stored) 18 phase 19 raw slot
+// 20 x2[0] 21 x2[1] 22 sum of the fp32 2-D features 23 HW_ID 24, 25 exp(-2 ambient) (fast kernel)
+// 26..57 the 32 fp32 2-D features [level][channel] (fast kernel) 58 XCC_ID
+#endif
+
+#ifdef GF_DIAG
+struct DiagReg { const void* ws; float* buf; uint32_t stride, last_tag; };
+static DiagReg g_diag_reg[8] = {};
+static uint32_t g_diag_tag = 0;
+static uint32_t g_diag_cfg[4] = {0, 0, 0, 0};   // start poison, per-round poison, grid override, pool-cap override
+#endif
+
 struct HeadArgs {
     gf::MarchParams mp;
     gf::GridLevels lv3, lv2;
@@ -87,6 +105,10 @@ struct HeadArgs {
     uint32_t* trace;
     unsigned long long* spans;   // [2 phases][512 workgroups][start tick, end tick, rounds, XCC id]
 #endif
+#ifdef GF_DIAG
+    float* diag;                 // [N][diag_stride][kDiagWords] per-sample record, or NULL
+    uint32_t diag_tag, diag_stride, poison, poison_round, pool_cap_override;
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------------- LDS carve
@@ -102,10 +124,15 @@ struct Smem {
 #ifdef GF_TRACE
     uint32_t* tr;    // [kTraceSlots]
 #endif
+#ifdef GF_DIAG
+    uint32_t* dkey;  // [kPass] record index of the sample in raw slot r (0xFFFFFFFF: none)
+#endif
 };
 constexpr int kSmemBase = (kPass * kHS + kPFloats + 3 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
-#ifdef GF_TRACE
+#if defined(GF_TRACE)
 constexpr int kSmemBytes = kSmemBase + 4 * kTraceSlots;
+#elif defined(GF_DIAG)
+constexpr int kSmemBytes = kSmemBase + 4 * kPass;
 #else
 constexpr int kSmemBytes = kSmemBase;
 #endif
@@ -124,6 +151,9 @@ __device__ __forceinline__ Smem carve(char* base) {
     s.d2r = b; s.rcnt = b + kPass; s.rbase = b + 2 * kPass; s.rrank = b + 3 * kPass;
 #ifdef GF_TRACE
     s.tr = reinterpret_cast<uint32_t*>(b + 4 * kPass);
+#endif
+#ifdef GF_DIAG
+    s.dkey = reinterpret_cast<uint32_t*>(b + 4 * kPass);
 #endif
     return s;
 }
@@ -301,6 +331,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
 #define GF_PRIO_HI() do { } while (0)
 #define GF_PRIO_LO() do { } while (0)
 #endif
+#ifdef GF_DIAG
+    uint32_t dkey = 0xFFFFFFFFu;
+#endif
     floatx16 A[4], S[4];
     WPipe wp;
 #pragma unroll
@@ -313,6 +346,13 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         float pf[16];
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16(Hrow + 16 * half, pf);
+#ifdef GF_DIAG
+        dkey = valid ? s.dkey[raw] : 0xFFFFFFFFu;
+        float c = 0.0f;
+        for (int i = 0; i < 16; i++) c += pf[i];
+        c += __shfl_xor(c, 32);
+        if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 16] = c;
+#endif
     }
     GF_STAMP(7);
     __syncthreads();
@@ -351,6 +391,17 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16(Hrow + 16 * half, af);
+#ifdef GF_DIAG
+        float c = 0.0f;
+        for (int i = 0; i < 16; i++) c += af[i];
+        c += __shfl_xor(c, 32);
+        if (a.diag && dkey != 0xFFFFFFFFu && half == 0) {
+            float* rec = a.diag + (size_t)dkey * kDiagWords;
+            rec[12] = ambient[0]; rec[13] = ambient[1]; rec[17] = c;
+            rec[20] = x2[0]; rec[21] = x2[1]; rec[22] = c;
+            reinterpret_cast<uint32_t*>(rec)[23] = __builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */);
+        }
+#endif
     }
     GF_STAMP(17);
     __syncthreads();
@@ -384,6 +435,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         float h0[1];
         rows_from_lds<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
         sigma = expf(h0[0]);
+#ifdef GF_DIAG
+        if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 14] = h0[0];
+#endif
     }
     GF_PRIO_LO();
     obw_zero<NT>(A);
@@ -594,6 +648,9 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
         store16h(SHT + slot * 16, sh);
     }
+#ifdef GF_DIAG
+    uint32_t dkey = 0xFFFFFFFFu;
+#endif
     floatx16 A[4];
     WPipe16 wp;
 #pragma unroll
@@ -606,6 +663,13 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         float pf[16];
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16h(Frow + 16 * half, pf);
+#ifdef GF_DIAG
+        dkey = valid ? s.dkey[raw] : 0xFFFFFFFFu;
+        float c = 0.0f;
+        for (int i = 0; i < 16; i++) c += (float)(_Float16)pf[i];
+        c += __shfl_xor(c, 32);
+        if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 16] = c;
+#endif
     }
     GF_STAMP(7);
     __syncthreads();
@@ -634,10 +698,27 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         float ambient[2];
         rows_from_lds16<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
         // (tanh(v) + 1) / 2 = 1 / (1 + exp(-2 v))
-        const float x2[2] = {1.0f / (1.0f + __expf(-2.0f * ambient[0])), 1.0f / (1.0f + __expf(-2.0f * ambient[1]))};
+        const float e2[2] = {__expf(-2.0f * ambient[0]), __expf(-2.0f * ambient[1])};
+        const float x2[2] = {1.0f / (1.0f + e2[0]), 1.0f / (1.0f + e2[1])};
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16h(Hrow + 16 * half, af);
+#ifdef GF_DIAG
+        float c = 0.0f, cf = 0.0f;
+        for (int i = 0; i < 16; i++) { c += (float)(_Float16)af[i]; cf += af[i]; }
+        c += __shfl_xor(c, 32);
+        cf += __shfl_xor(cf, 32);
+        if (a.diag && dkey != 0xFFFFFFFFu) {
+            float* rec = a.diag + (size_t)dkey * kDiagWords;
+            for (int i = 0; i < 16; i++) rec[26 + 16 * half + i] = af[i];
+            if (half == 0) {
+                rec[12] = ambient[0]; rec[13] = ambient[1]; rec[17] = c;
+                rec[20] = x2[0]; rec[21] = x2[1]; rec[22] = cf; rec[24] = e2[0]; rec[25] = e2[1];
+                reinterpret_cast<uint32_t*>(rec)[23] = __builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */);
+                reinterpret_cast<uint32_t*>(rec)[58] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID */);
+            }
+        }
+#endif
     }
     GF_STAMP(17);
     __syncthreads();
@@ -669,6 +750,9 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         float h0[1];
         rows_from_lds16<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
         sigma = expf(h0[0]);
+#ifdef GF_DIAG
+        if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 14] = h0[0];
+#endif
     }
     obw_zero<4>(A);
     obw16_mfma<gf::H16_SIG3, 8>(wp, Ws, lane16, Hb, A, nt);
@@ -755,7 +839,19 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     // every ray up to 8 samples per round instead of walking 128 rays through B - max_steps rounds on a handful of CUs.
     uint32_t pool_cap = (limit + gridDim.x - 1) / gridDim.x;
     pool_cap = pool_cap < 16u ? 16u : (pool_cap > (uint32_t)kPool ? (uint32_t)kPool : pool_cap);
+#ifdef GF_DIAG
+    if (a.pool_cap_override) pool_cap = a.pool_cap_override;
+#endif
     if ((uint32_t)blockIdx.x * pool_cap >= limit) return;  // not even one refill's worth of work for this workgroup
+#ifdef GF_DIAG
+    if (a.poison) {   // any read of LDS this workgroup has not written itself now returns NaN (fp32 and f16 views alike)
+        __syncthreads();
+        uint32_t* w = reinterpret_cast<uint32_t*>(smem_raw);
+        for (int i = tid; i < kSmemBytes / 4; i += kThreads) w[i] = a.poison;
+        __syncthreads();
+    }
+    uint32_t dg_round = 0;
+#endif
 
     for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
     if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
@@ -784,6 +880,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     for (;;) {
         __syncthreads();  // previous round fully retired (staging, H)
         GF_STAMP(0);
+#ifdef GF_DIAG
+        if (a.poison_round) {   // nothing in the activation buffer is live between rounds
+            uint32_t* w = reinterpret_cast<uint32_t*>(s.H);
+            for (int i = tid; i < kPass * kHS; i += kThreads) w[i] = a.poison_round;
+            __syncthreads();
+        }
+        dg_round++;
+#endif
         // ------------------------------------------------------------------ refill empty pool slots from the queue
         if (queue_open && wave < 2) {  // wave-uniform branch
             const bool want = ray < 0 && (uint32_t)tid < pool_cap;
@@ -851,6 +955,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                                 [&](uint32_t q, float x, float y, float z, float dt, float t_after, float) {
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
                                     s.sdt[base + q] = dt; s.st[base + q] = t_after;
+#ifdef GF_DIAG
+                                    const uint32_t k = (a.phase ? a.max_steps : 0u) + r_done + q;
+                                    uint32_t key = 0xFFFFFFFFu;
+                                    if (a.diag && k < a.diag_stride) {
+                                        key = (uint32_t)ray * a.diag_stride + k;
+                                        float* rec = a.diag + (size_t)key * kDiagWords;
+                                        rec[15] = x; rec[4] = dt; rec[5] = t_after;
+                                        reinterpret_cast<uint32_t*>(rec)[18] = a.phase; reinterpret_cast<uint32_t*>(rec)[19] = base + q;
+                                    }
+                                    s.dkey[base + q] = key;
+#endif
                                 }, req + kMarchSlack);
         }
         GF_STAMP(3);
@@ -903,6 +1018,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             uint32_t d = 0;
             for (uint32_t q = 0; q < cnt; q++) {
                 r_done++;
+#ifdef GF_DIAG
+                if (a.diag && s.dkey[base + q] != 0xFFFFFFFFu) {
+                    float* rec = a.diag + (size_t)s.dkey[base + q] * kDiagWords;
+                    uint32_t* ru = reinterpret_cast<uint32_t*>(rec);
+                    rec[0] = s.sx[base + q]; rec[1] = s.sy[base + q]; rec[2] = s.sz[base + q]; rec[3] = s.ob[base + q];
+                    ru[6] = a.diag_tag; ru[7] = blockIdx.x; ru[8] = dg_round; ru[9] = (uint32_t)s.rbase[tid] + q; ru[10] = Mv;
+                    ru[11] = (n_pool << 8) | n;
+                }
+#endif
                 if (!gf::composite_sample(acc, s.sx[base + q], s.sy[base + q], s.sz[base + q], s.ob[base + q], s.sdt[base + q], s.st[base + q], a.T_thresh)) {
                     died = true;  // T < T_thresh: terminates at this sample (raymarching.cu:1004)
                     d = r_done;
@@ -1109,6 +1233,12 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.trace = g_trace_buf;
     ha.spans = g_span_buf;
 #endif
+#ifdef GF_DIAG
+    ha.diag = nullptr; ha.diag_stride = 0; ha.diag_tag = ++g_diag_tag;
+    for (auto& e : g_diag_reg)
+        if (e.ws == f->workspace) { ha.diag = e.buf; ha.diag_stride = e.stride; e.last_tag = ha.diag_tag; }
+    ha.poison = g_diag_cfg[0]; ha.poison_round = g_diag_cfg[1]; ha.pool_cap_override = g_diag_cfg[3];
+#endif
 
     const bool fast = f->precision == 1;
     ha.head_pack16 = f->head_pack16;
@@ -1124,6 +1254,9 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     uint32_t grid = pools < 512u ? pools : 512u;
 #ifdef GF_TRACE
     if (const char* e = getenv("GF_HEAD_GRID")) { const uint32_t g = (uint32_t)atoi(e); if (g >= 1 && g <= 512) grid = g; }   // timeline experiments
+#endif
+#ifdef GF_DIAG
+    if (g_diag_cfg[2] >= 1 && g_diag_cfg[2] <= 512) grid = g_diag_cfg[2];
 #endif
     for (uint32_t phase = 0; phase < 2; phase++) {
         ha.phase = phase;
@@ -1144,6 +1277,20 @@ GF_EXPORT void gf_trace_set(void* dev_buf) { g_trace_buf = reinterpret_cast<uint
 // device buffer of 2 * 512 * 4 uint64: per phase and workgroup {start tick, end tick, rounds, XCC id}
 GF_EXPORT void gf_trace_set_spans(void* dev_buf) { g_span_buf = reinterpret_cast<unsigned long long*>(dev_buf); }
 GF_EXPORT uint32_t gf_trace_dims(uint32_t which) { return which == 0 ? kTraceWGs : which == 1 ? kTraceRounds : kTraceSlots; }
+#endif
+
+#ifdef GF_DIAG
+// diag build only: per-sample records of the frames rendered into `workspace` go to `dev_buf` ([n_rays][stride][gf_diag_words()] words)
+GF_EXPORT int gf_diag_register(uint32_t slot, const void* workspace, void* dev_buf, uint32_t stride) {
+    if (slot >= 8) return -1;
+    g_diag_reg[slot] = {workspace, reinterpret_cast<float*>(dev_buf), stride, 0};
+    return 0;
+}
+GF_EXPORT uint32_t gf_diag_last_tag(uint32_t slot) { return slot < 8 ? g_diag_reg[slot].last_tag : 0; }
+GF_EXPORT uint32_t gf_diag_words(void) { return kDiagWords; }
+GF_EXPORT void gf_diag_config(uint32_t poison, uint32_t poison_round, uint32_t grid, uint32_t pool_cap) {
+    g_diag_cfg[0] = poison; g_diag_cfg[1] = poison_round; g_diag_cfg[2] = grid; g_diag_cfg[3] = pool_cap;
+}
 #endif
 
 GF_EXPORT uint64_t gf_frame_workspace_bytes(uint32_t n_rays) { return gf::carve_workspace(reinterpret_cast<void*>(uintptr_t(1) << 20), n_rays).bytes; }

@@ -113,6 +113,9 @@ class FusedState:
             self.torso_S = float(np.log2(model.torso_embedder.per_level_scale))
         self._ws = {}
         self.cond = self._build_cond(model)
+        # everything above is a COPY of (or a raw pointer into) model state: remember what it was built from (see get_state)
+        self._watch = _watched_tensors(model)
+        self.stamp = _stamp(self._watch)
 
     def pack16(self, model):
         """f16 A-operand streams of the head's six MFMA layers (gf_frame_t.precision = 1, the "fast" parity tier)."""
@@ -204,16 +207,35 @@ class FusedState:
         return self._ws[key]
 
 
+def _watched_tensors(model):
+    """Every tensor a FusedState copies from or points into: all parameters (MLP weights are repacked, the condition encoder's and the
+    tables' device pointers are handed to the kernels) and the occupancy buffers (the march box is derived from the bitfield)."""
+    t = list(model.parameters())
+    for name in ("density_bitfield", "aabb_infer", "density_grid_torso"):
+        if getattr(model, name, None) is not None:
+            t.append(getattr(model, name))
+    return t
+
+
+def _stamp(tensors):
+    # in-place updates (optimizer steps, load_state_dict, broadcast, update_extra_state) bump _version; .half() / .to() / `p.data = ...`
+    # change data_ptr.  ~10 us for the ~45 tensors of a head+torso model.
+    return tuple((t._version, t.data_ptr()) for t in tensors)
+
+
 def get_state(model) -> FusedState:
+    """The model's FusedState, rebuilt whenever a tensor it was packed from has changed since (train -> validate loops,
+    load_state_dict, broadcast_model_, dtype / device moves): the packed copies can never go stale silently."""
     st = getattr(model, "_fused_state", None)
-    if st is None or st.device != model.density_bitfield.device:
+    if st is None or st.device != model.density_bitfield.device or _stamp(st._watch) != st.stamp:
         st = FusedState(model)
         object.__setattr__(model, "_fused_state", st)
     return st
 
 
 def invalidate(model):
-    """Call after changing weights (the packed copies are rebuilt on the next render)."""
+    """Drop the packed copies now (they are rebuilt on the next render).  Not required for correctness -- get_state notices changed
+    tensors by itself -- but frees the workspaces and packs early."""
     if hasattr(model, "_fused_state"):
         object.__delattr__(model, "_fused_state")
 

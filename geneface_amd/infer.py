@@ -42,6 +42,9 @@ def broadcast_model_(model: torch.nn.Module, src: int = 0):
                 n = t.numel()
                 t.copy_(flat[off:off + n].view_as(t))
                 off += n
+    if hasattr(model, "_fused_state"):      # packed copies of the old weights (get_state would notice as well; drop them now)
+        from .fused import invalidate
+        invalidate(model)
     return model
 
 
@@ -67,7 +70,8 @@ class FramePipeline:
         self.bg = torch.from_numpy(np.ascontiguousarray(seq["bg_img"])).float().view(1, -1, 3).to(dev)
         self.bg_coords = utils.get_bg_coords(self.H, self.W, dev)
         # frames enqueued concurrently (streams, frame slots, host buffers).  Measured optimum on MI355X: three for the strict fp32
-        # head kernel (its persistent grid drains slowly: 701 -> 724 fps over two), two for the fast tier (more only adds contention)
+        # head kernel (its persistent grid drains slowly: 701 -> 724 fps over two), two for the fast tier (more only adds contention).
+        # Any count gives the same bytes on both tiers (tests/test_gpu_render.py::test_frames_in_flight_do_not_interfere).
         if in_flight is None:
             in_flight = 2 if getattr(model, "render_precision", "fp32") == "fast" else 3
         self.in_flight = max(1, int(in_flight)) if overlap else 1

@@ -51,18 +51,23 @@ def decode_rgb8(data: bytes) -> np.ndarray:
 class FrameWriter:
     """Writes frames as `<dir>/<idx:05d>.png` on worker threads; `close()` waits for all of them."""
 
-    def __init__(self, out_dir: str, workers: int = 4, level: int = 1):
+    def __init__(self, out_dir: str, workers: int = 4, level: int = 1, max_pending: int = None):
         os.makedirs(out_dir, exist_ok=True)
         self.out_dir, self.level = out_dir, level
         self._pool = ThreadPoolExecutor(max_workers=workers)
         self._futures = []
+        self._max_pending = max_pending or 4 * workers   # frames copied but not yet encoded: bounds host memory
 
     def _write(self, idx: int, img: np.ndarray):
         with open(os.path.join(self.out_dir, f"{idx:05d}.png"), "wb") as fh:
             fh.write(encode_rgb8(img, self.level))
 
     def submit(self, idx: int, img: np.ndarray):
-        self._futures.append(self._pool.submit(self._write, idx, np.ascontiguousarray(img)))   # copies out of the pinned buffer
+        """Takes a private copy of `img` (callers hand in views of reused pinned buffers: FramePipeline.stream) and queues the encode.
+        Blocks while `max_pending` frames are waiting, so a renderer faster than the encoders cannot grow the queue without bound."""
+        while len(self._futures) >= self._max_pending:
+            self._futures.pop(0).result()
+        self._futures.append(self._pool.submit(self._write, idx, np.array(img, dtype=np.uint8, order="C", copy=True)))
 
     def close(self):
         for f in self._futures:
