@@ -1304,6 +1304,13 @@ GF_EXPORT uint64_t gf_frame_ctrl_offset(uint32_t n_rays) {
     return (uint64_t)((char*)w.ctrl - base);
 }
 
+GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {
+    char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);
+    const gf::FrameWs w = gf::carve_workspace(base, n_rays);
+    const void* const f[10] = {w.nears, w.fars, w.rays_t, w.weights_sum, w.depth, w.image, w.rays_o, w.rays_d, w.far_occ, w.alive_b};
+    return field < 10 ? (uint64_t)((const char*)f[field] - base) : ~uint64_t(0);
+}
+
 GF_EXPORT uint64_t gf_frame_sizeof(void) { return sizeof(gf_frame_t); }
 
 // HOST: do the fused kernels support these grid tables (see grid_core.hpp, LevelMeta)?  offsets_host = GridEncoder.offsets [L+1].

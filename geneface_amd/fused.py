@@ -426,7 +426,8 @@ def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
     N = pipe.H * pipe.W
     torso = st.has_torso
     _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
-    _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], 1e-4, amb_bias, bufs.bg, bufs.rgb[slot], bufs.depth[slot], rgb8, slot)
+    _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], hp.get("T_thresh", 1e-4), amb_bias, bufs.bg, bufs.rgb[slot], bufs.depth[slot],
+                 rgb8, slot)   # the reference forwards **hparams to render(): a T_thresh key overrides the 1e-4 default (renderer.py:263)
     f.img_h, f.img_w = pipe.H, pipe.W
     f.rays_o = f.rays_d = None
     p = bufs.poses_host[i]

@@ -10,7 +10,14 @@ Keeps the reference's call surface -- `LM3d_RADNeRFInfer(hparams, ...)`, `.get_c
     (tasks/radnerfs/dataset_utils.py:40-90): AD-NeRF c2w -> ngp axes, 7-tap smoothing, focal/cx/cy, bg image.  The reference
     materialises rays for every frame up front (lm3d_radnerf_infer.py:18-32, 6 MB per frame on the GPU); here only the 3x4
     poses go to the device and rays are generated inside the kernel;
-  * frames: contiguous block per rank (base_nerf_infer.py:150-155), one weight broadcast, FramePipeline per rank;
+  * model: `build_model` = RADNeRF(Torso)Task.build_model + BaseNeRFInfer.build_nerf_task: for the torso task the head
+    checkpoint of `head_model_dir` is loaded non-strictly first (tasks/radnerfs/radnerf_torso.py:30-38), then the newest
+    `model_ckpt_steps_*.ckpt` of `work_dir` strictly (base_nerf_infer.py:72-79) -- legacy-pickle files with optimizer state
+    and numpy scalars, as the reference's Trainer writes them (geneface_amd/ckpt_utils.py);
+  * frames: `forward_system` fans out like base_nerf_infer.py:131-193: the GPU ids of CUDA_VISIBLE_DEVICES, one spawned process
+    per GPU (torch.multiprocessing.spawn, NCCL == RCCL, 127.0.0.1), contiguous block per rank (:150-155), one weight
+    broadcast instead of the DDP constructor's, every rank writes its own `<tmp_imgs_dir>/<idx:05d>.png` block, barrier,
+    rank 0 muxes.  Under torchrun (process group already initialised) the caller's rank renders its block instead;
   * output: uint8 RGB frames, returned; with `tmp_imgs_dir` in `inp` every frame is also written as `<dir>/<idx:05d>.png`
     (the files base_nerf_infer.py:97-101 produces) by worker threads, off the render thread; `out_video_name` ending in .npy
     stores the stack.  The ffmpeg mux (:307) runs only when an ffmpeg binary exists (this image has none).
@@ -21,6 +28,7 @@ import numpy as np
 import torch
 
 from . import lm3d, utils
+from .ckpt_utils import load_ckpt
 from .infer import FramePipeline, broadcast_model_, shard_range
 
 
@@ -62,7 +70,75 @@ class RADNeRFPoseSource:
         return len(self.poses)
 
 
+def _is_torso(hparams) -> bool:
+    return "torso" in str(hparams.get("task_cls", "")).lower()
+
+
+def _new_model(hparams):
+    from .radnerf import RADNeRF
+    from .radnerf_torso import RADNeRFTorso
+    return (RADNeRFTorso if _is_torso(hparams) else RADNeRF)(hparams)
+
+
+def _render_block(model, hparams, dataset, batches, device, rank, world_size, tmp_imgs_dir, pipeline_cls, collect=True):
+    """One rank's share of base_nerf_infer.py:81-106 / :131-181: identical weights everywhere (one broadcast), the rank's contiguous block
+    of frames, `<tmp_imgs_dir>/<global idx:05d>.png` per frame.  Returns (first global index, uint8 [n,H,W,3] or None)."""
+    if float(hparams.get("infer_scale_factor", 1.0)) != 1.0:
+        raise NotImplementedError("infer_scale_factor != 1.0: the frame loop renders at the dataset's resolution")
+    T = len(batches)
+    seq = {"cond_wins": np.stack([b["cond_wins"] for b in batches]).astype(np.float32),
+           "poses": np.stack([b["pose44"] for b in batches]).astype(np.float32),
+           "intrinsics": dataset.intrinsics, "bg_img": dataset.bg_img, "H": dataset.H, "W": dataset.W}
+    broadcast_model_(model, src=0)
+    lo, hi = shard_range(T, rank, world_size)
+    writer = None
+    if tmp_imgs_dir:
+        from .png import FrameWriter
+        os.makedirs(tmp_imgs_dir, exist_ok=True)
+        writer = FrameWriter(tmp_imgs_dir)
+    pipe = pipeline_cls(model, hparams, seq, device, frames=(lo, hi), impl="fused" if torch.device(device).type == "cuda" else None)
+    out = np.empty((hi - lo, dataset.H, dataset.W, 3), dtype=np.uint8) if collect else None
+    with torch.no_grad():
+        for k, frame in pipe.stream(range(hi - lo)):
+            if out is not None:
+                out[k] = frame
+            if writer is not None:
+                writer.submit(lo + k, frame)      # FrameWriter.submit copies the (reused) pinned buffer
+    if writer is not None:
+        writer.close()
+    return lo, out
+
+
+def _spawned_rank(rank, world_size, hparams, dataset, state_dict, batches, tmp_imgs_dir, pipeline_cls, use_cuda, port, block_dir):
+    """Process `rank` of forward_system's fan-out (base_nerf_infer.py:131-181): own GPU, own replica, own block of frames."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"                     # init_ddp_connection, :108-113
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if use_cuda:
+        torch.cuda.set_device(rank)
+        device = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        model = _new_model(hparams)
+        if rank == 0:
+            model.load_state_dict(state_dict, strict=True)      # the other replicas receive the weights over RCCL (broadcast_model_)
+        model = model.to(device).eval()
+        dist.barrier()
+        lo, out = _render_block(model, hparams, dataset, batches, device, rank, world_size, tmp_imgs_dir, pipeline_cls, collect=bool(block_dir))
+        if block_dir:
+            np.save(os.path.join(block_dir, f"block_{lo:07d}.npy"), out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 class LM3d_RADNeRFInfer:
+    pipeline_cls = FramePipeline    # what renders a rank's block (tests substitute a CPU stand-in)
+
     def __init__(self, hparams: dict, model: torch.nn.Module = None, dataset: RADNeRFPoseSource = None, device=None):
         self.hparams = hparams
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -70,25 +146,31 @@ class LM3d_RADNeRFInfer:
             path = os.path.join(hparams["binary_data_dir"], hparams["video_id"], "trainval_dataset.npy")
             dataset = RADNeRFPoseSource.from_file(path, hparams)
         self.dataset = dataset
+        # base_nerf_infer.py:63-69: the GPUs to use are the ids listed in CUDA_VISIBLE_DEVICES; more than one -> one process per GPU
+        self.all_gpu_ids = [int(x) for x in os.environ.get("CUDA_VISIBLE_DEVICES", "").split(",") if x != ""]
+        self.num_gpus = len(self.all_gpu_ids)
+        self.use_ddp = self.num_gpus > 1
+        self.proc_rank = 0
+        self.global_step = None
         if model is None:
             model = self.build_model()
         self.model = model.to(self.device).eval()
 
-    # ------------------------------------------------------------------ model (base_nerf_infer.py:72-79)
+    # ------------------------------------------------------------------ model (radnerf_torso.py:30-38 + base_nerf_infer.py:72-79)
     def build_model(self):
-        """RADNeRF(Torso) from the hparams + the newest `model_ckpt_steps_*.ckpt` of hparams['work_dir'] (ckpt_utils.py:7-66)."""
-        from .radnerf import RADNeRF
-        from .radnerf_torso import RADNeRFTorso
-        torso = "torso" in str(self.hparams.get("task_cls", "")).lower()
-        model = (RADNeRFTorso if torso else RADNeRF)(self.hparams)
-        work_dir = self.hparams.get("work_dir", "")
-        ckpts = sorted((f for f in os.listdir(work_dir) if f.startswith("model_ckpt_steps_") and f.endswith(".ckpt")),
-                       key=lambda f: int(f[len("model_ckpt_steps_"):-len(".ckpt")])) if os.path.isdir(work_dir) else []
-        if not ckpts:
-            raise FileNotFoundError(f"no model_ckpt_steps_*.ckpt under work_dir={work_dir!r}")
-        ck = torch.load(os.path.join(work_dir, ckpts[-1]), map_location="cpu")
-        sd = ck["state_dict"]["model"] if "state_dict" in ck and "model" in ck["state_dict"] else ck
-        model.load_state_dict(sd, strict=True)
+        """RADNeRF(Torso) from the hparams and the reference's checkpoints.  Torso task: a RADNeRF is filled from the newest checkpoint
+        of `head_model_dir` and copied in with strict=False (the torso keys stay at their init), exactly as RADNeRFTorsoTask.build_model;
+        then, for both tasks, the newest `model_ckpt_steps_*.ckpt` of `work_dir` is loaded strictly (build_nerf_task)."""
+        model = _new_model(self.hparams)
+        if _is_torso(self.hparams):
+            from .radnerf import RADNeRF
+            head_model = RADNeRF(self.hparams)
+            load_ckpt(head_model, self.hparams["head_model_dir"])
+            print(f"Loaded Head Model from {self.hparams['head_model_dir']}")
+            model.load_state_dict(head_model.state_dict(), strict=False)
+            del head_model
+        ckpt = load_ckpt(model, self.hparams["work_dir"], "model")
+        self.global_step = ckpt["global_step"]
         return model
 
     # ------------------------------------------------------------------ condition (lm3d_radnerf_infer.py:34-86)
@@ -109,33 +191,51 @@ class LM3d_RADNeRFInfer:
         return samples
 
     # ------------------------------------------------------------------ frame loop (base_nerf_infer.py:81-193)
-    def forward_system(self, batches, rank: int = 0, world_size: int = 1, writer=None):
-        """Renders this rank's contiguous block of frames -> uint8 [n, H, W, 3] (host).  With torch.distributed initialised the
-        caller passes its rank / world size; weights are made identical to rank 0's with one broadcast."""
-        T = len(batches)
-        seq = {"cond_wins": np.stack([b["cond_wins"] for b in batches]).astype(np.float32),
-               "poses": np.stack([b["pose44"] for b in batches]).astype(np.float32),
-               "intrinsics": self.dataset.intrinsics, "bg_img": self.dataset.bg_img, "H": self.dataset.H, "W": self.dataset.W}
-        broadcast_model_(self.model, src=0)
-        lo, hi = shard_range(T, rank, world_size)
-        pipe = FramePipeline(self.model, self.hparams, seq, self.device, frames=(lo, hi), impl="fused" if self.device.type == "cuda" else None)
-        out = np.empty((hi - lo, self.dataset.H, self.dataset.W, 3), dtype=np.uint8)
-        with torch.no_grad():
-            for k, frame in pipe.stream(range(hi - lo)):
-                out[k] = frame
-                if writer is not None:
-                    writer.submit(lo + k, out[k])
-        return out
+    def forward_system(self, batches, world_size: int = None, tmp_imgs_dir: str = None, collect: bool = True):
+        """base_nerf_infer.py:182-193.  Three ways in, one block partition (:150-155):
+          * a process group already exists (torchrun): this process renders ITS block and returns it;
+          * `world_size` (default: the number of GPU ids in CUDA_VISIBLE_DEVICES) > 1: spawn one process per GPU, each renders and
+            writes its block, the parent returns the concatenated frames (collect=True) or the image directory, like the reference;
+          * otherwise: this process renders everything.
+        Returns uint8 [n, H, W, 3] (host) of the frames this call is responsible for, or `tmp_imgs_dir` when collect=False."""
+        import torch.distributed as dist
+        tmp_imgs_dir = tmp_imgs_dir if tmp_imgs_dir is not None else getattr(self, "inp", {}).get("tmp_imgs_dir")
+        if dist.is_available() and dist.is_initialized():
+            self.proc_rank = dist.get_rank()
+            _, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, self.proc_rank, dist.get_world_size(),
+                                   tmp_imgs_dir, self.pipeline_cls, collect)
+            dist.barrier()
+            return out if collect else tmp_imgs_dir
+        world = int(world_size) if world_size is not None else (self.num_gpus if self.use_ddp else 1)
+        if world <= 1:
+            _, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, 0, 1, tmp_imgs_dir, self.pipeline_cls, collect)
+            return out if collect else tmp_imgs_dir
+        import shutil
+        import tempfile
+        import torch.multiprocessing as mp
+        use_cuda = self.device.type == "cuda"
+        if use_cuda and torch.cuda.device_count() < world:
+            raise RuntimeError(f"forward_system: {world} ranks requested but {torch.cuda.device_count()} GPUs are visible")
+        block_dir = tempfile.mkdtemp(prefix="gf_blocks_") if collect else None
+        state_dict = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        port = int(os.environ.get("MASTER_PORT", "12345"))          # the reference hard-codes 12345 (:112)
+        try:
+            mp.spawn(_spawned_rank, nprocs=world, join=True,
+                     args=(world, self.hparams, self.dataset, state_dict, batches, tmp_imgs_dir, self.pipeline_cls, use_cuda, port, block_dir))
+            if not collect:
+                return tmp_imgs_dir
+            blocks = [np.load(os.path.join(block_dir, f)) for f in sorted(os.listdir(block_dir))]
+            return np.concatenate(blocks, axis=0)
+        finally:
+            if block_dir:
+                shutil.rmtree(block_dir, ignore_errors=True)
 
     def infer_once(self, inp: dict):
+        self.inp = inp
         samples = self.get_pose_from_ds(self.get_cond_from_input(inp))
-        writer = None
-        if inp.get("tmp_imgs_dir"):
-            from .png import FrameWriter
-            writer = FrameWriter(inp["tmp_imgs_dir"])
-        frames = self.forward_system(samples, writer=writer)
-        if writer is not None:
-            writer.close()
+        frames = self.forward_system(samples)
+        if self.proc_rank != 0:          # base_nerf_infer.py:267: only rank 0 post-processes
+            return frames
         name = inp.get("out_video_name", "")
         if name.endswith(".npy"):
             os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
@@ -143,7 +243,7 @@ class LM3d_RADNeRFInfer:
         elif name:
             import shutil
             import subprocess
-            if shutil.which("ffmpeg") and writer is not None:   # base_nerf_infer.py:307 (video only; the wav is muxed when given)
+            if shutil.which("ffmpeg") and inp.get("tmp_imgs_dir"):   # base_nerf_infer.py:307 (video only; the wav is muxed when given)
                 wav = inp.get("audio_source_name") or None
                 cmd = ["ffmpeg", "-y", "-loglevel", "error", "-r", "25", "-i", os.path.join(inp["tmp_imgs_dir"], "%05d.png")]
                 cmd += (["-i", wav] if wav and os.path.exists(wav) else []) + ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-r", "25", name]

@@ -59,7 +59,8 @@ def cond_in_dim(hp):
     return {"esperanto": 44, "deepspeech": 29, "idexp_lm3d_normalized": 204}[hp["cond_type"]]
 
 
-def make_state_dict(hp: dict, torso: bool = True, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+def make_state_dict(hp: dict, torso: bool = True, seed: int = 0, sigma_row_scale: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """`sigma_row_scale` < 1 thins the density (0.02: sigma ~ 1 everywhere, no ray ever saturates -- bench.py's stress fixture)."""
     sd = OrderedDict()
     G = hp["grid_size"]
     cascade = 1 + math.ceil(math.log2(hp["bound"]))
@@ -120,7 +121,7 @@ def make_state_dict(hp: dict, torso: bool = True, seed: int = 0) -> "OrderedDict
     grid("ambient_embedder", hp["ambient_out_dim"], hp["desired_resolution"])
     mlp("sigma_net", 32 + 32, 1 + hp["geo_feat_dim"], hp["hidden_dim_sigma"], hp["num_layers_sigma"])
     last = f"sigma_net.net.{hp['num_layers_sigma'] - 1}.weight"
-    sd[last][0] = np.float32(SIGMA_ROW_ABS) * np.abs(sd[last][0]) + np.float32(SIGMA_ROW_LIN) * sd[last][0]
+    sd[last][0] = (np.float32(SIGMA_ROW_ABS) * np.abs(sd[last][0]) + np.float32(SIGMA_ROW_LIN) * sd[last][0]) * np.float32(sigma_row_scale)
     mlp("color_net", 16 + hp["geo_feat_dim"] + hp["individual_embedding_dim"], 3, hp["hidden_dim_color"], hp["num_layers_color"])
     if torso:
         grid("torso_embedder", 2, 2048)
@@ -153,6 +154,11 @@ def head_occupancy(G: int, bound: float, seed: int = 0) -> np.ndarray:
     ax, ay, az = 0.40 + 0.03 * r.uniform(-1, 1), 0.30, 0.33 + 0.03 * r.uniform(-1, 1)
     head = ((X - cx) / ax) ** 2 + (Y / ay) ** 2 + ((Z - cz) / az) ** 2 <= 1.0
     neck = (X > -0.62) & (X < cx - 0.2) & ((Y + 0.03) ** 2 + (Z - cz) ** 2 <= 0.16 ** 2)
+    if seed >= 1000:   # second identity (BASELINE.json configs[4]): narrower, taller head with a hair cap, thicker neck, off-centre
+        head = ((X - cx - 0.05) / (ax * 1.1)) ** 2 + ((Y + 0.02) / (ay * 0.9)) ** 2 + ((Z - cz + 0.04) / (az * 0.85)) ** 2 <= 1.0
+        cap = ((X - cx - 0.28) / 0.22) ** 2 + (Y / 0.26) ** 2 + ((Z - cz + 0.04) / 0.30) ** 2 <= 1.0
+        neck = (X > -0.70) & (X < cx - 0.15) & ((Y + 0.02) ** 2 + (Z - cz + 0.03) ** 2 <= 0.20 ** 2)
+        return head | cap | neck
     return head | neck
 
 

@@ -211,6 +211,11 @@ uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
 uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */
 uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/csrc/frame.hpp (queue heads, counts, terminal-index histogram) */
+/* Byte offset of one per-ray array inside the workspace, for tests that inspect what k_frame_init derived from the pose (the
+ * reference materialises the same arrays: get_rays utils.py:282-363, near_far_from_aabb raymarching.cu:92-145).
+ * field: 0 nears [N], 1 fars [N], 2 rays_t [N], 3 weights_sum [N], 4 depth [N], 5 image [N,3], 6 rays_o [N,3], 7 rays_d [N,3],
+ * 8 far_occ [N], 9 hit list int32 [N].  Returns UINT64_MAX for an unknown field. */
+uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field);
 /* HOST: {xmin,ymin,zmin,xmax,ymax,zmax} of the occupied cells of a density_bitfield (HOST pointer).  No sample of
  * kernel_march_rays (raymarching.cu:828-929) can lie outside it, so the fused marcher stops at a ray's exit from it. */
 int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, uint32_t H, float bound, float* out6_host);

@@ -33,3 +33,26 @@ def frame_inputs(seq, idx):
 def psnr(a, b):
     mse = float(((a.double() - b.double()) ** 2).mean())
     return 99.0 if mse == 0 else -10 * np.log10(mse)
+
+
+class StubPipeline:
+    """CPU stand-in for geneface_amd.infer.FramePipeline in world-size-2 gloo tests of the entry point's fan-out: same constructor and
+    `stream`, but a "frame" is a flat image whose bytes encode (global frame index, a checksum of the replica's weights, the rank's first
+    cond value), so the test can tell which rank rendered what from which weights.  Importable from spawned processes."""
+
+    def __init__(self, model, hp, seq, device, frames=None, impl=None, **kw):
+        self.H, self.W = int(seq["H"]), int(seq["W"])
+        self.lo, self.hi = frames
+        self.cond = np.asarray(seq["cond_wins"])[self.lo:self.hi]
+        w = next(p for n, p in model.named_parameters() if n.endswith("sigma_net.net.0.weight"))
+        self.wsum = int(abs(float(w.detach().double().sum())) * 1000) % 251
+        self._buf = np.zeros((self.H, self.W, 3), dtype=np.uint8)      # ONE reused buffer, like the pinned slots of the real pipeline
+
+    def stream(self, indices):
+        for k in indices:
+            g = self.lo + k
+            self._buf[...] = 0
+            self._buf[..., 0] = g % 256
+            self._buf[..., 1] = self.wsum
+            self._buf[..., 2] = int(abs(float(self.cond[k].reshape(-1)[0])) * 100) % 256
+            yield k, self._buf

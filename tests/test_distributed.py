@@ -81,3 +81,45 @@ def test_broadcast_is_noop_without_process_group():
     assert broadcast_model_(m) is m
     for k, v in m.state_dict().items():
         assert torch.equal(before[k], v)
+
+
+def test_forward_system_spawns_one_rank_per_gpu_world2_gloo(tmp_path, monkeypatch):
+    """The entry point's own fan-out (base_nerf_infer.py:131-193) on two spawned gloo ranks with a CPU stand-in for the frame pipeline:
+    every `%05d.png` index is written exactly once, by the rank that owns it (:150-155), from rank 0's weights (the replicas are built
+    fresh in every process and receive them through the one broadcast), in frame order; the parent gets the frames back in order."""
+    import numpy as np
+    from helpers import StubPipeline
+    from geneface_amd import synthetic as S
+    from geneface_amd.lm3d_radnerf_infer import LM3d_RADNeRFInfer, RADNeRFPoseSource
+    from geneface_amd.png import decode_rgb8
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_entry_point import _ds_dict
+    hp = HP.may_hparams(True)
+    T, H, W = 11, 16, 16
+    dd, _ = _ds_dict(T=T, H=H, W=W)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True, seed=7), strict=True)
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "0,1")          # what the reference reads to decide on the fan-out (:63-69)
+    inf = LM3d_RADNeRFInfer(hp, model=model, dataset=RADNeRFPoseSource(dd, hp), device="cpu")
+    assert inf.num_gpus == 2 and inf.use_ddp
+    inf.pipeline_cls = StubPipeline
+    lm = S.make_landmarks(T).astype(np.float32)
+    cond_path = str(tmp_path / "lm.npy")
+    np.save(cond_path, lm[None])
+    imgs = str(tmp_path / "imgs")
+    frames = inf.infer_once({"cond_name": cond_path, "out_video_name": str(tmp_path / "out.npy"), "audio_source_name": "", "tmp_imgs_dir": imgs})
+    assert frames.shape == (T, H, W, 3)
+    assert sorted(os.listdir(imgs)) == [f"{i:05d}.png" for i in range(T)]            # every index exactly once, nothing else
+    want = StubPipeline(model, hp, {"H": H, "W": W, "cond_wins": np.stack([s["cond_wins"] for s in inf.get_cond_from_input({"cond_name": cond_path})])},
+                        "cpu", frames=(0, T))
+    for (k, ref), i in zip(want.stream(range(T)), range(T)):
+        png = decode_rgb8(open(os.path.join(imgs, f"{i:05d}.png"), "rb").read())
+        np.testing.assert_array_equal(png, ref)                  # global index, rank-0 weights' checksum, this frame's condition
+        np.testing.assert_array_equal(frames[i], ref)
+    np.testing.assert_array_equal(np.load(str(tmp_path / "out.npy")), frames)
+    # world_size=1 through the same entry point gives the same files
+    inf1 = LM3d_RADNeRFInfer(hp, model=model, dataset=RADNeRFPoseSource(dd, hp), device="cpu")
+    inf1.pipeline_cls, inf1.use_ddp = StubPipeline, False
+    frames1 = inf1.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": "", "tmp_imgs_dir": str(tmp_path / "imgs1")})
+    np.testing.assert_array_equal(frames1, frames)

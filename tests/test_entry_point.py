@@ -108,6 +108,86 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         assert psnr(got.float() / 255, ref8.float() / 255) > 45
 
 
+def _save_reference_checkpoint(path, model_sd, step, extra_children=True):
+    """A checkpoint exactly as the reference's Trainer writes it (utils/commons/trainer.py:454-473): per-child state dicts, optimizer
+    states, a numpy scalar, LEGACY (non-zip) serialization."""
+    params = [torch.nn.Parameter(torch.zeros(3))]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    params[0].grad = torch.ones(3)
+    opt.step()
+    state = {"model": model_sd}
+    if extra_children:
+        state["criterion_lpips"] = {"net.lin0.weight": torch.zeros(4)}      # RADNeRFTask has an LPIPS child with parameters
+    ck = {"epoch": 3, "global_step": step, "checkpoint_callback_best": np.float64(0.123), "optimizer_states": [opt.state_dict()],
+          "state_dict": state}
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(ck, path, _use_new_zipfile_serialization=False)
+
+
+def test_build_model_from_reference_checkpoints(tmp_path):
+    """f3: LM3d_RADNeRFInfer.build_model = RADNeRFTorsoTask.build_model (head checkpoint, strict=False) + build_nerf_task (work_dir,
+    strict) over legacy-pickle checkpoints with optimizer states and a numpy scalar; newest step wins; the head-only task too."""
+    import zipfile
+    from geneface_amd import ckpt_utils
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp_t, hp_h = HP.may_hparams(True), HP.may_hparams(False)
+    sd_head, sd_torso_old, sd_torso = S.make_state_dict(hp_h, False, seed=2), S.make_state_dict(hp_t, True, seed=3), S.make_state_dict(hp_t, True, seed=4)
+    head_dir, work_dir = str(tmp_path / "ckpt" / "lm3d_radnerf"), str(tmp_path / "ckpt" / "lm3d_radnerf_torso")
+    _save_reference_checkpoint(os.path.join(head_dir, "model_ckpt_steps_250000.ckpt"), sd_head, 250000)
+    _save_reference_checkpoint(os.path.join(work_dir, "model_ckpt_steps_8000.ckpt"), sd_torso_old, 8000)
+    _save_reference_checkpoint(os.path.join(work_dir, "model_ckpt_steps_250000.ckpt"), sd_torso, 250000)
+    assert not zipfile.is_zipfile(os.path.join(work_dir, "model_ckpt_steps_250000.ckpt"))       # the legacy container, as the reference writes
+    assert [os.path.basename(p) for p in ckpt_utils.get_all_ckpts(work_dir)] == ["model_ckpt_steps_250000.ckpt", "model_ckpt_steps_8000.ckpt"]
+    ck, path = ckpt_utils.get_last_checkpoint(work_dir)
+    assert path.endswith("250000.ckpt") and ck["global_step"] == 250000 and float(ck["checkpoint_callback_best"]) == 0.123
+    assert ck["optimizer_states"][0]["state"][0]["exp_avg"].shape == (3,)
+
+    dd, _ = _ds_dict()
+    hp = dict(hp_t, work_dir=work_dir, head_model_dir=head_dir)
+    inf = LM3d_RADNeRFInfer(hp, dataset=RADNeRFPoseSource(dd, hp), device="cpu")
+    assert isinstance(inf.model, RADNeRFTorso) and inf.global_step == 250000
+    got = inf.model.state_dict()
+    for k, v in sd_torso.items():
+        assert torch.equal(got[k], v), k
+    # the two stages separately: after the head stage alone the head keys are the head checkpoint's, the torso keys untouched
+    stage1 = RADNeRFTorso(hp)
+    init = {k: v.clone() for k, v in stage1.state_dict().items()}
+    head = RADNeRF(hp)
+    ckpt_utils.load_ckpt(head, head_dir)
+    stage1.load_state_dict(head.state_dict(), strict=False)
+    for k, v in stage1.state_dict().items():
+        assert torch.equal(v, sd_head[k] if k in sd_head else init[k]), k
+    # head-only task: one strict load from work_dir
+    hp1 = dict(hp_h, work_dir=head_dir, task_cls="tasks.radnerfs.radnerf.RADNeRFTask")
+    inf1 = LM3d_RADNeRFInfer(hp1, dataset=RADNeRFPoseSource(dd, hp1), device="cpu")
+    assert isinstance(inf1.model, RADNeRF) and not isinstance(inf1.model, RADNeRFTorso)
+    assert all(torch.equal(inf1.model.state_dict()[k], v) for k, v in sd_head.items())
+    # load_ckpt's other behaviours (ckpt_utils.py:27-66): a file path, `steps`, flat 'model.' prefixes, strict=False dropping a mismatched
+    # shape, and the assert on a missing checkpoint
+    m = RADNeRFTorso(hp)
+    ckpt_utils.load_ckpt(m, work_dir, steps=8000)
+    assert torch.equal(m.state_dict()["sigma_net.net.0.weight"], sd_torso_old["sigma_net.net.0.weight"])
+    ckpt_utils.load_ckpt(m, os.path.join(work_dir, "model_ckpt_steps_250000.ckpt"))
+    assert torch.equal(m.state_dict()["sigma_net.net.0.weight"], sd_torso["sigma_net.net.0.weight"])
+    flat = {"state_dict": {f"model.{k}": v for k, v in sd_torso_old.items()}, "global_step": 1}
+    torch.save(flat, str(tmp_path / "flat.ckpt"), _use_new_zipfile_serialization=False)
+    ckpt_utils.load_ckpt(m, str(tmp_path / "flat.ckpt"))
+    assert torch.equal(m.state_dict()["sigma_net.net.0.weight"], sd_torso_old["sigma_net.net.0.weight"])
+    bad = dict(sd_torso, **{"color_net.net.1.weight": torch.zeros(5, 7)})
+    _save_reference_checkpoint(str(tmp_path / "bad" / "model_ckpt_steps_1.ckpt"), bad, 1, extra_children=False)
+    with pytest.raises(RuntimeError):
+        ckpt_utils.load_ckpt(m, str(tmp_path / "bad"))
+    before = m.state_dict()["color_net.net.1.weight"].clone()
+    ckpt_utils.load_ckpt(m, str(tmp_path / "bad"), strict=False)
+    assert torch.equal(m.state_dict()["color_net.net.1.weight"], before)
+    with pytest.raises(AssertionError):
+        ckpt_utils.load_ckpt(m, str(tmp_path / "nothing_here"))
+    assert ckpt_utils.load_ckpt(m, str(tmp_path / "nothing_here"), force=False) is None
+    with pytest.raises(AssertionError):                                   # a torso task whose head_model_dir is missing fails like the reference
+        LM3d_RADNeRFInfer(dict(hp, head_model_dir=str(tmp_path / "nope")), dataset=RADNeRFPoseSource(dd, hp), device="cpu")
+
+
 def test_png_writer_roundtrip(tmp_path):
     """The %05d.png frame files of base_nerf_infer.py:97-101, written without cv2: valid PNG signature/chunks/CRCs, lossless."""
     import struct
@@ -129,6 +209,16 @@ def test_png_writer_roundtrip(tmp_path):
     w.close()
     for i, f in enumerate(frames):
         np.testing.assert_array_equal(decode_rgb8(open(tmp_path / "imgs" / f"{i:05d}.png", "rb").read()), f)
+    # submit() must take a private copy: the frame loop hands in views of ONE reused (pinned) buffer and overwrites it right away
+    w = FrameWriter(str(tmp_path / "reused"), workers=1, max_pending=3)
+    buf = np.zeros((64, 64, 3), dtype=np.uint8)
+    for i in range(12):
+        buf[...] = i
+        w.submit(i, buf)
+        assert len(w._futures) <= 3                                        # the queue is bounded
+    w.close()
+    for i in range(12):
+        assert (decode_rgb8(open(tmp_path / "reused" / f"{i:05d}.png", "rb").read()) == i).all()
     with pytest.raises(ValueError):
         encode_rgb8(np.zeros((4, 4), dtype=np.uint8))
 

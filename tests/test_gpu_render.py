@@ -15,7 +15,7 @@ DEV = "cuda:0"
 # fp32 everywhere; what differs from the oracle is summation order inside the MLPs (MFMA / rocBLAS vs
 # MKL) and __expf, amplified by exp(h) of the density head.  Strict tolerance of BASELINE.md section 4,
 # widened where the amplification is visible, plus a PSNR floor far above the 40 dB "fast" bar.
-RGB_ATOL = 5e-4
+RGB_ATOL = 1e-4      # BASELINE.md section 4, strict tier: max|d rgb| <= 1e-4
 PSNR_MIN = 65.0
 
 
@@ -204,7 +204,7 @@ def test_full_size_fused_vs_ops_and_invariants():
     assert [n for _, n in fs["schedule"]] == sched_ops
     assert fs["budget"] == fs["budget_device"] == sum(sched_ops)
     a, b = out["rgb_map"].float().cpu(), out_ops["rgb_map"].float().cpu()
-    assert (a - b).abs().max().item() < 5e-4 and psnr(a, b) > 65
+    assert (a - b).abs().max().item() < RGB_ATOL and psnr(a, b) > 65
     u8 = (a * 255).to(torch.uint8).int() - (b * 255).to(torch.uint8).int()
     assert (u8.abs() <= 1).float().mean().item() > 0.999
     assert (out["depth_map"].cpu() - out_ops["depth_map"].cpu()).abs().max().item() < 2e-3
@@ -415,6 +415,85 @@ def test_fast_precision_tier_vs_oracle():
     with pytest.raises(ValueError):
         model.render_precision = "bf8"
         render_gpu(model, hp, fi)
+
+
+def _workspace_field(model, N, field, shape, dtype=torch.float32, slot=0):
+    """A per-ray array of the frame workspace the last fused render on `slot` left behind (include/geneface_hip.h: gf_frame_field_offset)."""
+    from geneface_amd import fused
+    from geneface_amd.lib import lib
+    ws = fused.get_state(model).workspace(N, slot)[0]
+    off = int(lib().gf_frame_field_offset(N, field))
+    n = int(np.prod(shape)) * 4
+    return ws[off:off + n].view(dtype).view(*shape).clone()
+
+
+def test_in_kernel_rays_vs_get_rays_512():
+    """k_frame_init generates the pinhole rays from pose + intrinsics (utils.py:282-363 restated per lane) and runs the slab test
+    (raymarching.cu:92-145).  Max-abs against the torch get_rays / the oracle's near_far_from_aabb at the full 512x512: directions
+    within 2 ulp of a unit vector's component (a 3-term rotation sum, fused differently by torch's matmul), origins exact, near / far
+    within a few ulp of t ~ 3."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(True, "fused")
+    seq = sequence(4, 512, 512)
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused", overlap=False)
+    N = 512 * 512
+    for i in (0, 3):
+        slot = pipe._slot
+        pipe.render_frame(i)
+        pipe.wait()
+        torch.cuda.synchronize()
+        fi = frame_inputs(seq, i)
+        ws_slot = slot % 2
+        rays_o = _workspace_field(model, N, 6, (N, 3), slot=ws_slot).cpu()
+        rays_d = _workspace_field(model, N, 7, (N, 3), slot=ws_slot).cpu()
+        nears = _workspace_field(model, N, 0, (N,), slot=ws_slot).cpu()
+        fars = _workspace_field(model, N, 1, (N,), slot=ws_slot).cpu()
+        ro, rd = fi["rays_o"].view(N, 3), fi["rays_d"].view(N, 3)
+        assert torch.equal(rays_o, ro)
+        err_d = (rays_d - rd).abs().max().item()
+        assert err_d <= 2 ** -22, err_d                       # <= 2 ulp of a component of magnitude <= 1 (measured: 1.5)
+        assert (rays_d.norm(dim=-1) - 1).abs().max().item() < 2e-7
+        n_ref, f_ref = R.near_far_from_aabb(ro, rd, sd["aabb_infer"], hp["min_near"])
+        hit = f_ref < 1e30
+        assert torch.equal(hit, fars < 1e30)
+        assert (nears[hit] - n_ref[hit]).abs().max().item() < 2e-6 and (fars[hit] - f_ref[hit]).abs().max().item() < 2e-6
+        assert torch.equal(nears[~hit], n_ref[~hit]) and torch.equal(fars[~hit], f_ref[~hit])
+
+
+def test_head_only_512_vs_oracle():
+    """BASELINE.json configs[1]: May lm3d_radnerf head-only at the full 512x512 against the CPU oracle (explicit rays through the module
+    API -> fp32 rgb_map, and the frame loop's in-kernel rays -> uint8)."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(False, "fused")
+    seq = sequence(4, 512, 512)
+    fi = frame_inputs(seq, 2)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=False)
+    out = render_gpu(model, hp, fi)
+    check(out, ref, False)
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused")
+    frame = pipe.render_frame(2)
+    pipe.wait()
+    ref8 = (ref["rgb_map"] * 255).view(512, 512, 3).to(torch.uint8)
+    d = (frame.int() - ref8.int()).abs()
+    assert int(d.max()) <= 1 and (d == 0).float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize("impl", ["ops", "fused"])
+def test_second_identity_256_vs_oracle(impl):
+    """BASELINE.json configs[4] (second identity, Obama2-style: same architecture, other weights, another occupancy shape): head+torso at
+    256x256 against the oracle."""
+    hp = model_fixture(True)[0]
+    from geneface_amd import synthetic as S
+    sd = S.make_state_dict(hp, True, seed=1000)
+    assert not torch.equal(sd["density_bitfield"], model_fixture(True)[1]["density_bitfield"])
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m.render_impl = impl
+    m = m.to(DEV).eval()
+    fi = frame_inputs(sequence(4, 256, 256, seed=5), 1)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+    check(render_gpu(m, hp, fi), ref, True)
 
 
 def test_fused_state_follows_the_weights():
