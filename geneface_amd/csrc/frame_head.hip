@@ -101,6 +101,7 @@ struct HeadArgs {
     uint32_t* ctrl;
     uint32_t N, phase, max_steps, gridtype, interp;
     float T_thresh, bound;
+    float cam_o[3]; uint32_t pose_mode;   // rays generated from a pose share one origin: it travels by value, no per-ray origin array
 #ifdef GF_TRACE
     uint32_t* trace;
     unsigned long long* spans;   // [2 phases][512 workgroups][start tick, end tick, rounds, XCC id]
@@ -189,16 +190,17 @@ template <int G>
 __device__ __forceinline__ float4 wpipe_take(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
     return wp.q[G % kWAhead];
 }
-template <int G>
+// GEND: one past the last group this launch consumes (the density-only field stops before density L3)
+template <int G, int GEND = (int)gf::G_TOTAL>
 __device__ __forceinline__ void wpipe_refill(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
-    if constexpr (G + kWAhead < (int)gf::G_TOTAL) wp.q[G % kWAhead] = load_group(Ws, G + kWAhead, lane16);
+    if constexpr (G + kWAhead < GEND) wp.q[G % kWAhead] = load_group(Ws, G + kWAhead, lane16);
 }
 
 // U 4-step groups (first one = group G0 of this wave's stream Ws) of this wave's output block over NT sample tiles.
 // Hb = &H[lane & 31][col0 + 4 * (lane >> 5)]: tile t is 32 rows further, group u eight floats further.
 // Software pipeline, pinned with sched_barrier so the scheduler cannot sink the loads next to their use: while the 16 MFMAs
 // of group u issue, the B operands of group u+1 (LDS) and the A operands of group u+3 (L2) are in flight.
-template <int NT, int G0, int U, int u>
+template <int NT, int G0, int U, int u, int GEND = (int)gf::G_TOTAL>
 __device__ __forceinline__ void obw_step(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4],
                                          const float4 (&b)[NT]) {
     if constexpr (u < U) {
@@ -217,18 +219,18 @@ __device__ __forceinline__ void obw_step(WPipe& wp, const char* __restrict__ Ws,
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-        wpipe_refill<G0 + u>(wp, Ws, lane16);
+        wpipe_refill<G0 + u, GEND>(wp, Ws, lane16);
         __builtin_amdgcn_sched_barrier(0);
-        obw_step<NT, G0, U, u + 1>(wp, Ws, lane16, Hb, acc, bn);
+        obw_step<NT, G0, U, u + 1, GEND>(wp, Ws, lane16, Hb, acc, bn);
     }
 }
-template <int NT, int G0, int U>
+template <int NT, int G0, int U, int GEND = (int)gf::G_TOTAL>
 __device__ __forceinline__ void obw_mfma(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4]) {
     float4 b[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4*>(Hb + t * 32 * kHS);
     __builtin_amdgcn_sched_barrier(0);
-    obw_step<NT, G0, U, 0>(wp, Ws, lane16, Hb, acc, b);
+    obw_step<NT, G0, U, 0, GEND>(wp, Ws, lane16, Hb, acc, b);
 }
 
 template <int NT>
@@ -301,8 +303,10 @@ __device__ __forceinline__ void store16(float* dst, const float (&f)[16]) {
 }
 
 // The field (radnerf.py:73-105) for the round's Mv densely packed samples, NT = ceil(Mv / 32) tiles.
-template <int NT>
+// DENSITY_ONLY = RADNeRF.density (radnerf.py:107-126): the same layers up to the density row; sigma is left in s.sx[raw].
+template <int NT, bool DENSITY_ONLY = false>
 __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
+    constexpr int GEND = DENSITY_ONLY ? (int)gf::G_SIG3 : (int)gf::G_TOTAL;
     const int half = lane >> 5, j = lane & 31;
     // lane-pair view (grid lookups, skinny layers): sample sI of this wave's tile
     const uint32_t sI = (uint32_t)(wave * 32 + j);
@@ -361,8 +365,8 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     // ---- ambient L1 (cond_feat folded into the bias) and the 3-D half of density L1, both from H[:, 0:32]
     obw_bias<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A);
     obw_zero<NT>(S);
-    obw_mfma<NT, gf::G_AMB1, 4>(wp, Ws, lane16, Hb, A);
-    obw_mfma<NT, gf::G_SIG1A, 4>(wp, Ws, lane16, Hb, S);
+    obw_mfma<NT, gf::G_AMB1, 4, GEND>(wp, Ws, lane16, Hb, A);
+    obw_mfma<NT, gf::G_SIG1A, 4, GEND>(wp, Ws, lane16, Hb, S);
     GF_PRIO_HI();
     GF_STAMP(9);
     __syncthreads();
@@ -374,7 +378,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     // ---- ambient L2
     GF_PRIO_LO();
     obw_zero<NT>(A);
-    obw_mfma<NT, gf::G_AMB2, 16>(wp, Ws, lane16, Hb, A);
+    obw_mfma<NT, gf::G_AMB2, 16, GEND>(wp, Ws, lane16, Hb, A);
     GF_PRIO_HI();
     GF_STAMP(13);
     __syncthreads();
@@ -408,7 +412,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     GF_STAMP(18);
     // ---- density L1, 2-D half
     GF_PRIO_LO();
-    obw_mfma<NT, gf::G_SIG1B, 4>(wp, Ws, lane16, Hb, S);
+    obw_mfma<NT, gf::G_SIG1B, 4, GEND>(wp, Ws, lane16, Hb, S);
     GF_PRIO_HI();
     GF_STAMP(19);
     __syncthreads();
@@ -420,7 +424,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     // ---- density L2
     GF_PRIO_LO();
     obw_zero<NT>(A);
-    obw_mfma<NT, gf::G_SIG2, 16>(wp, Ws, lane16, Hb, A);
+    obw_mfma<NT, gf::G_SIG2, 16, GEND>(wp, Ws, lane16, Hb, A);
     GF_PRIO_HI();
     GF_STAMP(23);
     __syncthreads();
@@ -438,6 +442,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
 #ifdef GF_DIAG
         if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 14] = h0[0];
 #endif
+    }
+    if constexpr (DENSITY_ONLY) {
+        if (tile_on && valid && half == 0) s.sx[raw] = sigma;
+        __syncthreads();
+        return;
     }
     GF_PRIO_LO();
     obw_zero<NT>(A);
@@ -900,9 +909,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (idx < limit) {
                     ray = a.queue[idx];
-                    const float* o = a.rays_o + (size_t)ray * 3;
                     const float* d = a.rays_d + (size_t)ray * 3;
-                    r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
+                    if (a.pose_mode) {
+                        r_ox = a.cam_o[0]; r_oy = a.cam_o[1]; r_oz = a.cam_o[2];
+                    } else {
+                        const float* o = a.rays_o + (size_t)ray * 3;
+                        r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
+                    }
                     r_dx = d[0]; r_dy = d[1]; r_dz = d[2];
                     r_t = a.rays_t[ray];
                     r_far = a.far_occ[ray];
@@ -1086,6 +1099,72 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- occupancy-grid refresh
+// NeRFRenderer.update_extra_state's field queries (renderer.py:232-246) for ALL cascades and cells in one launch: cell -> jittered
+// centre -> density head on the matrix pipe (the same field_round as the renderer, cut after the density row) -> sigma * density_scale
+// into tmp_grid at the cell's Morton index.  Cells are walked in the reference's meshgrid order (x slowest), which is also the order of
+// the jitter array, 128 per round.
+struct GridArgs {
+    const float* noise;     // [C][G^3][3] U[0,1) in meshgrid order, or NULL (cell centres)
+    float* tmp_grid;        // [C][G^3] Morton order
+    uint32_t C, G;
+    float density_scale;
+};
+
+__global__ void __launch_bounds__(kThreads, 2) k_grid_density(const HeadArgs a, const GridArgs u) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
+    if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
+    if (tid < 32) {
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
+    }
+    const uint32_t G = u.G, G3 = G * G * G, total = u.C * G3;
+    const uint32_t chunks = (total + kPass - 1) / kPass;
+#ifndef GF_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        __syncthreads();   // previous round retired
+        const uint32_t i = chunk * kPass + (uint32_t)tid;
+        uint32_t cas = 0, cx = 0, cy = 0, cz = 0;
+        if (tid < kPass && i < total) {
+#pragma clang fp contract(off)
+            cas = i / G3;
+            const uint32_t lin = i - cas * G3;
+            cx = lin / (G * G); cy = (lin / G) % G; cz = lin % G;
+            // xyzs = 2 * coords / (G - 1) - 1;  cas_xyzs = xyzs * (bound_c - half) + (noise * 2 - 1) * half    (renderer.py:236-243)
+            const float bound_c = fminf(scalbnf(1.0f, (int)cas), a.bound);
+            const float hgs = (float)((double)bound_c / (double)G);
+            const float span = (float)((double)bound_c - (double)bound_c / (double)G);
+            const float gm1 = (float)(G - 1);
+            const float c3[3] = {(float)cx, (float)cy, (float)cz};
+            float p[3];
+            for (int d = 0; d < 3; d++) {
+                float v = (2.0f * c3[d] / gm1 - 1.0f) * span;
+                if (u.noise) v = v + (u.noise[(size_t)i * 3 + d] * 2.0f - 1.0f) * hgs;
+                p[d] = v;
+            }
+            s.sx[tid] = p[0]; s.sy[tid] = p[1]; s.sz[tid] = p[2];
+            s.d2r[tid] = (uint8_t)tid;
+        }
+        const uint32_t left = total - chunk * kPass;
+        const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
+        __syncthreads();
+        const uint32_t nt = (Mv + 31) / 32;
+        if (nt == 4) field_round<4, true>(a, s, Mv, wave, lane);
+        else if (nt == 3) field_round<3, true>(a, s, Mv, wave, lane);
+        else if (nt == 2) field_round<2, true>(a, s, Mv, wave, lane);
+        else field_round<1, true>(a, s, Mv, wave, lane);
+        if (tid < kPass && i < total) u.tmp_grid[(size_t)cas * G3 + gf::morton3d(cx, cy, cz)] = s.sx[tid] * u.density_scale;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- frame setup
 struct InitArgs {
     gf::MarchParams mp;
@@ -1118,8 +1197,6 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
             dz = ux * a.pose[8] + uy * a.pose[9] + uz * a.pose[10];
             ox = a.pose[3]; oy = a.pose[7]; oz = a.pose[11];
         }
-        a.rays_o[(size_t)n * 3] = ox; a.rays_o[(size_t)n * 3 + 1] = oy; a.rays_o[(size_t)n * 3 + 2] = oz;
-        a.rays_d[(size_t)n * 3] = dx; a.rays_d[(size_t)n * 3 + 1] = dy; a.rays_d[(size_t)n * 3 + 2] = dz;
         float near, far;
         gf::near_far_from_aabb_1(ox, oy, oz, dx, dy, dz, a.aabb, a.min_near, near, far);
         a.nears[n] = near;
@@ -1136,14 +1213,18 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
             if (of == FLT_MAX) far_m = near;              // misses the occupied region: no sample on this ray
             else far_m = fminf(far, of);
         }
-        a.far_occ[n] = far_m;
         // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there
         float t = near, t_first = near;
         const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far_m, 0.0f, 1u, t,
                                            [&](uint32_t, float, float, float, float, float, float t_at) { t_first = t_at; });
-        a.rays_t[n] = t_first;
         hit = got > 0;
         miss = !hit;
+        if (hit) {   // marcher state only for the rays the field kernel will pick up (~35 % of a head frame): 20-32 B less per missed ray
+            a.rays_d[(size_t)n * 3] = dx; a.rays_d[(size_t)n * 3 + 1] = dy; a.rays_d[(size_t)n * 3 + 2] = dz;
+            if (a.rays_o_in) { a.rays_o[(size_t)n * 3] = ox; a.rays_o[(size_t)n * 3 + 1] = oy; a.rays_o[(size_t)n * 3 + 2] = oz; }
+            a.far_occ[n] = far_m;
+            a.rays_t[n] = t_first;
+        }
     }
     // rays with a sample -> hit list (order is irrelevant: rays are independent); rays without one terminate at index 1
     const unsigned long long hm = __ballot(hit), mm = __ballot(miss);
@@ -1229,6 +1310,8 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.survivors = w.alive_a;
     ha.ctrl = w.ctrl; ha.N = N; ha.max_steps = f->max_steps; ha.gridtype = f->gridtype; ha.interp = f->interp;
     ha.T_thresh = f->T_thresh; ha.bound = f->bound;
+    ha.pose_mode = f->rays_o == nullptr;
+    ha.cam_o[0] = f->pose[3]; ha.cam_o[1] = f->pose[7]; ha.cam_o[2] = f->pose[11];
 #ifdef GF_TRACE
     ha.trace = g_trace_buf;
     ha.spans = g_span_buf;
@@ -1302,6 +1385,35 @@ GF_EXPORT uint64_t gf_frame_ctrl_offset(uint32_t n_rays) {
     char* const base = reinterpret_cast<char*>(uintptr_t(1) << 20);
     const gf::FrameWs w = gf::carve_workspace(base, n_rays);
     return (uint64_t)((char*)w.ctrl - base);
+}
+
+// NeRFRenderer.update_extra_state, field queries (renderer.py:232-246): sigma * density_scale of every cell of every cascade into
+// tmp_grid [cascade][grid_size^3] (Morton order).  Uses f's tables, packed head weights, amb_bias, bound / cascade / grid_size / gridtype /
+// interp / level scales; noise_or_null = [cascade][grid_size^3][3] U[0,1) jitter in meshgrid order (x slowest), NULL = cell centres.
+GF_EXPORT int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, float density_scale, float* tmp_grid, void* stream) {
+    if (!f || !tmp_grid) return gf_set_error(GF_ERR_INVALID, "grid_density: null pointer");
+    if (!f->pos_table || !f->pos_offsets || !f->amb_table || !f->amb_offsets || !f->head_pack || !f->amb_bias)
+        return gf_set_error(GF_ERR_INVALID, "grid_density: null pointer in the field description");
+    if (f->cascade == 0 || f->grid_size == 0 || f->grid_size > 1024 || f->gridtype > 1 || f->interp > 1)
+        return gf_set_error(GF_ERR_INVALID, "grid_density: bad grid configuration");
+    HeadArgs ha = {};
+    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
+        return gf_set_error(GF_ERR_INVALID, "grid_density: bad grid levels");
+    ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
+    ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
+    ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
+    GridArgs ga = {noise_or_null, tmp_grid, f->cascade, f->grid_size, density_scale};
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_density), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+            return gf_set_error(GF_ERR_HIP, "grid_density: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
+        attr_set = true;
+    }
+    const uint64_t total = (uint64_t)f->cascade * f->grid_size * f->grid_size * f->grid_size;
+    if (total >= (1ull << 32)) return gf_set_error(GF_ERR_UNSUPPORTED, "grid_density: more than 2^32 cells");
+    const uint32_t chunks = (uint32_t)((total + kPass - 1) / kPass);
+    hipLaunchKernelGGL(k_grid_density, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ga);
+    return gf_check_launch("grid_density");
 }
 
 GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {

@@ -92,47 +92,47 @@ class NeRFRenderer(nn.Module):
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
         """renderer.py:129-196: cells no training camera sees get density -1 (never marched, never updated).
-        poses [B,4,4] c2w (ngp axes), intrinsic (fx, fy, cx, cy).  Morton indices come from the HIP op."""
+        poses [B,4,4] c2w (ngp axes), intrinsic (fx, fy, cx, cy).  One launch (gf_mark_untrained_grid: one lane per cascade cell walks
+        the cameras and stops at the first frustum that contains the cell) instead of the reference's S^3-block x cascade x camera-batch
+        Python loops; `S` only sized those blocks and is accepted for signature parity."""
         if not self.cuda_ray:
             return
         if isinstance(poses, np.ndarray):
             poses = torch.from_numpy(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
+        fx, fy, cx, cy = (float(v) for v in intrinsic)
         dev = self.density_bitfield.device
-        G = self.grid_size
-        X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(dev).float()
+        p44 = poses.to(dev).float().contiguous()
+        from .lib import check, current_stream, lib, ptr
+        check(lib().gf_mark_untrained_grid(ptr(p44, torch.float32), int(p44.shape[0]), fx, fy, cx, cy, int(self.cascade), int(self.grid_size),
+                                           float(self.bound), ptr(self.density_grid, torch.float32), current_stream(dev)))
+
+    def _cell_jitter(self, S, generator):
+        """U[0,1) jitter for every cascade cell, [cascade, G^3, 3] in meshgrid order.  With a generator the numbers are drawn block by
+        block and cascade by cascade exactly as the reference's loop consumes them (renderer.py:222-243), so a CPU restatement seeded the
+        same way sees the same jitter; without one a single device draw serves (the stream is unobservable)."""
+        G, C, dev = self.grid_size, self.cascade, self.density_bitfield.device
+        if generator is None:
+            return torch.rand(C, G ** 3, 3, device=dev)
+        noise = torch.empty(C, G, G, G, 3, dtype=torch.float32)
+        X = torch.arange(G).split(S)
         for xs in X:
             for ys in X:
                 for zs in X:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    world_xyzs = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / G
-                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                        head = 0
-                        while head < B:
-                            tail = min(head + S, B)
-                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                            mask_z = cam_xyzs[:, :, 2] > 0
-                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            count[cas, indices] += (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-                            head += S
-        self.density_grid[count == 0] = -1
+                    n = len(xs) * len(ys) * len(zs)
+                    for cas in range(C):
+                        blk = torch.rand((n, 3), generator=generator, device=generator.device, dtype=torch.float32).cpu()
+                        noise[cas, xs[0]:xs[-1] + 1, ys[0]:ys[-1] + 1, zs[0]:zs[-1] + 1] = blk.view(len(xs), len(ys), len(zs), 3)
+        return noise.view(C, G ** 3, 3).to(dev)
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128, cond=None, generator=None):
         """renderer.py:199-260: re-sample the density field on the jittered cell centres of every cascade, dilate in Morton
         space, EMA-max into density_grid, re-derive mean_density and the packed density_bitfield.  The reference draws the
         condition window at random from `self.conds` (set by the task); pass `cond` ([smo_win, cond_win, C]) to fix it.
-        `generator` seeds the cell jitter.  Field queries, Morton codes, dilation and bit packing run in libgeneface_hip.so."""
+        `generator` seeds the cell jitter.
+        Three launches on the device (geneface_hip.h: gf_grid_density = every cell of every cascade through the density head on the
+        matrix pipe, gf_grid_update = dilation + EMA-max + mean, then bit packing) and one host read (mean_density is a Python float in
+        the reference's API); models the fused field does not cover take the op-by-op route."""
         if not self.cuda_ray:
             return
         dev = self.density_bitfield.device
@@ -142,38 +142,62 @@ class NeRFRenderer(nn.Module):
             from .utils import get_audio_features
             rand_idx = random.randint(0, self.conds.shape[0] - 1)
             cond = get_audio_features(self.conds, 2, rand_idx, self.smo_win_size)
-        enc_a = self.cal_cond_feat(cond.to(dev))
-        G = self.grid_size
-        tmp_grid = torch.zeros_like(self.density_grid)
-        X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
-        for xs in X:
-            for ys in X:
-                for zs in X:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    xyzs = 2 * coords.float() / (G - 1) - 1
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / G
-                        cas_xyzs = xyzs * (bound - half_grid_size)
-                        noise = _rand_like(cas_xyzs, generator)
-                        cas_xyzs = cas_xyzs + (noise * 2 - 1) * half_grid_size
-                        sigmas = self.density(cas_xyzs, enc_a)["sigma"].reshape(-1).detach().to(tmp_grid.dtype)
-                        tmp_grid[cas, indices] = sigmas * self.density_scale
-        tmp_grid = raymarching.morton3D_dilation(tmp_grid)
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        noise = self._cell_jitter(S, generator)
+        if self._pick_impl("auto", False, 1) == "fused":
+            tmp_grid = self._density_grid_fused(cond.to(dev), noise)
+        else:
+            tmp_grid = self._density_grid_ops(cond.to(dev), noise)
+        from .lib import check, current_stream, lib, ptr
+        L = lib()
+        C, G = int(self.cascade), int(self.grid_size)
+        ws = torch.empty(L.gf_grid_update_ws_bytes(C, G), dtype=torch.uint8, device=dev)
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        check(L.gf_grid_update(ptr(self.density_grid, torch.float32), ptr(tmp_grid, torch.float32), C, G, float(decay), float(self.density_thresh),
+                               ptr(self.density_bitfield, torch.uint8), ws.data_ptr(), ptr(stats), current_stream(dev)))
+        self.mean_density = float(stats[0].item())
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
         total_step = min(16, self.local_step)
         if total_step > 0:
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
         self.local_step = 0
         from .fused import invalidate
         invalidate(self)   # the fused path caches the occupancy bounding box of the bitfield
+
+    def _density_grid_fused(self, cond, noise):
+        """tmp_grid [C, G^3] (Morton order) = density * density_scale of every jittered cell, one launch."""
+        import ctypes as C_
+        from . import fused
+        from .lib import check, current_stream, lib, ptr
+        dev = self.density_bitfield.device
+        st = fused.get_state(self)
+        _, amb_bias, _ = fused._per_frame_vectors(self, st, cond.float().contiguous())
+        f = fused.GfFrame()
+        pe, ae = self.position_embedder, self.ambient_embedder
+        f.bound, f.cascade, f.grid_size = float(self.bound), int(self.cascade), int(self.grid_size)
+        f.pos_table, f.pos_offsets = ptr(pe.embeddings, torch.float32), ptr(pe.offsets, torch.int32)
+        f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+        f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
+        f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
+        tmp_grid = torch.empty_like(self.density_grid)
+        check(lib().gf_grid_density(C_.byref(f), ptr(noise, torch.float32), float(self.density_scale), ptr(tmp_grid, torch.float32), current_stream(dev)))
+        return tmp_grid
+
+    def _density_grid_ops(self, cond, noise):
+        """The same tmp_grid through the stand-alone ops (any architecture `density()` serves): one field query per cascade."""
+        dev = self.density_bitfield.device
+        G = self.grid_size
+        enc_a = self.cal_cond_feat(cond)
+        ax = torch.arange(G, dtype=torch.int32, device=dev)
+        coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3)
+        indices = raymarching.morton3D(coords).long()
+        xyzs = 2 * coords.float() / (G - 1) - 1
+        tmp_grid = torch.zeros_like(self.density_grid)
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            half_grid_size = bound / G
+            pts = xyzs * (bound - half_grid_size) + (noise[cas] * 2 - 1) * half_grid_size
+            tmp_grid[cas, indices] = self.density(pts, enc_a)["sigma"].reshape(-1).float() * self.density_scale
+        return tmp_grid
 
     def _pick_impl(self, impl, perturb, max_steps):
         if impl != "auto":

@@ -214,8 +214,27 @@ uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/c
 /* Byte offset of one per-ray array inside the workspace, for tests that inspect what k_frame_init derived from the pose (the
  * reference materialises the same arrays: get_rays utils.py:282-363, near_far_from_aabb raymarching.cu:92-145).
  * field: 0 nears [N], 1 fars [N], 2 rays_t [N], 3 weights_sum [N], 4 depth [N], 5 image [N,3], 6 rays_o [N,3], 7 rays_d [N,3],
- * 8 far_occ [N], 9 hit list int32 [N].  Returns UINT64_MAX for an unknown field. */
+ * 8 far_occ [N], 9 hit list int32 [N].  Fields 2, 7, 8 are written only for the rays of the hit list (the first ctrl[1] entries of
+ * field 9: rays with at least one sample), field 6 only for those and only when explicit rays were passed in (rays generated from
+ * the pose share one origin, which travels by value).  Returns UINT64_MAX for an unknown field. */
 uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field);
+
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy-grid maintenance on the device: NeRFRenderer.update_extra_state (renderer.py:199-260) in three launches,
+ * mark_untrained_grid (:129-196) in one.  The reference walks cell blocks and cascades in Python, one field query per block.
+ * gf_grid_density: sigma * density_scale of every cell of every cascade (RADNeRF.density, radnerf.py:107-126, on the matrix pipe) into
+ *   tmp_grid [cascade][grid_size^3], Morton order.  Reads f's tables, level scales, packed head weights, amb_bias, bound, cascade,
+ *   grid_size, gridtype, interp.  noise_or_null: [cascade][grid_size^3][3] U[0,1) jitter in meshgrid order (x slowest), NULL = centres.
+ * gf_grid_update: Morton dilation of tmp_grid (raymarching.cu:300-341) + EMA-max into density_grid + mean of clamp(grid, 0) (fixed
+ *   summation order) + packbits with min(mean, density_thresh) (raymarching.cu:268-289).  partial_ws: gf_grid_update_ws_bytes() bytes of
+ *   device scratch; stats_dev[0] = mean_density, [1] = threshold used.
+ * gf_mark_untrained_grid: cells outside every camera frustum get density -1.  poses: device [B,4,4] c2w, ngp axes. */
+int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, float density_scale, float* tmp_grid, void* stream);
+uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
+int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
+                   uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);
+int gf_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H, float bound,
+                           float* density_grid, void* stream);
 /* HOST: {xmin,ymin,zmin,xmax,ymax,zmax} of the occupied cells of a density_bitfield (HOST pointer).  No sample of
  * kernel_march_rays (raymarching.cu:828-929) can lie outside it, so the fused marcher stops at a ray's exit from it. */
 int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, uint32_t H, float bound, float* out6_host);

@@ -52,6 +52,40 @@ def test_update_extra_state_head_vs_oracle():
     assert not hasattr(model, "_fused_state")
 
 
+def test_update_extra_state_device_path_vs_ops_full_grid():
+    """The full 128^3 grid: the three-launch device path (density head on the matrix pipe -> dilation + EMA-max + mean -> packbits)
+    against the op-by-op route (grid-encode ops + library GEMMs through `density()`) on the same jitter; smaller S only changes how the
+    reference's loop would consume the jitter stream, which `_cell_jitter` reproduces."""
+    import time
+    hp, sd, model = _model(torso=False, G=128)
+    cond = torch.randn(5, 1, 204, generator=torch.Generator().manual_seed(5)).to(DEV)
+    grid0 = torch.zeros(1, 128 ** 3)
+    grid0[0, ::11] = -1.0
+    grid0[0, 3::11] = 2.0
+    noise = model._cell_jitter(64, torch.Generator().manual_seed(21))
+    a = model._density_grid_fused(cond, noise)
+    b = model._density_grid_ops(cond, noise)
+    rel = ((a - b).abs() / b.abs().clamp(min=1e-2)).max().item()
+    assert rel < 5e-3, rel
+    model.density_grid.copy_(grid0.to(DEV))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.update_extra_state(cond=cond, generator=torch.Generator().manual_seed(21), S=64)
+    torch.cuda.synchronize()
+    print(f"update_extra_state 128^3 (incl. host-side jitter draw): {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    got = model.density_grid.cpu()
+    assert torch.equal(got < 0, grid0 < 0)
+    own = torch.zeros(128 ** 3 // 8, dtype=torch.uint8)
+    R.RM.packbits(got.contiguous(), own.numel(), min(model.mean_density, hp["density_thresh"]), own)
+    assert torch.equal(model.density_bitfield.cpu(), own)
+    assert abs(model.mean_density - got.clamp(min=0).double().mean().item()) < 1e-6 * max(1.0, model.mean_density)
+    # run-to-run identical (the mean is reduced in a fixed order)
+    bits1 = model.density_bitfield.clone()
+    model.density_grid.copy_(grid0.to(DEV))
+    model.update_extra_state(cond=cond, generator=torch.Generator().manual_seed(21), S=64)
+    assert torch.equal(model.density_bitfield, bits1)
+
+
 def test_update_extra_state_torso_vs_oracle():
     hp, sd, model = _model()
     p6 = torch.tensor([[0.05, -0.03, 0.02, 0.01, 3.3, -0.02]])

@@ -444,15 +444,18 @@ def test_in_kernel_rays_vs_get_rays_512():
         torch.cuda.synchronize()
         fi = frame_inputs(seq, i)
         ws_slot = slot % 2
-        rays_o = _workspace_field(model, N, 6, (N, 3), slot=ws_slot).cpu()
         rays_d = _workspace_field(model, N, 7, (N, 3), slot=ws_slot).cpu()
         nears = _workspace_field(model, N, 0, (N,), slot=ws_slot).cpu()
         fars = _workspace_field(model, N, 1, (N,), slot=ws_slot).cpu()
+        from geneface_amd import fused
+        n_hit = int(fused.get_state(model).workspace(N, ws_slot)[1][1])
+        hits = _workspace_field(model, N, 9, (N,), dtype=torch.int32, slot=ws_slot).cpu()[:n_hit].long()
+        assert 0.2 * N < n_hit < 0.6 * N and hits.unique().numel() == n_hit      # per-ray marcher state exists for the hit rays only
         ro, rd = fi["rays_o"].view(N, 3), fi["rays_d"].view(N, 3)
-        assert torch.equal(rays_o, ro)
-        err_d = (rays_d - rd).abs().max().item()
+        assert torch.equal(ro[0], torch.from_numpy(seq["poses"][i][:3, 3]))          # the one origin, handed to the kernel by value
+        err_d = (rays_d[hits] - rd[hits]).abs().max().item()
         assert err_d <= 2 ** -22, err_d                       # <= 2 ulp of a component of magnitude <= 1 (measured: 1.5)
-        assert (rays_d.norm(dim=-1) - 1).abs().max().item() < 2e-7
+        assert (rays_d[hits].norm(dim=-1) - 1).abs().max().item() < 2e-7
         n_ref, f_ref = R.near_far_from_aabb(ro, rd, sd["aabb_infer"], hp["min_near"])
         hit = f_ref < 1e30
         assert torch.equal(hit, fars < 1e30)
