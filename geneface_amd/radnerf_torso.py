@@ -4,7 +4,9 @@ Drop-in for `RADNeRFTorso` of modules/radnerfs/radnerf_torso.py:17-241 on the in
 `forward_torso` :51-84 and `render` :86-198 keep their signatures and result keys
 (`rgb_map, depth_map, torso_alpha_map, torso_rgb_map, deform`).  Unlike the reference, `torso_shrink`
 and `torso_head_aware` are read from the hparams given to the constructor rather than from a
-process-global dict.  `torso_head_aware=True` (random branch at inference, :175-179) is not built.
+process-global dict.  `torso_head_aware=True` (:36-46, :68-74, :175-179: a small encoder of the head's colour / opacity at the
+pixel feeds both torso MLPs, on a coin flip per frame) is served by the op-by-op path; the fused torso kernel is specialised
+for the default architecture (base.yaml:90 `torso_head_aware: false`) and `render_impl="auto"` routes accordingly.
 """
 import random
 
@@ -26,8 +28,7 @@ class RADNeRFTorso(RADNeRF):
         self.mean_density_torso = 0  # not in the state_dict: a freshly loaded model thresholds at 0
         self.density_thresh_torso = hparams["density_thresh_torso"]
         self.torso_shrink = hparams["torso_shrink"]
-        if hparams.get("torso_head_aware", False):
-            raise NotImplementedError("torso_head_aware=True takes a random branch per frame in the reference; not built")
+        self.torso_head_aware = bool(hparams.get("torso_head_aware", False))
 
         self.torso_individual_embedding_num = hparams["individual_embedding_num"]
         self.torso_individual_embedding_dim = hparams["torso_individual_embedding_dim"]
@@ -40,6 +41,11 @@ class RADNeRFTorso(RADNeRF):
         self.torso_embedder, self.torso_in_dim = get_encoder("tiledgrid", input_dim=2, num_levels=16, level_dim=2,
                                                              base_resolution=16, log2_hashmap_size=16, desired_resolution=2048)
         deform_in = self.torso_deform_pos_dim + self.pose_embedding_dim + self.torso_individual_embedding_dim
+        if self.torso_head_aware:   # radnerf_torso.py:36-46
+            self.head_color_weights_encoder = nn.Sequential(nn.Linear(3 + 1, 16, bias=True), nn.LeakyReLU(0.02, True),
+                                                            nn.Linear(16, 32, bias=True), nn.LeakyReLU(0.02, True),
+                                                            nn.Linear(32, 16, bias=True))
+            deform_in += 16
         self.torso_deform_net = MLP(deform_in, 2, 64, 3)
         self.torso_canonicial_net = MLP(self.torso_in_dim + deform_in, 4, 32, 3)
 
@@ -53,6 +59,11 @@ class RADNeRFTorso(RADNeRF):
         parts = [self.torso_deform_pos_embedder(x), self.torso_pose_embedder(poses).reshape(1, -1).expand(m, -1)]
         if c is not None:
             parts.append(c.reshape(1, -1).expand(m, -1))
+        if self.torso_head_aware:   # radnerf_torso.py:68-74: no head given -> the encoding of a black, transparent head
+            if image is None:
+                image = torch.zeros([m, 3], dtype=parts[0].dtype, device=x.device)
+                weights_sum = torch.zeros([m, 1], dtype=parts[0].dtype, device=x.device)
+            parts.append(self.head_color_weights_encoder(torch.cat([image, weights_sum], dim=-1)))
         h = torch.cat(parts, dim=-1)
         dx = self.torso_deform_net(h)
         xc = (x + dx).clamp(-1, 1).float()
@@ -87,7 +98,10 @@ class RADNeRFTorso(RADNeRF):
         torso_alpha = torch.zeros([N, 1], device=device)
         torso_color = torch.zeros([N, 3], device=device)
         if mask.any():
-            a, c, deform = self.forward_torso(bg_coords[mask], poses, code)
+            if self.torso_head_aware and random.random() < 0.5:
+                a, c, deform = self.forward_torso(bg_coords[mask], poses, code, image[mask], weights_sum.unsqueeze(-1)[mask])
+            else:
+                a, c, deform = self.forward_torso(bg_coords[mask], poses, code)
             torso_alpha[mask] = a.float()
             torso_color[mask] = c.float()
             results["deform"] = deform
@@ -124,7 +138,10 @@ class RADNeRFTorso(RADNeRF):
             torso_alpha = torch.zeros([N, 1], device=device)
             torso_color = torch.zeros([N, 3], device=device)
             if mask.any():
-                a, c, deform = self.forward_torso(bg_coords[mask], poses, self._torso_code())
+                if self.torso_head_aware and random.random() < 0.5:   # the reference flips this coin at inference too (:175-179)
+                    a, c, deform = self.forward_torso(bg_coords[mask], poses, self._torso_code(), image[mask], weights_sum.unsqueeze(-1)[mask])
+                else:
+                    a, c, deform = self.forward_torso(bg_coords[mask], poses, self._torso_code())
                 torso_alpha[mask] = a.float()
                 torso_color[mask] = c.float()
                 results["deform"] = deform

@@ -126,6 +126,12 @@ def make_state_dict(hp: dict, torso: bool = True, seed: int = 0, sigma_row_scale
     if torso:
         grid("torso_embedder", 2, 2048)
         din = 42 + 54 + hp["torso_individual_embedding_dim"]
+        if hp.get("torso_head_aware", False):   # radnerf_torso.py:36-46
+            for i, (o, ii) in zip((0, 2, 4), ((16, 4), (32, 16), (16, 32))):
+                n = f"head_color_weights_encoder.{i}"
+                sd[n + ".weight"] = _linear(n + ".weight", seed, o, ii) * np.float32(2.0)
+                sd[n + ".bias"] = _uniform(n + ".bias", seed, (o,), 1.0 / math.sqrt(ii))
+            din += 16
         mlp("torso_deform_net", din, 2, 64, 3)
         mlp("torso_canonicial_net", 32 + din, 4, 32, 3)
         w = sd["torso_canonicial_net.net.2.weight"]

@@ -219,13 +219,23 @@ def head_field(sd, hp, position, direction, cond_feat, ind_code):
     return sigma, color, ambient_pos
 
 
-def torso_field(sd, hp, x, poses6, code):
-    """RADNeRFTorso.forward_torso: x [m,2], poses6 [1,6], code [8] -> alpha [m,1], color [m,3], dx [m,2]"""
+def torso_field(sd, hp, x, poses6, code, image=None, weights_sum=None):
+    """RADNeRFTorso.forward_torso (radnerf_torso.py:51-84): x [m,2], poses6 [1,6], code [8] -> alpha [m,1], color [m,3], dx [m,2];
+    with hp['torso_head_aware'] the head's colour / opacity at the pixel (or zeros) goes through head_color_weights_encoder (:68-74)."""
     m = x.shape[0]
     x = x * hp["torso_shrink"]
     parts = [freq_encode(x, 10), freq_encode(poses6.reshape(1, 6), 4).repeat(m, 1)]
     if code is not None:
         parts.append(code.reshape(1, -1).repeat(m, 1))
+    if hp.get("torso_head_aware", False):
+        if image is None:
+            image, weights_sum = torch.zeros(m, 3), torch.zeros(m, 1)
+        e = torch.cat([image, weights_sum], dim=-1)
+        for i in (0, 2, 4):
+            e = F.linear(e, sd[f"head_color_weights_encoder.{i}.weight"], sd[f"head_color_weights_encoder.{i}.bias"])
+            if i < 4:
+                e = F.leaky_relu(e, 0.02)
+        parts.append(e)
     h = torch.cat(parts, dim=-1)
     dx = mlp(sd, "torso_deform_net", h, 3)
     xc = (x + dx).clamp(-1, 1).float()
@@ -280,8 +290,10 @@ def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh,
     return weights_sum, depth, image, nears, fars
 
 
-def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_gamma=None, max_steps=None, T_thresh=1e-4, trace=None):
-    """One frame: the dict `NeRFRenderer.render` / `RADNeRFTorso.render` return at inference."""
+def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_gamma=None, max_steps=None, T_thresh=1e-4, trace=None,
+           head_aware_branch=False):
+    """One frame: the dict `NeRFRenderer.render` / `RADNeRFTorso.render` return at inference.  `head_aware_branch` fixes the coin the
+    reference flips per frame when torso_head_aware is set (radnerf_torso.py:175-179): True = the torso sees the rendered head."""
     dt_gamma = hp["dt_gamma"] if dt_gamma is None else dt_gamma
     max_steps = hp["max_steps"] if max_steps is None else max_steps
     with torch.no_grad():
@@ -302,7 +314,10 @@ def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_
             torso_alpha, torso_color = torch.zeros(N, 1, device=rays_o.device), torch.zeros(N, 3, device=rays_o.device)
             if mask.any():
                 code = sd["torso_individual_codes"][0] if hp["torso_individual_embedding_dim"] > 0 else None
-                a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code)
+                if hp.get("torso_head_aware", False) and head_aware_branch:
+                    a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code, image[mask], weights_sum.unsqueeze(-1)[mask])
+                else:
+                    a, c, deform = torso_field(sd, hp, bg_coords[mask], poses6, code)
                 torso_alpha[mask], torso_color[mask] = a, c
                 out["deform"] = deform
             bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)

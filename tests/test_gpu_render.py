@@ -499,6 +499,29 @@ def test_second_identity_256_vs_oracle(impl):
     check(render_gpu(m, hp, fi), ref, True)
 
 
+@pytest.mark.parametrize("branch", [False, True])
+def test_torso_head_aware_vs_oracle(branch, monkeypatch):
+    """`torso_head_aware: true` (radnerf_torso.py:36-46, :68-74, :175-179): the head-colour encoder widens both torso MLPs; the reference
+    flips a coin per frame between showing the torso the rendered head and zeros.  Both outcomes against the oracle; render_impl='auto'
+    must route this architecture to the op-by-op path (the fused torso kernel is built for the default layer shapes)."""
+    import random
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = dict(model_fixture(True)[0], torso_head_aware=True)
+    sd = S.make_state_dict(hp, True, seed=2)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    assert m._pick_impl("auto", False, hp["max_steps"]) == "ops"
+    monkeypatch.setattr(random, "random", lambda: 0.25 if branch else 0.75)
+    fi = frame_inputs(sequence(4, 96, 96), 2)
+    out = render_gpu(m, hp, fi)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True, head_aware_branch=branch)
+    check(out, ref, True)
+    other = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True, head_aware_branch=not branch)
+    assert (other["torso_alpha_map"] - ref["torso_alpha_map"]).abs().max() > 1e-3     # the two branches really differ
+
+
 def test_fused_state_follows_the_weights():
     """The fused path renders from packed COPIES of the MLP weights, fold matrices and the occupancy box.  Whatever changes the model after
     a first render -- load_state_dict, an in-place optimizer-style update, a new occupancy bitfield, a dtype round trip that reallocates the
