@@ -270,7 +270,8 @@ def stress_leg(args, hp, torso, seq, dev, impl, timed_loop):
         dt, dts = timed_loop(pipe)
         r = measure_roofline(pipe, impl, args.warmup, min(4, args.steps), PEAK_F32_MFMA_TFLOPS, fast=args.fast)
     return {"value": args.steps / dt, "unit": "frames/s", "repeats": len(dts), "samples_per_frame": r.get("samples_per_frame"),
-            "roofline_frac": r.get("frac"), "kernel_ms_per_frame": r.get("kernel_ms_per_frame"),
+            "roofline_frac": r.get("frac"), "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "tile_fill": r.get("tile_fill"),
+            "example_frame": r.get("example_frame"),
             "fixture": "density row of sigma_net scaled by 0.02 (sigma ~ 1): no ray terminates early, every hit ray marches its full budget"}
 
 

@@ -14,12 +14,12 @@ for s in $STEPS; do
     testv:*) V=${s#testv:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_$V.log; tail -3 $OUT/pytest_$V.log ;;
     bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     benchfast) timeout 600 python bench.py --fast --no-cpu-baseline > $OUT/bench_fast.json 2> $OUT/bench_fast.err; cat $OUT/bench_fast.json
-           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_fast -o k --output-format csv -- python $REPO/bench.py --fast --steps 30 --warmup 5 --no-cpu-baseline --no-overlap > $OUT/prof_fast.log 2>&1); head -6 $OUT/prof_fast/k_kernel_stats.csv | cut -c1-160 ;;
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_fast -o k --output-format csv -- python $REPO/bench.py --fast --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --no-overlap > $OUT/prof_fast.log 2>&1); head -6 $OUT/prof_fast/k_kernel_stats.csv | cut -c1-160 ;;
     ab:*)  # A/B of an experiment library against the product one, interleaved, short benches: ab:<variant>
            V=${s#ab:}
            for rep in 1 2 3; do
              for lib in "" "_$V"; do
-               GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip$lib.so timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/ab_$V.txt
+               GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip$lib.so timeout 300 python bench.py --steps 60 --warmup 10 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/ab_$V.txt
              done
            done ;;
     abm:*) # several experiment libraries against the product one, interleaved: abm:<v1>,<v2>,...
@@ -27,19 +27,19 @@ for s in $STEPS; do
            for rep in 1 2 3; do
              for lib in "" $(echo $VS | tr ',' ' '); do
                L=$REPO/geneface_amd/csrc/libgeneface_hip${lib:+_$lib}.so
-               GF_HIP_LIB=$L timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/abm.txt
+               GF_HIP_LIB=$L timeout 300 python bench.py --steps 60 --warmup 10 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/abm.txt
              done
            done ;;
     trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     tracev:*) V=${s#tracev:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 300 python tools/trace_head.py > $OUT/trace_$V.txt 2>&1; grep -E "phase ms|lifetime|round =" $OUT/trace_$V.txt ;;
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
     prof)  # one frame in flight: per-kernel durations are those of the kernel alone (what bench.py's roofline leg times)
-           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-overlap > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --no-overlap > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160
            # the default command (three frames in flight: durations include the time a kernel shares the GPU with its neighbour frame)
-           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_overlap -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof_overlap.log 2>&1); head -4 $OUT/prof_overlap/k_kernel_stats.csv | cut -c1-160 ;;
-    pmc)   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmc_sq -o sq --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_sq.log 2>&1)
-           (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_fetch.log 2>&1)
-           (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o w --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_write.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_overlap -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline > $OUT/prof_overlap.log 2>&1); head -4 $OUT/prof_overlap/k_kernel_stats.csv | cut -c1-160 ;;
+    pmc)   (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmc_sq -o sq --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_sq.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_fetch.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o w --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmc_write.log 2>&1)
            python tools/pmc_summary.py $OUT ;;
   esac
 done
