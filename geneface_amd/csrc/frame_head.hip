@@ -304,7 +304,8 @@ __device__ __forceinline__ void store16(float* dst, const float (&f)[16]) {
 
 // The field (radnerf.py:73-105) for the round's Mv densely packed samples, NT = ceil(Mv / 32) tiles.
 // DENSITY_ONLY = RADNeRF.density (radnerf.py:107-126): the same layers up to the density row; sigma is left in s.sx[raw].
-template <int NT, bool DENSITY_ONLY = false>
+// AMB_OUT (dense point lists only: the staging arrays are free there): tanh(ambient) is left in s.sdt / s.st [raw].
+template <int NT, bool DENSITY_ONLY = false, bool AMB_OUT = false>
 __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
     constexpr int GEND = DENSITY_ONLY ? (int)gf::G_SIG3 : (int)gf::G_TOTAL;
     const int half = lane >> 5, j = lane & 31;
@@ -391,7 +392,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     if (tile_on) {
         float ambient[2];
         rows_from_lds<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
-        const float x2[2] = {(tanhf(ambient[0]) + 1.0f) / 2.0f, (tanhf(ambient[1]) + 1.0f) / 2.0f};
+        const float th[2] = {tanhf(ambient[0]), tanhf(ambient[1])};
+        const float x2[2] = {(th[0] + 1.0f) / 2.0f, (th[1] + 1.0f) / 2.0f};
+        if constexpr (AMB_OUT) {
+            if (valid && half == 0) { s.sdt[raw] = th[0]; s.st[raw] = th[1]; }
+        }
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16(Hrow + 16 * half, af);
@@ -1165,6 +1170,61 @@ __global__ void __launch_bounds__(kThreads, 2) k_grid_density(const HeadArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- field on a dense point list
+// RADNeRF.forward (radnerf.py:73-105) for M points in ONE launch: what the training marcher, the viewer and update_extra_state hand to the
+// field -- (xyz, dir) lists, not rays.  The same field_round as the renderer, 128 points per round; no autograd (the caller is in
+// inference mode, or renders a frozen head under no_grad: radnerf_torso.py:97-150).
+struct PointArgs {
+    const float* xyz; const float* dirs;      // [M,3] each
+    const float* col_bias;                    // [128] accumulator order: W_color0[:, 144:148] @ individual_code, or NULL = the packed one
+    float* sigma; float* rgb; float* ambient; // [M], [M,3], [M,2] (ambient may be NULL)
+    uint32_t M;
+};
+
+__global__ void __launch_bounds__(kThreads, 2) k_field_points(const HeadArgs a, const PointArgs u) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
+    __syncthreads();
+    if (u.col_bias && tid < 128) s.P[P_SMALL + gf::HS_COLBIAS + tid] = u.col_bias[tid];
+    if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
+    if (tid < 32) {
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
+    }
+    const uint32_t chunks = (u.M + kPass - 1) / kPass;
+#ifndef GF_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        __syncthreads();   // previous round retired
+        const uint32_t i = chunk * kPass + (uint32_t)tid;
+        if (tid < kPass && i < u.M) {
+            s.sx[tid] = u.xyz[(size_t)i * 3]; s.sy[tid] = u.xyz[(size_t)i * 3 + 1]; s.sz[tid] = u.xyz[(size_t)i * 3 + 2];
+            s.p_dx[tid] = u.dirs[(size_t)i * 3]; s.p_dy[tid] = u.dirs[(size_t)i * 3 + 1]; s.p_dz[tid] = u.dirs[(size_t)i * 3 + 2];
+            s.d2r[tid] = (uint8_t)tid;
+            s.rrank[tid] = (uint8_t)tid;
+        }
+        const uint32_t left = u.M - chunk * kPass;
+        const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
+        __syncthreads();
+        const uint32_t nt = (Mv + 31) / 32;
+        if (nt == 4) field_round<4, false, true>(a, s, Mv, wave, lane);
+        else if (nt == 3) field_round<3, false, true>(a, s, Mv, wave, lane);
+        else if (nt == 2) field_round<2, false, true>(a, s, Mv, wave, lane);
+        else field_round<1, false, true>(a, s, Mv, wave, lane);
+        if (tid < kPass && i < u.M) {
+            u.sigma[i] = s.sx[tid];
+            u.rgb[(size_t)i * 3] = s.sy[tid]; u.rgb[(size_t)i * 3 + 1] = s.sz[tid]; u.rgb[(size_t)i * 3 + 2] = s.ob[tid];
+            if (u.ambient) { u.ambient[(size_t)i * 2] = s.sdt[tid]; u.ambient[(size_t)i * 2 + 1] = s.st[tid]; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- frame setup
 struct InitArgs {
     gf::MarchParams mp;
@@ -1414,6 +1474,34 @@ GF_EXPORT int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, f
     const uint32_t chunks = (uint32_t)((total + kPass - 1) / kPass);
     hipLaunchKernelGGL(k_grid_density, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ga);
     return gf_check_launch("grid_density");
+}
+
+// RADNeRF.forward (radnerf.py:73-105) on a dense point list, inference arithmetic (no autograd): sigma [M], rgb [M,3], ambient [M,2]
+// (tanh output; may be NULL).  Uses f's tables, level scales, packed head weights, amb_bias, bound, gridtype, interp.
+// col_bias_or_null: [128] W_color0[:, 144:148] @ individual_code in accumulator order (gf_clayout_perm), NULL = the code packed into head_pack.
+GF_EXPORT int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                               float* sigma, float* rgb, float* ambient_or_null, void* stream) {
+    if (M == 0) return GF_OK;
+    if (!f || !xyz || !dirs || !sigma || !rgb) return gf_set_error(GF_ERR_INVALID, "field_forward: null pointer");
+    if (!f->pos_table || !f->pos_offsets || !f->amb_table || !f->amb_offsets || !f->head_pack || !f->amb_bias)
+        return gf_set_error(GF_ERR_INVALID, "field_forward: null pointer in the field description");
+    if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "field_forward: gridtype/interp must be 0 or 1");
+    HeadArgs ha = {};
+    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
+        return gf_set_error(GF_ERR_INVALID, "field_forward: bad grid levels");
+    ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
+    ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
+    ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
+    PointArgs pa = {xyz, dirs, col_bias_or_null, sigma, rgb, ambient_or_null, M};
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+            return gf_set_error(GF_ERR_HIP, "field_forward: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
+        attr_set = true;
+    }
+    const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
+    hipLaunchKernelGGL(k_field_points, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
+    return gf_check_launch("field_forward");
 }
 
 GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {

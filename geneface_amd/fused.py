@@ -87,6 +87,8 @@ class FusedState:
         self._head_pack16 = None            # fast path: packed on first use (pack16)
         # ambient L1's cond_feat columns, rows in accumulator-layout order: amb_bias = W_cond @ cond_feat per frame
         self.W_cond = a[0].weight.detach()[self.perm.to(dev), 32:].contiguous()
+        # colour L1's identity-code columns, same row order: col_bias = W_ind @ individual_code (field_forward with a per-call code)
+        self.W_ind = c[0].weight.detach()[self.perm.to(dev), 144:].contiguous() if model.individual_embedding_dim > 0 else None
 
         pe, ae = model.position_embedder, model.ambient_embedder
         self.pos_S, self.amb_S = float(np.log2(pe.per_level_scale)), float(np.log2(ae.per_level_scale))
@@ -380,6 +382,38 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
             if bool(mask.any()):
                 results["deform"] = out_deform[mask]
         return results
+
+
+def field_forward(model, position, direction, cond_feat, individual_code):
+    """RADNeRF.forward (radnerf.py:73-105) for a dense point list in one launch (gf_field_forward): sigma [M], color [M,3], ambient [M,2].
+    Inference arithmetic, no autograd graph: callers are in eval / no_grad context (viewer, frozen head of torso training, op-by-op
+    render loop)."""
+    with torch.no_grad():
+        st = get_state(model)
+        dev = position.device
+        x = position.detach().reshape(-1, 3).float().contiguous()
+        d = direction.detach().reshape(-1, 3).float().contiguous()
+        M = x.shape[0]
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        amb = torch.empty(M, 2, dtype=torch.float32, device=dev)
+        if M == 0:
+            return sigma, rgb, amb
+        amb_bias = torch.mv(st.W_cond, cond_feat.detach().reshape(-1).float())
+        col_bias = None
+        if st.W_ind is not None:
+            code = individual_code.detach().reshape(-1).float() if individual_code is not None else torch.zeros(st.W_ind.shape[1], device=dev)
+            col_bias = torch.mv(st.W_ind, code)
+        f = GfFrame()
+        pe, ae = model.position_embedder, model.ambient_embedder
+        f.bound = float(model.bound)
+        f.pos_table, f.pos_offsets = ptr(pe.embeddings, torch.float32), ptr(pe.offsets, torch.int32)
+        f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+        f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
+        f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
+        check(lib().gf_field_forward(C.byref(f), ptr(x, torch.float32), ptr(d, torch.float32), M, ptr(col_bias, torch.float32, allow_none=True),
+                                     ptr(sigma), ptr(rgb), ptr(amb), current_stream(dev)))
+        return sigma, rgb, amb
 
 
 def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:

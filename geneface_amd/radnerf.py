@@ -73,7 +73,15 @@ class RADNeRF(NeRFRenderer):
         h = self.sigma_net(torch.cat([pos_feat, ambient_feat], dim=-1))
         return trunc_exp(h[..., 0]), h[..., 1:], ambient_pos
 
+    def _fused_field_ok(self, position):
+        """One-launch field (fused.field_forward) when nothing can ask for gradients and the kernels cover this model."""
+        return (not torch.is_grad_enabled() and position.is_cuda and self.render_impl in ("auto", "fused")
+                and self._pick_impl("auto", False, 1) == "fused")
+
     def forward(self, position, direction, cond_feat, individual_code):
+        if self._fused_field_ok(position):
+            from .fused import field_forward
+            return field_forward(self, position, direction, cond_feat, individual_code)
         sigma, geo_feat, ambient_pos = self._geometry(position, cond_feat)
         parts = [self.direction_embedder(direction), geo_feat]
         if individual_code is not None:

@@ -230,6 +230,13 @@ uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field);
  *   device scratch; stats_dev[0] = mean_density, [1] = threshold used.
  * gf_mark_untrained_grid: cells outside every camera frustum get density -1.  poses: device [B,4,4] c2w, ngp axes. */
 int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, float density_scale, float* tmp_grid, void* stream);
+/* RADNeRF.forward (radnerf.py:73-105) for a dense point list in one launch, inference arithmetic (no autograd): what the reference runs
+ * as ~40 launches per call for the viewer, for the frozen head of torso training (radnerf_torso.py:97-150, under no_grad) and for any
+ * eval-mode model(x, d, cond_feat, code).  xyz, dirs [M,3]; sigma [M], rgb [M,3], ambient_or_null [M,2] (the tanh output).
+ * col_bias_or_null: [128] = W_color0[:, 144:148] @ individual_code in accumulator order (gf_clayout_perm); NULL = the code packed into
+ * f->head_pack.  Reads f's tables, level scales, head_pack, amb_bias, bound, gridtype, interp. */
+int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                     float* sigma, float* rgb, float* ambient_or_null, void* stream);
 uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
 int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
                    uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);

@@ -119,6 +119,32 @@ def test_field_query_vs_oracle():
     assert (ta.cpu() - ta_ref).abs().max() < 1e-4 and (tc.cpu() - tc_ref).abs().max() < 1e-4 and (tdx.cpu() - tdx_ref).abs().max() < 1e-4
 
 
+def test_field_forward_one_launch_vs_oracle():
+    """model(x, d, cond_feat, code) outside autograd (viewer, frozen head of torso training, the op-by-op render loop) is ONE launch of the
+    renderer's own field core over the point list (gf_field_forward), with the caller's condition vector and identity code; under
+    autograd the same call builds the torch graph."""
+    hp, sd, model = build(True, "fused")
+    model.render_impl = "auto"
+    g = torch.Generator().manual_seed(5)
+    for M in (5000, 1, 129):
+        x = (torch.rand(M, 3, generator=g) * 2 - 1) * torch.tensor([0.5, 0.3, 0.5])
+        d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+        cf = R.cal_cond_feat(sd, hp, torch.randn(5, 1, 204, generator=g))
+        code = sd["individual_embeddings"][7]
+        s_ref, c_ref, a_ref = R.head_field(sd, hp, x, d, cf, code)
+        with torch.no_grad():
+            s, c, a = model(x.to(DEV), d.to(DEV), cf.to(DEV), model.individual_embeddings[7])
+        assert not s.requires_grad and s.shape == (M,) and c.shape == (M, 3) and a.shape == (M, 2)
+        assert (a.cpu() - a_ref).abs().max() < 1e-5
+        assert ((s.cpu() - s_ref).abs() / s_ref.abs().clamp(min=1e-3)).max() < 2e-3   # exp() amplifies 1e-6-level logit noise
+        assert (c.cpu() - c_ref).abs().max() < 1e-4
+    with torch.no_grad():
+        s0, c0, a0 = model(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV), cf.to(DEV), model.individual_embeddings[0])
+    assert s0.numel() == 0 and c0.shape == (0, 3)
+    s2, c2, a2 = model(x.to(DEV), d.to(DEV), cf.to(DEV), model.individual_embeddings[7])      # grad mode: the autograd route
+    assert s2.requires_grad and (s2.detach() - s).abs().max() / s.abs().max() < 2e-3
+
+
 @pytest.mark.parametrize("torso", [False, True])
 def test_frame_pipeline_pose_mode_vs_oracle(torso):
     """FramePipeline (the frame loop of base_nerf_infer.py:81-106): rays generated inside the kernel from the pose,
