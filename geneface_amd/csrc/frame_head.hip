@@ -274,6 +274,30 @@ __device__ __forceinline__ void obw_store(float* Hw, const floatx16 (&acc)[4]) {
         }
 }
 
+// Training forward (gf_field_forward with save buffers): what the backward pass needs of every layer, as [M, width] fp32 in global memory.
+struct SaveBufs {
+    float *f3, *ha1, *ha2, *f2, *hs1, *hs2, *geo, *hc1;   // [M,32] [M,128] [M,128] [M,32] [M,128] [M,128] [M,128] [M,128]
+};
+
+// The values obw_store writes to LDS, also to row (gbase + sample) of a [M,128] matrix: this lane's 4 consecutive floats per (tile, q) --
+// the wave's four stores per tile complete one 128-byte line of every sample row.
+template <int NT, bool RELU>
+__device__ __forceinline__ void obw_save(float* __restrict__ G, uint32_t gbase, uint32_t Mv, int wave, int lane, const floatx16 (&acc)[4]) {
+    const int half = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if ((uint32_t)(t * 32 + j) < Mv) {
+            float* row = G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+                *reinterpret_cast<float4*>(row + 8 * q) = v;
+            }
+        }
+    }
+}
+
 // NOUT skinny outputs of one sample on a lane pair: lane half h sums features 64h .. 64h+63 of the sample's row, the halves
 // are added with one cross-half exchange (both lanes end up with the same value).
 template <int NOUT>
@@ -305,8 +329,10 @@ __device__ __forceinline__ void store16(float* dst, const float (&f)[16]) {
 // The field (radnerf.py:73-105) for the round's Mv densely packed samples, NT = ceil(Mv / 32) tiles.
 // DENSITY_ONLY = RADNeRF.density (radnerf.py:107-126): the same layers up to the density row; sigma is left in s.sx[raw].
 // AMB_OUT (dense point lists only: the staging arrays are free there): tanh(ambient) is left in s.sdt / s.st [raw].
-template <int NT, bool DENSITY_ONLY = false, bool AMB_OUT = false>
-__device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane) {
+// SAVE (dense point lists only, dense index == point index - gbase): every layer's activations go to `sv` as well (training forward).
+template <int NT, bool DENSITY_ONLY = false, bool AMB_OUT = false, bool SAVE = false>
+__device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, uint32_t Mv, int wave, int lane, const SaveBufs* sv = nullptr,
+                                            uint32_t gbase = 0) {
     constexpr int GEND = DENSITY_ONLY ? (int)gf::G_SIG3 : (int)gf::G_TOTAL;
     const int half = lane >> 5, j = lane & 31;
     // lane-pair view (grid lookups, skinny layers): sample sI of this wave's tile
@@ -351,6 +377,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         float pf[16];
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16(Hrow + 16 * half, pf);
+        if constexpr (SAVE) {
+            if (valid) store16(sv->f3 + (size_t)(gbase + sI) * 32 + 16 * half, pf);
+        }
 #ifdef GF_DIAG
         dkey = valid ? s.dkey[raw] : 0xFFFFFFFFu;
         float c = 0.0f;
@@ -373,6 +402,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(10);
     obw_store<NT, true>(Hw, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->ha1, gbase, Mv, wave, lane, A);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
@@ -385,6 +415,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(14);
     obw_store<NT, true>(Hw, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->ha2, gbase, Mv, wave, lane, A);
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
@@ -400,6 +431,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16(Hrow + 16 * half, af);
+        if constexpr (SAVE) {
+            if (valid) store16(sv->f2 + (size_t)(gbase + sI) * 32 + 16 * half, af);
+        }
 #ifdef GF_DIAG
         float c = 0.0f;
         for (int i = 0; i < 16; i++) c += af[i];
@@ -423,6 +457,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(20);
     obw_store<NT, true>(Hw, S);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hs1, gbase, Mv, wave, lane, S);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
@@ -435,6 +470,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(24);
     obw_store<NT, true>(Hw, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hs2, gbase, Mv, wave, lane, A);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -461,6 +497,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(28);
     obw_store<NT, false>(Hw, A);   // no activation
+    if constexpr (SAVE) obw_save<NT, false>(sv->geo, gbase, Mv, wave, lane, A);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
@@ -504,6 +541,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(32);
     obw_store<NT, true>(Hw, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hc1, gbase, Mv, wave, lane, A);
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
@@ -1179,8 +1217,10 @@ struct PointArgs {
     const float* col_bias;                    // [128] accumulator order: W_color0[:, 144:148] @ individual_code, or NULL = the packed one
     float* sigma; float* rgb; float* ambient; // [M], [M,3], [M,2] (ambient may be NULL)
     uint32_t M;
+    SaveBufs sv;                              // SAVE launches only
 };
 
+template <bool SAVE>
 __global__ void __launch_bounds__(kThreads, 2) k_field_points(const HeadArgs a, const PointArgs u) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
@@ -1213,10 +1253,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_points(const HeadArgs a, 
         const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
         __syncthreads();
         const uint32_t nt = (Mv + 31) / 32;
-        if (nt == 4) field_round<4, false, true>(a, s, Mv, wave, lane);
-        else if (nt == 3) field_round<3, false, true>(a, s, Mv, wave, lane);
-        else if (nt == 2) field_round<2, false, true>(a, s, Mv, wave, lane);
-        else field_round<1, false, true>(a, s, Mv, wave, lane);
+        const uint32_t gbase = chunk * kPass;
+        if (nt == 4) field_round<4, false, true, SAVE>(a, s, Mv, wave, lane, &u.sv, gbase);
+        else if (nt == 3) field_round<3, false, true, SAVE>(a, s, Mv, wave, lane, &u.sv, gbase);
+        else if (nt == 2) field_round<2, false, true, SAVE>(a, s, Mv, wave, lane, &u.sv, gbase);
+        else field_round<1, false, true, SAVE>(a, s, Mv, wave, lane, &u.sv, gbase);
         if (tid < kPass && i < u.M) {
             u.sigma[i] = s.sx[tid];
             u.rgb[(size_t)i * 3] = s.sy[tid]; u.rgb[(size_t)i * 3 + 1] = s.sz[tid]; u.rgb[(size_t)i * 3 + 2] = s.ob[tid];
@@ -1479,8 +1520,8 @@ GF_EXPORT int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, f
 // RADNeRF.forward (radnerf.py:73-105) on a dense point list, inference arithmetic (no autograd): sigma [M], rgb [M,3], ambient [M,2]
 // (tanh output; may be NULL).  Uses f's tables, level scales, packed head weights, amb_bias, bound, gridtype, interp.
 // col_bias_or_null: [128] W_color0[:, 144:148] @ individual_code in accumulator order (gf_clayout_perm), NULL = the code packed into head_pack.
-GF_EXPORT int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
-                               float* sigma, float* rgb, float* ambient_or_null, void* stream) {
+static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                              float* sigma, float* rgb, float* ambient_or_null, const gf_field_saves_t* saves, void* stream) {
     if (M == 0) return GF_OK;
     if (!f || !xyz || !dirs || !sigma || !rgb) return gf_set_error(GF_ERR_INVALID, "field_forward: null pointer");
     if (!f->pos_table || !f->pos_offsets || !f->amb_table || !f->amb_offsets || !f->head_pack || !f->amb_bias)
@@ -1492,16 +1533,37 @@ GF_EXPORT int gf_field_forward(const gf_frame_t* f, const float* xyz, const floa
     ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
     ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
-    PointArgs pa = {xyz, dirs, col_bias_or_null, sigma, rgb, ambient_or_null, M};
+    PointArgs pa = {xyz, dirs, col_bias_or_null, sigma, rgb, ambient_or_null, M, {}};
+    if (saves) {
+        if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1)
+            return gf_set_error(GF_ERR_INVALID, "field_forward_train: null save buffer");
+        pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1};
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
             return gf_set_error(GF_ERR_HIP, "field_forward: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
         attr_set = true;
     }
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
-    hipLaunchKernelGGL(k_field_points, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
+    const dim3 grid(chunks < 512u ? chunks : 512u);
+    if (saves) hipLaunchKernelGGL(k_field_points<true>, grid, dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
+    else hipLaunchKernelGGL(k_field_points<false>, grid, dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
     return gf_check_launch("field_forward");
+}
+
+GF_EXPORT int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                               float* sigma, float* rgb, float* ambient_or_null, void* stream) {
+    return field_forward_impl(f, xyz, dirs, M, col_bias_or_null, sigma, rgb, ambient_or_null, nullptr, stream);
+}
+
+// The same launch for the training forward: additionally every layer's activations, which the backward pass (geneface_amd/train_field.py)
+// turns into weight / table / input gradients.
+GF_EXPORT int gf_field_forward_train(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                                     float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream) {
+    if (!saves || !ambient) return gf_set_error(GF_ERR_INVALID, "field_forward_train: null pointer");
+    return field_forward_impl(f, xyz, dirs, M, col_bias_or_null, sigma, rgb, ambient, saves, stream);
 }
 
 GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {

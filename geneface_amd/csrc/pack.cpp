@@ -17,6 +17,8 @@ inline uint32_t hidden_col(uint32_t t, uint32_t h) { return (t / 16) * 32 + c_ro
 
 GF_EXPORT uint32_t gf_head_pack_floats(void) { return gf::HP_TOTAL; }
 GF_EXPORT uint32_t gf_torso_pack_floats(void) { return gf::TP_TOTAL; }
+// float offset of the 128 folded identity-code biases (W_color0[:, 144:148] @ code, gf_clayout_perm row order) inside the head pack
+GF_EXPORT uint32_t gf_head_pack_colbias_offset(void) { return gf::HP_SMALL + gf::HS_COLBIAS; }
 
 // perm[i] (i = ob*32 + half*16 + r) = feature index ob*32 + c_row(r, half): the order in which per-frame bias
 // vectors (amb_bias) must be handed to the kernels.

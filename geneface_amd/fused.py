@@ -60,6 +60,23 @@ def _hp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _pack_index(pack, shapes, n_out):
+    """Where every float of a packed layout comes from: run the HOST packer on weights whose values are their own (1-based) flat indices
+    and read the layout back as an index map (0 = a slot the packer fills with zero / a derived value).  With it a weight update becomes
+    one device-side gather instead of a device -> host -> pack -> device round trip per training step."""
+    arrays, off = [], 1
+    for shp in shapes:
+        n = int(np.prod(shp))
+        arrays.append(np.arange(off, off + n, dtype=np.float32).reshape(shp))
+        off += n
+    assert off < (1 << 24), "flat indices must be exact in fp32"
+    out = np.zeros(n_out, dtype=np.float32)
+    pack(arrays, out)
+    idx = out.astype(np.int64)
+    assert np.array_equal(idx.astype(np.float32), out) and idx.min() >= 0 and idx.max() < off
+    return torch.from_numpy(idx)
+
+
 class FusedState:
     """Everything the kernels need that depends only on the model (built once, device resident)."""
 
@@ -89,6 +106,9 @@ class FusedState:
         self.W_cond = a[0].weight.detach()[self.perm.to(dev), 32:].contiguous()
         # colour L1's identity-code columns, same row order: col_bias = W_ind @ individual_code (field_forward with a per-call code)
         self.W_ind = c[0].weight.detach()[self.perm.to(dev), 144:].contiguous() if model.individual_embedding_dim > 0 else None
+        if self.W_ind is not None:   # the folded identity-code bias is always this device product (refresh_weights computes the same one)
+            off = int(L.gf_head_pack_colbias_offset())
+            self.head_pack[off:off + 128] = torch.mv(self.W_ind, model.individual_embeddings[0].detach().float())
 
         pe, ae = model.position_embedder, model.ambient_embedder
         self.pos_S, self.amb_S = float(np.log2(pe.per_level_scale)), float(np.log2(ae.per_level_scale))
@@ -115,9 +135,63 @@ class FusedState:
             self.torso_S = float(np.log2(model.torso_embedder.per_level_scale))
         self._ws = {}
         self.cond = self._build_cond(model)
+        self._head_idx = self._torso_idx = None      # index maps of the packed layouts (refresh_weights), built on first use
         # everything above is a COPY of (or a raw pointer into) model state: remember what it was built from (see get_state)
         self._watch = _watched_tensors(model)
         self.stamp = _stamp(self._watch)
+
+    # ---- in-place weight updates (a training step, load_state_dict, a broadcast): repack on the device, no host round trip
+    @staticmethod
+    def _head_weights(model):
+        a, s, c = model.ambient_net.net, model.sigma_net.net, model.color_net.net
+        return [a[0].weight, a[1].weight, a[2].weight, s[0].weight, s[1].weight, s[2].weight, c[0].weight, c[1].weight]
+
+    @staticmethod
+    def _torso_weights(model):
+        d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
+        return [d[0].weight, d[1].weight, d[2].weight, cn[0].weight, cn[1].weight, cn[2].weight]
+
+    def refresh_weights(self, model):
+        """The packed copies follow the model's current weights: per pack one cat + one gather on the device."""
+        L = lib()
+        dev = self.device
+        if self._head_idx is None:
+            ws = self._head_weights(model)
+            self._head_idx = _pack_index(lambda arr, out: check(L.gf_head_pack(*[_hp(a) for a in arr], None, _hp(out))),
+                                         [tuple(w.shape) for w in ws], L.gf_head_pack_floats()).to(dev)
+            self._colbias_off = int(L.gf_head_pack_colbias_offset())
+        zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        flat = torch.cat([zero] + [w.detach().reshape(-1).float() for w in self._head_weights(model)])
+        self.head_pack = flat[self._head_idx]
+        a, c = model.ambient_net.net, model.color_net.net
+        perm = self.perm.to(dev)
+        self.W_cond = a[0].weight.detach()[perm, 32:].contiguous()
+        if model.individual_embedding_dim > 0:
+            self.W_ind = c[0].weight.detach()[perm, 144:].contiguous()
+            self.head_pack[self._colbias_off:self._colbias_off + 128] = torch.mv(self.W_ind, model.individual_embeddings[0].detach().float())
+        self._head_pack16 = None
+        if self.has_torso:
+            if self._torso_idx is None:
+                ws = self._torso_weights(model)
+                self._torso_idx = _pack_index(lambda arr, out: check(L.gf_torso_pack(*[_hp(a) for a in arr], _hp(out))),
+                                              [tuple(w.shape) for w in ws], L.gf_torso_pack_floats()).to(dev)
+            flat = torch.cat([zero] + [w.detach().reshape(-1).float() for w in self._torso_weights(model)])
+            self.torso_pack = flat[self._torso_idx]
+            d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
+            self.W_tconst = torch.cat([d[0].weight.detach()[perm[:64], 42:], cn[0].weight.detach()[perm[:32], 74:]], dim=0).contiguous()
+            if self.cond is not None and model.torso_individual_embedding_dim > 0:
+                self._torso_code = model.torso_individual_codes[0].detach().contiguous()
+        if self.cond is not None:          # the cached gf_cond_t points at W_cond / W_tconst / the torso code
+            self.cond.W_cond = ptr(self.W_cond)
+            if self.has_torso:
+                self.cond.W_tconst = ptr(self.W_tconst)
+                self.cond.torso_code = ptr(self._torso_code) if getattr(self, "_torso_code", None) is not None else None
+
+    def refresh_occupancy(self, model):
+        bits = np.ascontiguousarray(model.density_bitfield.detach().cpu().numpy().astype(np.uint8))
+        box = np.zeros(6, dtype=np.float32)
+        check(lib().gf_occupancy_aabb(_hp(bits), int(model.cascade), int(model.grid_size), float(model.bound), _hp(box)))
+        self.occ_aabb = [float(v) for v in box]
 
     def pack16(self, model):
         """f16 A-operand streams of the head's six MFMA layers (gf_frame_t.precision = 1, the "fast" parity tier)."""
@@ -226,12 +300,26 @@ def _stamp(tensors):
 
 
 def get_state(model) -> FusedState:
-    """The model's FusedState, rebuilt whenever a tensor it was packed from has changed since (train -> validate loops,
-    load_state_dict, broadcast_model_, dtype / device moves): the packed copies can never go stale silently."""
+    """The model's FusedState, brought up to date whenever a tensor it was packed from has changed since (training steps, train ->
+    validate loops, load_state_dict, broadcast_model_, dtype / device moves): the packed copies can never go stale silently.  Values
+    changed in place are re-gathered on the device (refresh_weights); reallocated tensors or a new device rebuild everything."""
     st = getattr(model, "_fused_state", None)
-    if st is None or st.device != model.density_bitfield.device or _stamp(st._watch) != st.stamp:
+    if st is None or st.device != model.density_bitfield.device:
         st = FusedState(model)
         object.__setattr__(model, "_fused_state", st)
+        return st
+    stamp = _stamp(st._watch)
+    if stamp != st.stamp:
+        if any(a[1] != b[1] for a, b in zip(stamp, st.stamp)):          # a data_ptr moved
+            st = FusedState(model)
+            object.__setattr__(model, "_fused_state", st)
+            return st
+        n_param = len(list(model.parameters()))
+        if stamp[n_param:] != st.stamp[n_param:]:                       # an occupancy buffer changed in place
+            st.refresh_occupancy(model)
+        if stamp[:n_param] != st.stamp[:n_param]:
+            st.refresh_weights(model)
+        st.stamp = stamp
     return st
 
 

@@ -78,10 +78,18 @@ class RADNeRF(NeRFRenderer):
         return (not torch.is_grad_enabled() and position.is_cuda and self.render_impl in ("auto", "fused")
                 and self._pick_impl("auto", False, 1) == "fused")
 
+    #: "auto": under autograd the field is ONE graph node (train_field.head_field: fused forward, hand-written backward) whenever the
+    #: kernels cover this model; "ops": the reference's op-by-op torch graph.
+    field_impl = "auto"
+
     def forward(self, position, direction, cond_feat, individual_code):
         if self._fused_field_ok(position):
             from .fused import field_forward
             return field_forward(self, position, direction, cond_feat, individual_code)
+        if (torch.is_grad_enabled() and position.is_cuda and self.field_impl == "auto" and self.render_impl in ("auto", "fused")
+                and self._pick_impl("auto", False, 1) == "fused"):
+            from .train_field import head_field
+            return head_field(self, position, direction, cond_feat, individual_code)
         sigma, geo_feat, ambient_pos = self._geometry(position, cond_feat)
         parts = [self.direction_embedder(direction), geo_feat]
         if individual_code is not None:

@@ -237,6 +237,20 @@ int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, float densi
  * f->head_pack.  Reads f's tables, level scales, head_pack, amb_bias, bound, gridtype, interp. */
 int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
                      float* sigma, float* rgb, float* ambient_or_null, void* stream);
+/* Training forward of the same field (radnerf.py:73-105 under autograd): the one launch also leaves what the backward pass needs of
+ * every layer -- post-ReLU activations and the two grid feature sets -- as row-major [M, width] fp32 matrices. */
+typedef struct gf_field_saves {
+    float* f3;    /* [M,32]  3-D grid features (position_embedder output) */
+    float* ha1;   /* [M,128] ambient_net layer 0 output after ReLU */
+    float* ha2;   /* [M,128] ambient_net layer 1 output after ReLU */
+    float* f2;    /* [M,32]  2-D grid features (ambient_embedder output) */
+    float* hs1;   /* [M,128] sigma_net layer 0 output after ReLU */
+    float* hs2;   /* [M,128] sigma_net layer 1 output after ReLU */
+    float* geo;   /* [M,128] geometry feature (sigma_net output rows 1..128, no activation) */
+    float* hc1;   /* [M,128] color_net layer 0 output after ReLU */
+} gf_field_saves_t;
+int gf_field_forward_train(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                           float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream);
 uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
 int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
                    uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);
@@ -249,6 +263,7 @@ int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, uint32_t H
 int gf_grid_levels_fusable(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H);
 uint32_t gf_head_pack_floats(void);
 uint32_t gf_torso_pack_floats(void);
+uint32_t gf_head_pack_colbias_offset(void);   /* where gf_head_pack puts the 128 folded identity-code biases (float offset) */
 int gf_clayout_perm(uint32_t* perm128_host);
 /* HOST pointers: nn.Linear weights [out,in] of ambient_net / sigma_net / color_net (cond_encoder.py:92-111), individual code or NULL */
 int gf_head_pack(const float* amb0_host, const float* amb1_host, const float* amb2_host, const float* sig0_host,

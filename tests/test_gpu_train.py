@@ -164,7 +164,8 @@ def test_sh_and_freq_encoder_autograd_vs_oracle():
 
 # ----------------------------------------------------------------------------------------------- training branch of render()
 @pytest.mark.parametrize("torso", [False, True])
-def test_render_training_branch_gradients_vs_oracle(torso):
+@pytest.mark.parametrize("field_impl", ["auto", "ops"])
+def test_render_training_branch_gradients_vs_oracle(torso, field_impl):
     """model.train(); model.render(...) takes the reference's training branch (renderer.py:296-313 / radnerf_torso.py:93-198): one
     loss, one backward, every parameter gradient against the oracle's differentiable restatement on the CPU."""
     from geneface_amd.radnerf import RADNeRF
@@ -182,6 +183,7 @@ def test_render_training_branch_gradients_vs_oracle(torso):
     model = (RADNeRFTorso if torso else RADNeRF)(hp)
     model.load_state_dict(sd, strict=True)
     model = model.to(DEV).train()
+    model.field_impl = field_impl      # "auto": the field is one autograd node (fused forward, hand-written backward); "ops": the torch graph
     to = lambda t: t.to(DEV)
     out = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
                        bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
@@ -211,6 +213,40 @@ def test_render_training_branch_gradients_vs_oracle(torso):
         ev = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
                           bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
     assert "weights_sum" not in ev and ev["rgb_map"].shape == out["rgb_map"].shape
+
+
+def test_fused_training_field_vs_op_graph():
+    """RADNeRF.forward under autograd, one node (train_field.head_field) against the op-by-op torch graph on the same 20 000 points: the
+    three outputs and the gradient of every tensor the field touches (two grid tables, eight weights, the condition encoder through
+    cond_feat, the identity code), for an arbitrary downstream loss."""
+    from geneface_amd.radnerf import RADNeRF
+    hp, sd = model_fixture(False)
+    g = torch.Generator().manual_seed(6)
+    M = 20000
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * torch.tensor([0.5, 0.3, 0.5])).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1).to(DEV)
+    cond = torch.randn(5, 1, 204, generator=g).to(DEV)
+    ws, wc, wa = torch.rand(M, generator=g).to(DEV), torch.rand(M, 3, generator=g).to(DEV), torch.randn(M, 2, generator=g).to(DEV)
+    res = {}
+    for impl in ("ops", "auto"):
+        m = RADNeRF(hp)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).train()
+        m.field_impl = impl
+        cf = m.cal_cond_feat(cond)
+        s_, c_, a_ = m(x, d, cf, m.individual_embeddings[3])
+        loss = (torch.log1p(s_) * ws).sum() * 1e-3 + (c_ * wc).sum() * 1e-2 + (a_ * wa).sum() * 1e-2 + a_.abs().sum() * 1e-3
+        loss.backward()
+        res[impl] = (s_.detach(), c_.detach(), a_.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    so, co, ao, go = res["ops"]
+    sf, cf_, af, gf = res["auto"]
+    assert ((sf - so).abs() / so.abs().clamp(min=1e-3)).max() < 2e-3 and (cf_ - co).abs().max() < 1e-4 and (af - ao).abs().max() < 1e-5
+    assert set(gf) == set(go) and len(gf) >= 24
+    for n in go:
+        diff = (gf[n] - go[n]).double()
+        l2 = float(diff.norm() / go[n].double().norm().clamp(min=1e-20))
+        worst = float(diff.abs().max()) / max(float(go[n].abs().max()), 1e-12)
+        assert l2 < 5e-3 and worst < 2e-2, (n, l2, worst)     # the single-element attention bias sits on a cancelling sum: 3e-3
 
 
 def test_training_branch_under_fp16_autocast():
