@@ -258,9 +258,15 @@ __global__ void __launch_bounds__(kTB) k_train_count(gf::MarchParams mp, const f
     if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
 }
 
+// Point offsets are an exclusive prefix sum of the per-ray counts in ray order, started at block `rot` and wrapping around: when the
+// caller's buffer (mean_count of the last steps) is too small, the rays that lose their samples are the tail of THAT order.  rot comes from
+// the call's own jitter (noises[0], uniform in [0,1) under perturb=True, 0 otherwise), so with perturbation the dropped block moves from call
+// to call like the reference's (arbitrary, atomics decide), instead of always being the bottom rows of a raster-ordered batch; without
+// perturbation the order is plain ray order and the result deterministic.
 __global__ void __launch_bounds__(1024) k_train_scan(uint32_t* __restrict__ block_tot, uint32_t nblocks, int* __restrict__ counter, uint32_t N,
-                                                     uint32_t* __restrict__ base_out) {
+                                                     uint32_t* __restrict__ base_out, const float* __restrict__ noises) {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_total;
     // each thread owns a contiguous run of blocks
     const uint32_t per = (nblocks + 1023) / 1024;
     const uint32_t lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
@@ -274,10 +280,18 @@ __global__ void __launch_bounds__(1024) k_train_scan(uint32_t* __restrict__ bloc
         *base_out = (uint32_t)counter[0];
         counter[0] += (int)run;     // what the reference's atomicAdd(counter, num_steps) accumulates
         counter[1] += (int)N;       // ... and atomicAdd(counter + 1, 1)
+        s_total = run;
     }
     __syncthreads();
     uint32_t run = part[threadIdx.x];
     for (uint32_t i = lo; i < hi; i++) { const uint32_t v = block_tot[i]; block_tot[i] = run; run += v; }
+    uint32_t rot = (uint32_t)(noises[0] * (float)nblocks);
+    rot = rot < nblocks ? rot : nblocks - 1;
+    if (rot == 0) return;           // uniform
+    __syncthreads();
+    const uint32_t er = block_tot[rot], total = s_total;
+    __syncthreads();
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = block_tot[i]; block_tot[i] = i >= rot ? v - er : v - er + total; }
 }
 
 __global__ void __launch_bounds__(kTB) k_train_write(gf::MarchParams mp, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -413,7 +427,7 @@ GF_EXPORT int gf_march_rays_train(const float* rays_o, const float* rays_d, cons
     uint32_t* base = block_tot + nblocks;
     hipStream_t s = gf_stream(stream);
     hipLaunchKernelGGL(k_train_count, dim3(nblocks), dim3(kTB), 0, s, mp, rays_o, rays_d, nears, fars, noises, N, max_steps, counts, prefix, block_tot);
-    hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(1024), 0, s, block_tot, nblocks, counter, N, base);
+    hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(1024), 0, s, block_tot, nblocks, counter, N, base, noises);
     hipLaunchKernelGGL(k_train_write, dim3(nblocks), dim3(kTB), 0, s, mp, rays_o, rays_d, nears, fars, noises, N, M, counts, prefix, block_tot, base, 0,
                        xyzs, dirs, deltas, rays);
     return gf_check_launch("march_rays_train");

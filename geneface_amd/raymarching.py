@@ -94,7 +94,10 @@ class _march_rays_train(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
                 align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
         """-> xyzs [M,3], dirs [M,3], deltas [M,2] (dt, t), rays i32 [N,3] (ray, point offset, point count); see raymarching.py:189-208.
-        Point offsets follow ray order (deterministic; the reference's atomics give an arbitrary order)."""
+        Point offsets follow ray order (deterministic; the reference's atomics give an arbitrary order).  When `mean_count` underestimates
+        the batch, the rays that lose their samples are the tail of that order; under perturb=True the order starts at a block chosen by
+        the call's own jitter, so the victims move from step to step as in the reference instead of always being the last rows of a
+        raster-ordered batch."""
         rays_o = _f32(rays_o).contiguous().view(-1, 3)
         rays_d = _f32(rays_d).contiguous().view(-1, 3)
         density_bitfield = density_bitfield.contiguous()

@@ -38,21 +38,35 @@ def test_march_rays_train_bit_exact_vs_oracle(size, max_steps):
 
 
 def test_march_rays_train_overflow_and_perturb():
+    """A buffer three times too small, with jitter.  The reference hands out point offsets with atomics (any order); the oracle restates the
+    serial order, the product the ray order started at the 256-ray block floor(noises[0] * nblocks) -- so the rays that lose their samples
+    move with the call's jitter instead of always being the tail of the batch.  Rolling the oracle's inputs by that start reproduces the
+    product's buffers exactly."""
     from geneface_amd.compat import _raymarching_face as B
     hp, sd, ro, rd, nears, fars = _scene(48)
     N = ro.shape[0]
     g = torch.Generator().manual_seed(3)
     noises = torch.rand(N, generator=g)
-    full = march_train(hp, sd, ro, rd, nears, fars, noises=noises)
+    noises[0] = 0.6                                   # the entry that also picks the starting block
+    nblocks = (N + 255) // 256
+    r0 = min(int(float(noises[0]) * nblocks), nblocks - 1) * 256
+    assert r0 > 0
+    roll = lambda t: torch.roll(t, -r0, 0).contiguous()
+    full = march_train(hp, sd, roll(ro), roll(rd), roll(nears), roll(fars), noises=roll(noises))
     M = full[4][0].item() // 3
-    ref = march_train(hp, sd, ro, rd, nears, fars, M=M, noises=noises)
+    ref = march_train(hp, sd, roll(ro), roll(rd), roll(nears), roll(fars), M=M, noises=roll(noises))
     d = lambda t: t.to(DEV)
     xyzs, dirs, deltas = torch.zeros(M, 3, device=DEV), torch.zeros(M, 3, device=DEV), torch.zeros(M, 2, device=DEV)
     rays, counter = torch.empty(N, 3, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
     B.march_rays_train(d(ro), d(rd), d(sd["density_bitfield"]), float(hp["bound"]), hp["dt_gamma"], hp["max_steps"], N, 1, hp["grid_size"], M,
                        d(nears), d(fars), xyzs, dirs, deltas, rays, counter, d(noises))
-    assert torch.equal(rays.cpu(), ref[3]) and counter.cpu().tolist() == ref[4].tolist()
+    assert counter.cpu().tolist() == ref[4].tolist()
+    got = rays.cpu()
+    assert torch.equal(got[:, 0], torch.arange(N, dtype=torch.int32))                  # row n describes ray n
+    assert torch.equal(roll(got[:, 1:]), ref[3][:, 1:])                                # offsets / counts of the rolled order
     assert torch.equal(xyzs.cpu(), ref[0]) and torch.equal(deltas.cpu(), ref[2])
+    dropped = (got[:, 2] > 0) & (got[:, 1] + got[:, 2] > M)
+    assert dropped.any() and not dropped[r0:r0 + 256].any()                            # the victims are the tail of the ROTATED order
     # a second call accumulates into the counter like the reference's atomics
     B.march_rays_train(d(ro), d(rd), d(sd["density_bitfield"]), float(hp["bound"]), hp["dt_gamma"], hp["max_steps"], N, 1, hp["grid_size"], M,
                        d(nears), d(fars), xyzs, dirs, deltas, rays, counter, d(noises))
