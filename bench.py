@@ -133,6 +133,11 @@ def legacy_nerf_baseline(seq, rays=4096):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): whatever libraries print while the process runs (RCCL's version banner at communicator
+    # creation, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -145,7 +150,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torchrun (RANK set) the process group is created even for one rank, so a 1-GPU launch exercises the same RCCL init, broadcast,
+    # barrier and all-reduce calls as the 2/4/8-GPU runs
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -179,7 +189,7 @@ def main():
     pipe = FramePipeline(model, hp, seq, dev, frames=shard_range(per_rank * world, rank, world), impl=impl, overlap=not args.no_overlap, in_flight=args.in_flight or None)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -191,7 +201,7 @@ def main():
             p.render_frame(i)
         barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -242,8 +252,9 @@ def main():
         if not args.no_stress and world == 1 and impl == "fused":
             line["stress_fixture"] = stress_leg(args, hp, torso, seq, dev, impl, timed_loop)
         line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

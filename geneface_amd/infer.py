@@ -26,7 +26,7 @@ def broadcast_model_(model: torch.nn.Module, src: int = 0):
     """Make every replica bit-identical to rank `src` with ONE collective per dtype: parameters and buffers are
     flattened into a single contiguous buffer (~26 MB fp32 for head+torso), broadcast, and scattered back."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return model
     tensors = [t for _, t in sorted(list(model.named_parameters()) + list(model.named_buffers()), key=lambda kv: kv[0])]
     by_dtype = {}
