@@ -52,7 +52,10 @@ constexpr int kPool = 128;            // live rays per workgroup
 constexpr int kHS = 132;              // floats per activation row (128 + 4: rows 16 B apart in bank space -> conflict-free b128)
 constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 2 * 16 * 8 /*level meta*/;
 constexpr int kHistBins = gf::kMaxSteps + 2;
-constexpr uint32_t kMarchSlack = 3;   // empty-space skips a ray may add to its requested samples per round
+#ifndef GF_MARCH_SLACK
+#define GF_MARCH_SLACK 12
+#endif
+constexpr uint32_t kMarchSlack = GF_MARCH_SLACK;   // empty-space skips a ray may add to its requested samples per round (A/B 3 / 6 / 12 / 24: 12)
 
 // ---- optional per-round timeline (built only with -DGF_TRACE into libgeneface_hip_trace.so; see tools/trace_head.py) ----
 #ifdef GF_TRACE
@@ -1007,8 +1010,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             const uint32_t mine = n + (rank < extra ? 1u : 0u);
             req = mine < left ? mine : left;
             const uint32_t base = rank * n + (rank < extra ? rank : extra);
-            cnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req, r_t,
-                                [&](uint32_t q, float x, float y, float z, float dt, float t_after, float) {
+            // One sample of look-ahead: the traversal continues to the START of the sample after the requested ones (bounded like the rest).
+            // If there is none, the ray is known to be exhausted in THIS round and retires with the same terminal index (samples + 1) it
+            // would have discovered in the next one -- where it held a pool slot and produced nothing: one empty slot per exiting ray,
+            // 10 % of all slots.  If there is one, the ray clock is rewound to its start, where the next round's march begins anyway.
+            float t_next = 0.0f;
+            cnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u, r_t,
+                                [&](uint32_t q, float x, float y, float z, float dt, float t_after, float t_at) {
+                                    if (q >= req) { t_next = t_at; return; }
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
                                     s.sdt[base + q] = dt; s.st[base + q] = t_after;
 #ifdef GF_DIAG
@@ -1022,7 +1031,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                                     }
                                     s.dkey[base + q] = key;
 #endif
-                                }, req + kMarchSlack);
+                                }, req + 1u + kMarchSlack);
+            if (cnt > req) { cnt = req; r_t = t_next; }
         }
         GF_STAMP(3);
         if (owner) s.rcnt[tid] = (uint8_t)cnt;
@@ -1089,7 +1099,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     break;
                 }
             }
-            if (!died && cnt < req && !(r_t < r_far)) {  // the marcher ran out: the next request finds nothing (raymarching.cu:977)
+            if (!died && !(r_t < r_far)) {  // the marcher ran out (look-ahead included): the next request finds nothing (raymarching.cu:977)
                 died = true;
                 d = r_done + 1;
             }
