@@ -280,13 +280,24 @@ __device__ __forceinline__ void obw_store(float* Hw, const floatx16 (&acc)[4]) {
 // Training forward (gf_field_forward with save buffers): what the backward pass needs of every layer, as [M, width] fp32 in global memory.
 struct SaveBufs {
     float *f3, *ha1, *ha2, *f2, *hs1, *hs2, *geo, *hc1;   // [M,32] [M,128] [M,128] [M,32] [M,128] [M,128] [M,128] [M,128]
+    uint16_t *m_ha1, *m_ha2, *m_hs1, *m_hs2, *m_hc1;      // ReLU masks in ACCUMULATOR layout: [chunk of 128][tile 4][wave 4][lane 64], bit r = register r > 0
 };
 
 // The values obw_store writes to LDS, also to row (gbase + sample) of a [M,128] matrix: this lane's 4 consecutive floats per (tile, q) --
 // the wave's four stores per tile complete one 128-byte line of every sample row.
 template <int NT, bool RELU>
-__device__ __forceinline__ void obw_save(float* __restrict__ G, uint32_t gbase, uint32_t Mv, int wave, int lane, const floatx16 (&acc)[4]) {
+__device__ __forceinline__ void obw_save(float* __restrict__ G, uint32_t gbase, uint32_t Mv, int wave, int lane, const floatx16 (&acc)[4],
+                                         uint16_t* __restrict__ mask = nullptr) {
     const int half = lane >> 5, j = lane & 31;
+    if (mask) {   // the backward pass applies the ReLU derivative from these bits instead of re-reading the activations
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) bits |= (acc[t][r] > 0.0f ? 1u : 0u) << r;
+            mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane] = (uint16_t)bits;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         if ((uint32_t)(t * 32 + j) < Mv) {
@@ -405,7 +416,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(10);
     obw_store<NT, true>(Hw, A);
-    if constexpr (SAVE) obw_save<NT, true>(sv->ha1, gbase, Mv, wave, lane, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->ha1, gbase, Mv, wave, lane, A, sv->m_ha1);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
@@ -418,7 +429,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(14);
     obw_store<NT, true>(Hw, A);
-    if constexpr (SAVE) obw_save<NT, true>(sv->ha2, gbase, Mv, wave, lane, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->ha2, gbase, Mv, wave, lane, A, sv->m_ha2);
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
@@ -460,7 +471,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(20);
     obw_store<NT, true>(Hw, S);
-    if constexpr (SAVE) obw_save<NT, true>(sv->hs1, gbase, Mv, wave, lane, S);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hs1, gbase, Mv, wave, lane, S, sv->m_hs1);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
@@ -473,7 +484,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(24);
     obw_store<NT, true>(Hw, A);
-    if constexpr (SAVE) obw_save<NT, true>(sv->hs2, gbase, Mv, wave, lane, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hs2, gbase, Mv, wave, lane, A, sv->m_hs2);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -544,7 +555,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(32);
     obw_store<NT, true>(Hw, A);
-    if constexpr (SAVE) obw_save<NT, true>(sv->hc1, gbase, Mv, wave, lane, A);
+    if constexpr (SAVE) obw_save<NT, true>(sv->hc1, gbase, Mv, wave, lane, A, sv->m_hc1);
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
@@ -1276,6 +1287,227 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_points(const HeadArgs a, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- field backward (dX chain)
+// The input-gradient chain of RADNeRF.forward for a dense point list in ONE launch (geneface_amd/train_field.py): from (d sigma, d rgb,
+// d ambient) back through colour net -> geometry feature -> sigma net -> 2-D lookup (input gradient, re-gathered) -> ambient net, writing
+// the pre-activation gradient of every layer as an [M, 128] matrix (the weight gradients are tall GEMMs over those and the saved
+// activations) and the gradients of both grid feature sets (-> the table scatter kernels).  Same machinery as the forward: 128 points per
+// round, activations (here: gradients) in the LDS buffer H, wave w owns 32 output features, A operands = TRANSPOSED weight blocks streamed
+// L2 -> registers (gf_field_bwd stream: six 128 x 128 layers, the two narrow ones zero-padded), ReLU derivatives from the forward's mask bits.
+constexpr int BG_C1 = 0, BG_S3 = 16, BG_S2 = 32, BG_S1 = 48, BG_A2 = 64, BG_A1 = 80, BG_TOTAL = 96;
+
+struct BwdArgs {
+    const float* stream;                                   // [4 waves][BG_TOTAL][64][4]
+    const float *g_sigma, *g_rgb, *g_amb;                  // [M], [M,3], [M,2] incoming
+    const float *sigma, *rgb, *amb;                        // forward outputs
+    const uint16_t *m_hc1, *m_hs2, *m_hs1, *m_ha2, *m_ha1; // forward ReLU masks
+    float *g_zc, *g_h0, *g_za;                             // [M,3], [M], [M,2]   pre-activation gradients of the three skinny layers
+    float *g_hc1, *g_geo, *g_hs2, *g_hs1, *g_ha2, *g_ha1;  // [M,128] each
+    float *g_f3, *g_f2;                                    // [M,32] each
+    uint32_t M;
+};
+
+// accumulators -> LDS (and row gbase + sample of G), optionally through the ReLU mask of the layer whose pre-activation gradient this is
+template <int NT, bool MASK>
+__device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
+                                          int lane, const floatx16 (&acc)[4]) {
+    const int half = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        uint32_t bits = 0xFFFFu;
+        if (MASK) bits = mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane];
+        const bool ok = (uint32_t)(t * 32 + j) < Mv;
+        float* row = G ? G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            if (MASK) {
+                v.x = (bits >> (4 * q + 0)) & 1u ? v.x : 0.0f; v.y = (bits >> (4 * q + 1)) & 1u ? v.y : 0.0f;
+                v.z = (bits >> (4 * q + 2)) & 1u ? v.z : 0.0f; v.w = (bits >> (4 * q + 3)) & 1u ? v.w : 0.0f;
+            }
+            *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
+            if (row && ok) *reinterpret_cast<float4*>(row + 8 * q) = v;
+        }
+    }
+}
+
+// a layer whose result was written to H in ROW layout (the two rank-k products): pull this lane's accumulator-layout share back,
+// mask it, write it to H and to G
+template <int NT>
+__device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
+                                              int lane, floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(Hw + t * 32 * kHS + 8 * q);
+            acc[t][4 * q + 0] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
+        }
+    bwd_store<NT, true>(Hw, G, mask, gbase, Mv, wave, lane, acc);
+}
+
+template <int NT>
+__device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t sI = (uint32_t)(wave * 32 + j);
+    const bool tile_on = wave < NT;
+    const bool valid = sI < Mv;
+    const size_t pt = (size_t)gbase + sI;
+    float* Hrow = s.H + sI * kHS;
+    const float* Hb = s.H + j * kHS + 4 * half;
+    float* Hw = s.H + j * kHS + 32 * wave + 4 * half;
+    const char* Ws = reinterpret_cast<const char*>(u.stream) + (size_t)wave * BG_TOTAL * 1024;
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
+    floatx16 A[4];
+    WPipe wp;
+#pragma unroll
+    for (int g = 0; g < kWAhead; g++) wp.q[g] = load_group(Ws, g, lane16);
+
+    // ---- colour tail: d z_c = d rgb * rgb (1 - rgb);  H row <- W_c2^T d z_c  (lane half h writes features 64h .. 64h+63)
+    float gh0 = 0.0f, gamb[2] = {0.0f, 0.0f}, ambv[2] = {0.0f, 0.0f};
+    if (tile_on) {
+        float gz[3] = {0.0f, 0.0f, 0.0f};
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float r = u.rgb[pt * 3 + c]; gz[c] = u.g_rgb[pt * 3 + c] * r * (1.0f - r); }
+            const float sg = u.sigma[pt];
+            gh0 = u.g_sigma[pt] * fminf(fmaxf(sg, 3.0590232e-7f), 3269017.37f);   // trunc_exp backward: g * exp(clamp(x, -15, 15))
+            gamb[0] = u.g_amb[pt * 2]; gamb[1] = u.g_amb[pt * 2 + 1];
+            ambv[0] = u.amb[pt * 2]; ambv[1] = u.amb[pt * 2 + 1];
+            if (half == 0) { u.g_zc[pt * 3] = gz[0]; u.g_zc[pt * 3 + 1] = gz[1]; u.g_zc[pt * 3 + 2] = gz[2]; u.g_h0[pt] = gh0; }
+        }
+        if (half == 0) s.sdt[sI] = gh0;        // per-sample scalar the rank-1 term of the sigma layer reads by column
+        const float* W = s.P + P_SMALL + gf::HS_COL2 + 64 * half;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float4 w0 = *reinterpret_cast<const float4*>(W + 4 * i), w1 = *reinterpret_cast<const float4*>(W + 128 + 4 * i),
+                         w2 = *reinterpret_cast<const float4*>(W + 256 + 4 * i);
+            float4 v;
+            v.x = gz[0] * w0.x + gz[1] * w1.x + gz[2] * w2.x; v.y = gz[0] * w0.y + gz[1] * w1.y + gz[2] * w2.y;
+            v.z = gz[0] * w0.z + gz[1] * w1.z + gz[2] * w2.z; v.w = gz[0] * w0.w + gz[1] * w1.w + gz[2] * w2.w;
+            *reinterpret_cast<float4*>(Hrow + 64 * half + 4 * i) = v;
+        }
+    }
+    __syncthreads();
+    bwd_mask_pass<NT>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A);      // d h_c1 (pre-activation)
+    __syncthreads();
+    // ---- d geo = W_c1[:, 16:144]^T d h_c1
+    obw_zero<NT>(A);
+    obw_mfma<NT, BG_C1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, false>(Hw, u.g_geo, nullptr, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    // ---- d h_s2 = W_s3[1:]^T d geo + d h0 (x) W_s3[0], masked
+    {
+        const float* w0 = s.P + P_SMALL + gf::HS_SIGROW + 32 * wave + 4 * half;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float g0 = s.sdt[t * 32 + j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 w = *reinterpret_cast<const float4*>(w0 + 8 * q);
+                A[t][4 * q + 0] = g0 * w.x; A[t][4 * q + 1] = g0 * w.y; A[t][4 * q + 2] = g0 * w.z; A[t][4 * q + 3] = g0 * w.w;
+            }
+        }
+    }
+    obw_mfma<NT, BG_S3, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, true>(Hw, u.g_hs2, u.m_hs2, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    // ---- d h_s1 = W_s2^T d h_s2, masked
+    obw_zero<NT>(A);
+    obw_mfma<NT, BG_S2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, true>(Hw, u.g_hs1, u.m_hs1, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    // ---- [d f3 (sigma branch) | d f2] = W_s1^T d h_s1   (64 real outputs, zero-padded to 128)
+    obw_zero<NT>(A);
+    obw_mfma<NT, BG_S1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, false>(Hw, nullptr, nullptr, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    // ---- 2-D lookup: d f2 out, input gradient in; ambient tail: d z_a = (d amb + 0.5 d x2) (1 - amb^2);  H row <- W_a3^T d z_a
+    float gf3[16];
+    if (tile_on) {
+        float gf2[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v3 = *reinterpret_cast<const float4*>(Hrow + 16 * half + 4 * q), v2 = *reinterpret_cast<const float4*>(Hrow + 32 + 16 * half + 4 * q);
+            gf3[4 * q] = v3.x; gf3[4 * q + 1] = v3.y; gf3[4 * q + 2] = v3.z; gf3[4 * q + 3] = v3.w;
+            gf2[4 * q] = v2.x; gf2[4 * q + 1] = v2.y; gf2[4 * q + 2] = v2.z; gf2[4 * q + 3] = v2.w;
+        }
+        if (valid) store16(u.g_f2 + pt * 32 + 16 * half, gf2);
+        const float x2[2] = {(ambv[0] + 1.0f) / 2.0f, (ambv[1] + 1.0f) / 2.0f};
+        float dx[2];
+        gf::encode8_grad2(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, gf2, dx);
+        dx[0] += __shfl_xor(dx[0], 32);
+        dx[1] += __shfl_xor(dx[1], 32);
+        const float gza[2] = {valid ? (gamb[0] + 0.5f * dx[0]) * (1.0f - ambv[0] * ambv[0]) : 0.0f,
+                              valid ? (gamb[1] + 0.5f * dx[1]) * (1.0f - ambv[1] * ambv[1]) : 0.0f};
+        if (valid && half == 0) { u.g_za[pt * 2] = gza[0]; u.g_za[pt * 2 + 1] = gza[1]; }
+        const float* W = s.P + P_SMALL + gf::HS_AMB3 + 64 * half;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float4 w0 = *reinterpret_cast<const float4*>(W + 4 * i), w1 = *reinterpret_cast<const float4*>(W + 128 + 4 * i);
+            const float4 v = {gza[0] * w0.x + gza[1] * w1.x, gza[0] * w0.y + gza[1] * w1.y, gza[0] * w0.z + gza[1] * w1.z, gza[0] * w0.w + gza[1] * w1.w};
+            *reinterpret_cast<float4*>(Hrow + 64 * half + 4 * i) = v;
+        }
+    }
+    __syncthreads();
+    bwd_mask_pass<NT>(Hw, u.g_ha2, u.m_ha2, gbase, Mv, wave, lane, A);      // d h_a2
+    __syncthreads();
+    // ---- d h_a1 = W_a2^T d h_a2, masked
+    obw_zero<NT>(A);
+    obw_mfma<NT, BG_A2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, true>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1   (32 real outputs, zero-padded)
+    obw_zero<NT>(A);
+    obw_mfma<NT, BG_A1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
+    __syncthreads();
+    bwd_store<NT, false>(Hw, nullptr, nullptr, gbase, Mv, wave, lane, A);
+    __syncthreads();
+    if (tile_on && valid) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(Hrow + 16 * half + 4 * q);
+            gf3[4 * q] += v.x; gf3[4 * q + 1] += v.y; gf3[4 * q + 2] += v.z; gf3[4 * q + 3] += v.w;
+        }
+        store16(u.g_f3 + pt * 32 + 16 * half, gf3);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a, const BwdArgs u) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
+    if (tid < 32) {
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
+    }
+    const uint32_t chunks = (u.M + kPass - 1) / kPass;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        __syncthreads();
+        const uint32_t gbase = chunk * kPass;
+        const uint32_t left = u.M - gbase;
+        const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
+        const uint32_t nt = (Mv + 31) / 32;
+        if (nt == 4) bwd_round<4>(a, u, s, Mv, gbase, wave, lane);
+        else if (nt == 3) bwd_round<3>(a, u, s, Mv, gbase, wave, lane);
+        else if (nt == 2) bwd_round<2>(a, u, s, Mv, gbase, wave, lane);
+        else bwd_round<1>(a, u, s, Mv, gbase, wave, lane);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- frame setup
 struct InitArgs {
     gf::MarchParams mp;
@@ -1547,7 +1779,8 @@ static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float
     if (saves) {
         if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1)
             return gf_set_error(GF_ERR_INVALID, "field_forward_train: null save buffer");
-        pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1};
+        pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1,
+                 saves->m_ha1, saves->m_ha2, saves->m_hs1, saves->m_hs2, saves->m_hc1};
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -1574,6 +1807,38 @@ GF_EXPORT int gf_field_forward_train(const gf_frame_t* f, const float* xyz, cons
                                      float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream) {
     if (!saves || !ambient) return gf_set_error(GF_ERR_INVALID, "field_forward_train: null pointer");
     return field_forward_impl(f, xyz, dirs, M, col_bias_or_null, sigma, rgb, ambient, saves, stream);
+}
+
+
+// The dX chain of the training backward (see k_field_backward).  `bwd_stream`: gf_field_bwd_stream_floats() floats, the six transposed
+// 128 x 128 weight blocks as A-operand streams; f supplies the ambient table / offsets / level scales, head_pack (its skinny rows) and
+// gridtype / interp.  All [M, *] outputs are fully written for the M points.
+GF_EXPORT uint32_t gf_field_bwd_stream_floats(void) { return 4u * BG_TOTAL * 256u; }
+
+GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream) {
+    if (M == 0) return GF_OK;
+    if (!f || !bwd_stream || !g) return gf_set_error(GF_ERR_INVALID, "field_backward: null pointer");
+    if (!f->amb_table || !f->amb_offsets || !f->pos_offsets || !f->head_pack) return gf_set_error(GF_ERR_INVALID, "field_backward: null pointer in the field description");
+    const void* need[] = {g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1, g->g_zc, g->g_h0, g->g_za,
+                          g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2};
+    for (const void* p : need) if (!p) return gf_set_error(GF_ERR_INVALID, "field_backward: null buffer");
+    if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "field_backward: gridtype/interp must be 0 or 1");
+    HeadArgs ha = {};
+    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
+        return gf_set_error(GF_ERR_INVALID, "field_backward: bad grid levels");
+    ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets; ha.head_pack = f->head_pack;
+    ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
+    BwdArgs ba = {bwd_stream, g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1,
+                  g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, M};
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_backward), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+            return gf_set_error(GF_ERR_HIP, "field_backward: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
+        attr_set = true;
+    }
+    const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
+    hipLaunchKernelGGL(k_field_backward, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
+    return gf_check_launch("field_backward");
 }
 
 GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {

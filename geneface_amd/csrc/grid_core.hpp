@@ -263,6 +263,54 @@ __device__ __forceinline__ void encode8(const float* __restrict__ table, const L
     }
 }
 
+// Input gradient of the 2-D lookup for the fused training backward: this lane's eight levels at point x, output gradients gf[16] =
+// [level][channel] -> the lane's share of d loss / d x (the caller adds the two lane halves).  Same derivative as kernel_grid's dy_dx
+// (gridencoder.cu:163-196) contracted with the output gradient as kernel_input_backward does (:343-368).
+__device__ __forceinline__ void encode8_grad2(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t gridtype,
+                                              uint32_t interp, const float (&x)[2], const float (&gf)[16], float (&dx)[2]) {
+    constexpr uint32_t P1 = 2654435761u;
+    dx[0] = dx[1] = 0.0f;
+    if (x[0] < 0.0f || x[0] > 1.0f || x[1] < 0.0f || x[1] > 1.0f) return;
+    const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const uint4 m0 = reinterpret_cast<const uint4*>(meta8)[2 * l];
+        const uint2 m1 = reinterpret_cast<const uint2*>(meta8)[4 * l + 2];
+        const float scale = __uint_as_float(m0.x);
+        const uint32_t s1 = m0.y, mask = m0.w, row_off = m1.x, use_hash = m1.y;
+        float p[2], der[2];
+        uint32_t g[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            float q = __builtin_fmaf(x[d], scale, 0.5f);
+            const float fl = floorf(q);
+            g[d] = (uint32_t)fl;
+            q -= fl;
+            if (interp == 1) { der[d] = 6 * q * (1.0f - q); q = q * q * (3.0f - 2.0f * q); }
+            else der[d] = 1.0f;
+            p[d] = q;
+        }
+        float2 v[4];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            const uint32_t px = g[0] + (c & 1u), py = g[1] + ((c >> 1) & 1u);
+            const uint32_t idx = (gridtype == 0 && use_hash) ? (px ^ (py * P1)) : (px + py * s1);
+            v[c] = rows[row_off + (idx & mask)];
+        }
+        // d/dx0: corners differ in bit 0; d/dx1: in bit 1
+        float w = scale * (1 - p[1]);
+        float d00 = w * (v[1].x - v[0].x) * der[0], d01 = w * (v[1].y - v[0].y) * der[0];
+        w = scale * p[1];
+        d00 += w * (v[3].x - v[2].x) * der[0]; d01 += w * (v[3].y - v[2].y) * der[0];
+        w = scale * (1 - p[0]);
+        float d10 = w * (v[2].x - v[0].x) * der[1], d11 = w * (v[2].y - v[0].y) * der[1];
+        w = scale * p[0];
+        d10 += w * (v[3].x - v[1].x) * der[1]; d11 += w * (v[3].y - v[1].y) * der[1];
+        dx[0] += gf[2 * l] * d00 + gf[2 * l + 1] * d01;
+        dx[1] += gf[2 * l] * d10 + gf[2 * l + 1] * d11;
+    }
+}
+
 // HOST: can the fused kernels' specialised lookup reproduce get_grid_index for these tables?  offsets is a HOST array [L+1].
 inline bool grid_levels_fusable(const int* offsets, uint32_t L, uint32_t D, float S, uint32_t H) {
     GridLevels lv;

@@ -26,7 +26,38 @@ _vp = C.c_void_p
 
 class GfFieldSaves(C.Structure):
     """ctypes mirror of gf_field_saves_t (include/geneface_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1")]
+    _fields_ = [(n, _vp) for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1")]
+
+
+class GfFieldGrads(C.Structure):
+    """ctypes mirror of gf_field_grads_t."""
+    _fields_ = [(n, _vp) for n in ("g_sigma", "g_rgb", "g_amb", "sigma", "rgb", "amb", "m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1", "g_zc", "g_h0", "g_za",
+                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2")]
+
+
+def _bwd_stream_index(shapes):
+    """Index map of gf_field_backward's A-operand stream into cat([0], W_a1, W_a2, W_a3, W_s1, W_s2, W_s3, W_c1, W_c2) (1-based, 0 = zero
+    padding): six transposed 128 x 128 blocks, element [wave][layer][group][lane][i] = Wt[32 wave + (lane & 31)][8 group + 4 (lane >> 5) + i]
+    with Wt[n][o] = W[o0 + o][n0 + n] for n < the block's real width."""
+    names = ["a1", "a2", "a3", "s1", "s2", "s3", "c1", "c2"]
+    base, off = {}, 1
+    for n, shp in zip(names, shapes):
+        base[n] = (off, shp)
+        off += shp[0] * shp[1]
+    #          weight, first fwd-output row o0, first fwd-input column n0, real number of fwd-input columns
+    layers = [("c1", 0, 16, 128), ("s3", 1, 0, 128), ("s2", 0, 0, 128), ("s1", 0, 0, 64), ("a2", 0, 0, 128), ("a1", 0, 0, 32)]
+    w = np.arange(4).reshape(4, 1, 1, 1, 1)
+    u = np.arange(16).reshape(1, 1, 16, 1, 1)
+    l = np.arange(64).reshape(1, 1, 1, 64, 1)
+    i = np.arange(4).reshape(1, 1, 1, 1, 4)
+    n = 32 * w + (l & 31)                       # bwd output = forward input feature
+    o = 8 * u + 4 * (l >> 5) + i                # bwd reduction index = forward output feature
+    idx = np.zeros((4, 6, 16, 64, 4), dtype=np.int64)
+    for k, (name, o0, n0, width) in enumerate(layers):
+        b0, (rows, cols) = base[name]
+        src = b0 + (o0 + o) * cols + (n0 + n)
+        idx[:, k] = np.where(np.broadcast_to(n < width, src.shape), src, 0)[:, 0]
+    return torch.from_numpy(idx.reshape(-1))
 
 
 def _tall_tn(g, x):
@@ -80,6 +111,8 @@ class _HeadField(torch.autograd.Function):
         sigma, rgb, amb = torch.empty(M, **f32), torch.empty(M, 3, **f32), torch.empty(M, 2, **f32)
         sv = {n: torch.empty(M, w, **f32) for n, w in (("f3", 32), ("ha1", 128), ("ha2", 128), ("f2", 32), ("hs1", 128), ("hs2", 128),
                                                       ("geo", 128), ("hc1", 128))}
+        chunks = (M + 127) // 128
+        masks = {n: torch.empty(chunks * 1024, dtype=torch.int16, device=dev) for n in ("m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1")}
         if M > 0:
             amb_bias = torch.mv(st.W_cond, cond_feat.detach().reshape(-1).float())
             col_bias = torch.mv(st.W_ind, ind_code.detach().reshape(-1).float()) if (st.W_ind is not None and ind_code is not None) else None
@@ -92,64 +125,73 @@ class _HeadField(torch.autograd.Function):
             f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
             f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
             f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
-            saves = GfFieldSaves(**{n: t.data_ptr() for n, t in sv.items()})
+            saves = GfFieldSaves(**{n: t.data_ptr() for n, t in {**sv, **masks}.items()})
             check(lib().gf_field_forward_train(C.byref(f), ptr(x, torch.float32), ptr(d, torch.float32), M, ptr(col_bias, torch.float32, allow_none=True),
                                                ptr(sigma), ptr(rgb), ptr(amb), C.byref(saves), current_stream(dev)))
         ctx.model = model
         ctx.has_code = ind_code is not None
         ctx.save_for_backward(x, d, cond_feat, ind_code if ind_code is not None else torch.zeros(0, device=dev), sigma, rgb, amb,
-                              wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, *[sv[n] for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1")])
+                              wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, *[sv[n] for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1")],
+                              *[masks[n] for n in ("m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1")])
         return sigma, rgb, amb
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_sigma, g_rgb, g_amb):
-        (x, d, cond_feat, ind_code, sigma, rgb, amb, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, f3, ha1, ha2, f2, hs1, hs2, geo, hc1) = ctx.saved_tensors
+        (x, d, cond_feat, ind_code, sigma, rgb, amb, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, f3, ha1, ha2, f2, hs1, hs2, geo, hc1,
+         m_hc1, m_hs2, m_hs1, m_ha2, m_ha1) = ctx.saved_tensors
+        from . import fused
         model = ctx.model
-        M = x.shape[0]
-        tb = torch.ops.aten.threshold_backward
-        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=x.device)
+        M, dev = x.shape[0], x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda *shape: torch.zeros(*shape, **f32)
         g_sigma = g_sigma.float().contiguous() if g_sigma is not None else z(M)
         g_rgb = g_rgb.float().contiguous() if g_rgb is not None else z(M, 3)
         g_amb = g_amb.float().contiguous() if g_amb is not None else z(M, 2)
         cond = cond_feat.reshape(-1).float()
-        # ---- colour net: rgb = sigmoid(W_c2 relu(W_c1 [sh | geo | code]))
-        g_zc = g_rgb * rgb * (1 - rgb)                                            # [M,3]
-        g_wc2 = _tall_tn(g_zc, hc1)
-        g_hc1 = tb(g_zc @ wc2, hc1, 0)                                            # [M,128]
+        # ---- the dX chain: one launch (transposed weight blocks re-gathered on the device from the current weights)
+        st = fused.get_state(model)
+        if getattr(st, "_bwd_idx", None) is None:
+            st._bwd_idx = _bwd_stream_index([tuple(w.shape) for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)]).to(dev)
+        flat = torch.cat([z(1)] + [w.detach().reshape(-1).float() for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)])
+        stream = flat[st._bwd_idx]
+        out = {n: torch.empty(M, w, **f32) for n, w in (("g_zc", 3), ("g_za", 2), ("g_hc1", 128), ("g_geo", 128), ("g_hs2", 128), ("g_hs1", 128),
+                                                        ("g_ha2", 128), ("g_ha1", 128), ("g_f3", 32), ("g_f2", 32))}
+        out["g_h0"] = torch.empty(M, **f32)
+        if M > 0:
+            f = fused.GfFrame()
+            pe, ae = model.position_embedder, model.ambient_embedder
+            f.bound = float(model.bound)
+            f.pos_offsets = ptr(pe.offsets, torch.int32)
+            f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+            f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
+            f.head_pack = ptr(st.head_pack)
+            g = GfFieldGrads(g_sigma=g_sigma.data_ptr(), g_rgb=g_rgb.data_ptr(), g_amb=g_amb.data_ptr(), sigma=sigma.data_ptr(), rgb=rgb.data_ptr(),
+                             amb=amb.data_ptr(), m_hc1=m_hc1.data_ptr(), m_hs2=m_hs2.data_ptr(), m_hs1=m_hs1.data_ptr(), m_ha2=m_ha2.data_ptr(),
+                             m_ha1=m_ha1.data_ptr(), **{n: t.data_ptr() for n, t in out.items()})
+            check(lib().gf_field_backward(C.byref(f), ptr(stream, torch.float32), M, C.byref(g), current_stream(dev)))
+        g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
+        g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
+        # ---- weight gradients: tall products of the pre-activation gradients with the saved activations
         sh = model.direction_embedder(d)                                          # [M,16] (no gradient: directions are data)
-        s_hc1 = g_hc1.sum(0)
+        s_hc1, s_ha1 = g_hc1.sum(0), g_ha1.sum(0)
+        g_wc2 = _tall_tn(g_zc, hc1)
         parts = [_tall_tn(g_hc1, sh), _tall_tn(g_hc1, geo)]
         g_code = None
         if ctx.has_code:
             parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
             g_code = (s_hc1 @ wc1[:, 144:]).view_as(ind_code)
         g_wc1 = torch.cat(parts, dim=1)
-        g_geo = g_hc1 @ wc1[:, 16:144]                                            # [M,128]
-        # ---- sigma net: [log sigma | geo] = W_s3 relu(W_s2 relu(W_s1 [f3 | f2])), sigma = trunc_exp(.)
-        g_h0 = g_sigma * sigma.clamp(min=float(np.exp(-15.0)), max=float(np.exp(15.0)))   # trunc_exp backward (utils.py:44-49)
         g_ws3 = torch.cat([_tall_tn(g_h0.unsqueeze(1), hs2), _tall_tn(g_geo, hs2)], dim=0)
-        g_hs2 = torch.addmm(torch.outer(g_h0, ws3[0]), g_geo, ws3[1:])
-        g_hs2 = tb(g_hs2, hs2, 0)
         g_ws2 = _tall_tn(g_hs2, hs1)
-        g_hs1 = tb(g_hs2 @ ws2, hs1, 0)
         g_ws1 = torch.cat([_tall_tn(g_hs1, f3), _tall_tn(g_hs1, f2)], dim=1)
-        g_f3 = g_hs1 @ ws1[:, :32]
-        g_f2 = g_hs1 @ ws1[:, 32:]
-        # ---- 2-D grid at (ambient + 1) / 2: table gradient and d/d ambient
-        g_amb_tab, g_x2 = _grid_backward(model.ambient_embedder, ((amb + 1) / 2).contiguous(), g_f2.contiguous(), True)
-        # ---- ambient net: ambient = tanh(W_a3 relu(W_a2 relu(W_a1 [f3 | cond])))
-        g_za = (g_amb + 0.5 * g_x2) * (1 - amb * amb)                             # [M,2]
         g_wa3 = _tall_tn(g_za, ha2)
-        g_ha2 = tb(g_za @ wa3, ha2, 0)
         g_wa2 = _tall_tn(g_ha2, ha1)
-        g_ha1 = tb(g_ha2 @ wa2, ha1, 0)
-        s_ha1 = g_ha1.sum(0)
         g_wa1 = torch.cat([_tall_tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         g_cond = (s_ha1 @ wa1[:, 32:]).view_as(cond_feat)
-        g_f3 = g_f3.addmm_(g_ha1, wa1[:, :32])
-        # ---- 3-D grid table
-        g_pos_tab, _ = _grid_backward(model.position_embedder, ((x + model.bound) / (2 * model.bound)).contiguous(), g_f3, False)
+        # ---- grid tables
+        g_amb_tab, _ = _grid_backward(model.ambient_embedder, ((amb + 1) / 2).contiguous(), out["g_f2"], False)
+        g_pos_tab, _ = _grid_backward(model.position_embedder, ((x + model.bound) / (2 * model.bound)).contiguous(), out["g_f3"], False)
         return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
 
 

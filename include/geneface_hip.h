@@ -248,9 +248,28 @@ typedef struct gf_field_saves {
     float* hs2;   /* [M,128] sigma_net layer 1 output after ReLU */
     float* geo;   /* [M,128] geometry feature (sigma_net output rows 1..128, no activation) */
     float* hc1;   /* [M,128] color_net layer 0 output after ReLU */
+    /* optional (all five or none): ReLU masks of ha1, ha2, hs1, hs2, hc1 for gf_field_backward, 2 bytes per lane in the kernels'
+     * accumulator layout: uint16 [ceil(M/128)][4 tiles][4 waves][64 lanes], bit r set when the lane's r-th value of that tile is > 0 */
+    uint16_t* m_ha1; uint16_t* m_ha2; uint16_t* m_hs1; uint16_t* m_hs2; uint16_t* m_hc1;
 } gf_field_saves_t;
 int gf_field_forward_train(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
                            float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream);
+/* The input-gradient (dX) chain of the same field in one launch: from the gradients of the three outputs back through every layer, the
+ * ReLU derivatives taken from the forward's mask bits, the 2-D lookup's input gradient re-gathered.  It writes the pre-activation gradient
+ * of every layer (what the weight gradients are tall products of, with the saved activations) and the gradients of both grid feature sets
+ * (what gf_grid_encode_backward scatters into the tables).  bwd_stream: gf_field_bwd_stream_floats() floats = the transposed blocks
+ * W_color0[:, 16:144]^T, W_sigma2[1:]^T, W_sigma1^T, W_sigma0^T (64 rows, zero-padded to 128), W_ambient1^T, W_ambient0[:, :32]^T (32 rows,
+ * padded) as A-operand streams [wave 4][layer 6][group 16][lane 64][4]: element = Wt[32 wave + (lane & 31)][8 group + 4 (lane >> 5) + i]. */
+typedef struct gf_field_grads {
+    const float* g_sigma; const float* g_rgb; const float* g_amb;   /* in: [M], [M,3], [M,2] */
+    const float* sigma; const float* rgb; const float* amb;         /* in: the forward's outputs */
+    const uint16_t* m_hc1; const uint16_t* m_hs2; const uint16_t* m_hs1; const uint16_t* m_ha2; const uint16_t* m_ha1;   /* in: forward masks */
+    float* g_zc; float* g_h0; float* g_za;                          /* out: [M,3] colour pre-sigmoid, [M] log-density, [M,2] ambient pre-tanh */
+    float* g_hc1; float* g_geo; float* g_hs2; float* g_hs1; float* g_ha2; float* g_ha1;   /* out: [M,128] each, pre-activation gradients */
+    float* g_f3; float* g_f2;                                       /* out: [M,32] each */
+} gf_field_grads_t;
+uint32_t gf_field_bwd_stream_floats(void);
+int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
 uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
 int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
                    uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);
