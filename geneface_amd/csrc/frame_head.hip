@@ -1304,14 +1304,15 @@ struct BwdArgs {
     const uint16_t *m_hc1, *m_hs2, *m_hs1, *m_ha2, *m_ha1; // forward ReLU masks
     float *g_zc, *g_h0, *g_za;                             // [M,3], [M], [M,2]   pre-activation gradients of the three skinny layers
     float *g_hc1, *g_geo, *g_hs2, *g_hs1, *g_ha2, *g_ha1;  // [M,128] each
-    float *g_f3, *g_f2;                                    // [M,32] each
+    float *g_f3, *g_f2;                                    // [16 levels][M][2] each: the layout the table scatter kernel reads
+    float *s_hc1, *s_ha1;                                  // [128] each, ZEROED by the caller: column sums of g_hc1 / g_ha1 over the points
     uint32_t M;
 };
 
 // accumulators -> LDS (and row gbase + sample of G), optionally through the ReLU mask of the layer whose pre-activation gradient this is
 template <int NT, bool MASK>
 __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
-                                          int lane, const floatx16 (&acc)[4]) {
+                                          int lane, const floatx16 (&acc)[4], float* colsum = nullptr /* this lane's 16 running column sums */) {
     const int half = lane >> 5, j = lane & 31;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -1328,6 +1329,7 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
             }
             *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
             if (row && ok) *reinterpret_cast<float4*>(row + 8 * q) = v;
+            if (colsum && ok) { colsum[4 * q] += v.x; colsum[4 * q + 1] += v.y; colsum[4 * q + 2] += v.z; colsum[4 * q + 3] += v.w; }
         }
     }
 }
@@ -1336,7 +1338,7 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
 // mask it, write it to H and to G
 template <int NT>
 __device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
-                                              int lane, floatx16 (&acc)[4]) {
+                                              int lane, floatx16 (&acc)[4], float* colsum = nullptr) {
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -1344,11 +1346,12 @@ __device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, 
             const float4 v = *reinterpret_cast<const float4*>(Hw + t * 32 * kHS + 8 * q);
             acc[t][4 * q + 0] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
         }
-    bwd_store<NT, true>(Hw, G, mask, gbase, Mv, wave, lane, acc);
+    bwd_store<NT, true>(Hw, G, mask, gbase, Mv, wave, lane, acc, colsum);
 }
 
 template <int NT>
-__device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int wave, int lane) {
+__device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int wave, int lane,
+                                          float (&cs_hc1)[16], float (&cs_ha1)[16]) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
     const bool tile_on = wave < NT;
@@ -1392,7 +1395,7 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
     }
     __syncthreads();
-    bwd_mask_pass<NT>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A);      // d h_c1 (pre-activation)
+    bwd_mask_pass<NT>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A, cs_hc1);      // d h_c1 (pre-activation)
     __syncthreads();
     // ---- d geo = W_c1[:, 16:144]^T d h_c1
     obw_zero<NT>(A);
@@ -1439,7 +1442,10 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
             gf3[4 * q] = v3.x; gf3[4 * q + 1] = v3.y; gf3[4 * q + 2] = v3.z; gf3[4 * q + 3] = v3.w;
             gf2[4 * q] = v2.x; gf2[4 * q + 1] = v2.y; gf2[4 * q + 2] = v2.z; gf2[4 * q + 3] = v2.w;
         }
-        if (valid) store16(u.g_f2 + pt * 32 + 16 * half, gf2);
+        if (valid) {   // [level][point][channel]: the layout gf_grid_encode_backward indexes (gridencoder.cu:275), no transpose on the host
+#pragma unroll
+            for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f2 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf2[2 * l], gf2[2 * l + 1]};
+        }
         const float x2[2] = {(ambv[0] + 1.0f) / 2.0f, (ambv[1] + 1.0f) / 2.0f};
         float dx[2];
         gf::encode8_grad2(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, gf2, dx);
@@ -1463,7 +1469,7 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     obw_zero<NT>(A);
     obw_mfma<NT, BG_A2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A);
+    bwd_store<NT, true>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A, cs_ha1);
     __syncthreads();
     // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1   (32 real outputs, zero-padded)
     obw_zero<NT>(A);
@@ -1477,7 +1483,8 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
             const float4 v = *reinterpret_cast<const float4*>(Hrow + 16 * half + 4 * q);
             gf3[4 * q] += v.x; gf3[4 * q + 1] += v.y; gf3[4 * q + 2] += v.z; gf3[4 * q + 3] += v.w;
         }
-        store16(u.g_f3 + pt * 32 + 16 * half, gf3);
+#pragma unroll
+        for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf3[2 * l], gf3[2 * l + 1]};
     }
     __syncthreads();
 }
@@ -1495,16 +1502,32 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
                : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
     }
     const uint32_t chunks = (u.M + kPass - 1) / kPass;
+    float cs_hc1[16], cs_ha1[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) cs_hc1[r] = cs_ha1[r] = 0.0f;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         __syncthreads();
         const uint32_t gbase = chunk * kPass;
         const uint32_t left = u.M - gbase;
         const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
         const uint32_t nt = (Mv + 31) / 32;
-        if (nt == 4) bwd_round<4>(a, u, s, Mv, gbase, wave, lane);
-        else if (nt == 3) bwd_round<3>(a, u, s, Mv, gbase, wave, lane);
-        else if (nt == 2) bwd_round<2>(a, u, s, Mv, gbase, wave, lane);
-        else bwd_round<1>(a, u, s, Mv, gbase, wave, lane);
+        if (nt == 4) bwd_round<4>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else if (nt == 3) bwd_round<3>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else if (nt == 2) bwd_round<2>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else bwd_round<1>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+    }
+    // column sums (-> gradients of the identity code and of cond_feat): this lane's 16 features over its sample column, all rounds; the 32
+    // lanes of a half hold the same features -> one butterfly, then one atomic per feature and workgroup
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float vc = cs_hc1[r], va = cs_ha1[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { vc += __shfl_xor(vc, o); va += __shfl_xor(va, o); }
+        if ((lane & 31) == 0) {
+            const int feat = 32 * wave + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            atomicAdd(&u.s_hc1[feat], vc);
+            atomicAdd(&u.s_ha1[feat], va);
+        }
     }
 }
 
@@ -1820,7 +1843,7 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     if (!f || !bwd_stream || !g) return gf_set_error(GF_ERR_INVALID, "field_backward: null pointer");
     if (!f->amb_table || !f->amb_offsets || !f->pos_offsets || !f->head_pack) return gf_set_error(GF_ERR_INVALID, "field_backward: null pointer in the field description");
     const void* need[] = {g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1, g->g_zc, g->g_h0, g->g_za,
-                          g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2};
+                          g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1};
     for (const void* p : need) if (!p) return gf_set_error(GF_ERR_INVALID, "field_backward: null buffer");
     if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "field_backward: gridtype/interp must be 0 or 1");
     HeadArgs ha = {};
@@ -1829,7 +1852,7 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets; ha.head_pack = f->head_pack;
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     BwdArgs ba = {bwd_stream, g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1,
-                  g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, M};
+                  g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1, M};
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_backward), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)

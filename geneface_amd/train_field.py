@@ -5,12 +5,13 @@ cats of per-point copies of the condition vector and the identity code, ReLUs, t
 GEMMs are 8 ms and the glue between them 5.6 ms of an 18 ms step (profiles/round2/r2t_train_kernel_stats.csv).
 
 Forward: one launch of the renderer's own field core over the point list (gf_field_forward_train, csrc/frame_head.hip), which also leaves
-every layer's activations as [M, width] matrices.  Backward: the chain rule written out once, by hand, over those matrices:
-  * per-point constants (condition vector, identity code) enter as bias vectors, never as [M, 64] / [M, 4] copies; concatenated inputs
-    become sums of products with column blocks of the weight, so no `cat` is ever materialised;
-  * ReLU masks come from the saved post-activation values (aten.threshold_backward, one fused pass per layer);
-  * weight gradients use the split reduction of cond_encoder._linear_tall (a [128 x 128] result over a 10^6-long reduction);
-  * the two grid tables and the 2-D lookup's input gradient go through the library's own backward kernels (gf_grid_encode_backward).
+every layer's activations as [M, width] matrices and the ReLU masks as bits.  Backward:
+  * the input-gradient chain through all layers is ONE launch as well (gf_field_backward: transposed weight blocks through the same MFMA
+    core, ReLU derivatives from the mask bits, the 2-D lookup's input gradient re-gathered); it writes every layer's pre-activation
+    gradient, both grid feature gradients (level-major, as the scatter kernel reads them) and the column sums behind d cond_feat / d code;
+  * weight gradients are tall products of those with the saved activations (the split reduction of cond_encoder._linear_tall); per-point
+    constants (condition vector, identity code) enter as outer products, never as [M, 64] / [M, 4] copies, and no `cat` is materialised;
+  * the two grid tables go through the library's own scatter kernels (gf_grid_encode_backward).
 Gradients flow to: both grid tables, the eight MLP weights, cond_feat, individual_code.  Positions and directions get none (the
 reference's marcher outputs are not differentiable either: raymarching.py:262-265).
 """
@@ -32,7 +33,7 @@ class GfFieldSaves(C.Structure):
 class GfFieldGrads(C.Structure):
     """ctypes mirror of gf_field_grads_t."""
     _fields_ = [(n, _vp) for n in ("g_sigma", "g_rgb", "g_amb", "sigma", "rgb", "amb", "m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1", "g_zc", "g_h0", "g_za",
-                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2")]
+                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2", "s_hc1", "s_ha1")]
 
 
 def _bwd_stream_index(shapes):
@@ -72,9 +73,9 @@ def _tall_tn(g, x):
     return gw
 
 
-def _grid_backward(enc, x01, grad, want_input_grad):
+def _grid_backward(enc, x01, grad, want_input_grad, level_major=False):
     """Table gradient (and d/d x01 through a freshly evaluated dy_dx) of GridEncoder `enc` at inputs x01 [M,D] for an output gradient
-    `grad` [M, L*C]: the library's backward kernels, without re-entering autograd."""
+    `grad` [M, L*C] (or already [L, M, C] with level_major): the library's backward kernels, without re-entering autograd."""
     L_ = lib()
     dev = x01.device
     B, D = x01.shape
@@ -88,7 +89,7 @@ def _grid_backward(enc, x01, grad, want_input_grad):
                                             B, D, Cc, L, S, int(enc.base_resolution), ptr(dy_dx), enc.gridtype_id, int(bool(enc.align_corners)),
                                             enc.interp_id, current_stream(dev)))
         gin = torch.zeros_like(x01)
-    g_lbc = grad.view(B, L, Cc).permute(1, 0, 2).contiguous()
+    g_lbc = grad if level_major else grad.view(B, L, Cc).permute(1, 0, 2).contiguous()
     g_tab = torch.zeros_like(enc.embeddings)
     check(L_.gf_grid_encode_backward(ptr(g_lbc, torch.float32), ptr(x01, torch.float32), ptr(enc.embeddings, torch.float32), ptr(enc.offsets, torch.int32),
                                      ptr(g_tab, torch.float32), B, D, Cc, L, S, int(enc.base_resolution), ptr(dy_dx, torch.float32, allow_none=True),
@@ -158,6 +159,7 @@ class _HeadField(torch.autograd.Function):
         out = {n: torch.empty(M, w, **f32) for n, w in (("g_zc", 3), ("g_za", 2), ("g_hc1", 128), ("g_geo", 128), ("g_hs2", 128), ("g_hs1", 128),
                                                         ("g_ha2", 128), ("g_ha1", 128), ("g_f3", 32), ("g_f2", 32))}
         out["g_h0"] = torch.empty(M, **f32)
+        out["s_hc1"], out["s_ha1"] = z(128), z(128)
         if M > 0:
             f = fused.GfFrame()
             pe, ae = model.position_embedder, model.ambient_embedder
@@ -174,7 +176,7 @@ class _HeadField(torch.autograd.Function):
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
         # ---- weight gradients: tall products of the pre-activation gradients with the saved activations
         sh = model.direction_embedder(d)                                          # [M,16] (no gradient: directions are data)
-        s_hc1, s_ha1 = g_hc1.sum(0), g_ha1.sum(0)
+        s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
         g_wc2 = _tall_tn(g_zc, hc1)
         parts = [_tall_tn(g_hc1, sh), _tall_tn(g_hc1, geo)]
         g_code = None
@@ -190,8 +192,8 @@ class _HeadField(torch.autograd.Function):
         g_wa1 = torch.cat([_tall_tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         g_cond = (s_ha1 @ wa1[:, 32:]).view_as(cond_feat)
         # ---- grid tables
-        g_amb_tab, _ = _grid_backward(model.ambient_embedder, ((amb + 1) / 2).contiguous(), out["g_f2"], False)
-        g_pos_tab, _ = _grid_backward(model.position_embedder, ((x + model.bound) / (2 * model.bound)).contiguous(), out["g_f3"], False)
+        g_amb_tab, _ = _grid_backward(model.ambient_embedder, (amb + 1) / 2, out["g_f2"], False, level_major=True)
+        g_pos_tab, _ = _grid_backward(model.position_embedder, (x + model.bound) / (2 * model.bound), out["g_f3"], False, level_major=True)
         return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
 
 

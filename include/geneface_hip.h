@@ -266,7 +266,8 @@ typedef struct gf_field_grads {
     const uint16_t* m_hc1; const uint16_t* m_hs2; const uint16_t* m_hs1; const uint16_t* m_ha2; const uint16_t* m_ha1;   /* in: forward masks */
     float* g_zc; float* g_h0; float* g_za;                          /* out: [M,3] colour pre-sigmoid, [M] log-density, [M,2] ambient pre-tanh */
     float* g_hc1; float* g_geo; float* g_hs2; float* g_hs1; float* g_ha2; float* g_ha1;   /* out: [M,128] each, pre-activation gradients */
-    float* g_f3; float* g_f2;                                       /* out: [M,32] each */
+    float* g_f3; float* g_f2;                                       /* out: [16 levels][M][2] each (the [L,B,C] layout gf_grid_encode_backward reads) */
+    float* s_hc1; float* s_ha1;                                     /* out, ZEROED by the caller: [128] column sums of g_hc1 / g_ha1 over the points */
 } gf_field_grads_t;
 uint32_t gf_field_bwd_stream_floats(void);
 int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
