@@ -161,20 +161,50 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
 // flush of EVERY entry 0.28 ms, so the ds_add_f32 stream itself is 1.3 ms (268 M adds = 0.4 per clock and CU); point order (ray order,
 // random, ray-interleaved) moves it by < 6 %: it is the LDS atomic rate, not same-address serialisation.
 // A level too large for kGbMaxParts partitions (log2_hashmap_size > 17 at C = 2) falls back to direct global atomics.
+// Round 2: the LDS accumulators are 64-bit FIXED POINT.  tools/lds_atomic_probe.hip: ds_add_f32 retires 0.38 adds per clock and CU on gfx950
+// (exactly the rate the float version of this kernel ran at), ds_add_u32 11.6 and ds_add_u64 6.7 -- the float atomic is ~20x slower than the
+// integer ones.  Every contribution w * g is scaled by 2^30 / max|g| of its level (k_grid_absmax, one pass over the gradient), rounded to an
+// int32 and added as int64: no overflow below 2^33 contributions per entry, a quantum of 1e-9 of the level's largest gradient (below the
+// fp32 running sum's own rounding), and -- integer adds commute -- a table partial that no longer depends on the order the points arrive in.
 constexpr uint32_t kGbThreads = 1024;
-constexpr uint32_t kGbLdsFloats = 32768;
+constexpr uint32_t kGbLdsEntries = 16384;   // int64 accumulators: 128 KiB, one workgroup per CU
 constexpr uint32_t kGbMaxParts = 8;
+constexpr float kGbFixedOne = 1073741824.0f;   // 2^30
+
+// per-level max |grad| (bit pattern of a non-negative float orders like the uint): lvl_max[L] zeroed by the caller
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_absmax(const float* __restrict__ grad, uint32_t B, uint32_t* __restrict__ lvl_max) {
+    const uint32_t level = blockIdx.y;
+    const float* g = grad + (size_t)level * B * C;
+    const size_t n = (size_t)B * C;
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = fabsf(g[i]);
+        m = (v == v) ? fmaxf(m, v) : INFINITY;                      // a NaN gradient counts as an overflow (below)
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(&lvl_max[level], __float_as_uint(m));
+}
 
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                               const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
                                                               gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
-                                                              uint32_t flush_budget, uint32_t min_slices) {
-    __shared__ float tab[kGbLdsFloats];
+                                                              uint32_t flush_budget, uint32_t min_slices, const uint32_t* __restrict__ lvl_max) {
+    __shared__ long long tab[kGbLdsEntries];
     const uint32_t level = blockIdx.y;
+    const float gmax = __uint_as_float(lvl_max[level]);
+    if (!(gmax > 0.0f)) return;                                    // an all-zero gradient level adds nothing
+    if (!(gmax < INFINITY)) {                                      // inf / NaN in the gradient (fp16 loss scaling overflowed): the float scatter would
+        if (blockIdx.x == 0 && threadIdx.x == 0)                   // have put a non-finite value into the table, which is what GradScaler looks for
+            unsafeAtomicAdd(grad_grid + (size_t)offsets[level] * C, __uint_as_float(0x7fc00000u));
+        return;
+    }
+    const float to_fixed = kGbFixedOne / gmax;
+    const double from_fixed = (double)gmax / (double)kGbFixedOne;
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-    constexpr uint32_t rows_per_part = kGbLdsFloats / C;
+    constexpr uint32_t rows_per_part = kGbLdsEntries / C;
     uint32_t nparts = (hashmap_size + rows_per_part - 1) / rows_per_part;
     const bool direct = nparts > kGbMaxParts;                      // workgroup-uniform
     if (direct) nparts = 1;
@@ -188,7 +218,7 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     if (slice >= slices) return;
     const uint32_t row0 = direct ? 0u : part * rows_per_part;
     const uint32_t nrows = direct ? 0u : (hashmap_size - row0 < rows_per_part ? hashmap_size - row0 : rows_per_part);
-    for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) tab[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) tab[i] = 0;
     __syncthreads();
     const float scale = lv.scale[level];
     const uint32_t resolution = lv.resolution[level];
@@ -215,6 +245,9 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
         float g[C];
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) g[c] = grad[((size_t)level * B + b) * C + c];
+        float gs[C];                                               // in fixed-point units (|gs| <= 2^30)
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) gs[c] = g[c] * to_fixed;
         float pos[D];
         uint32_t pos_grid[D];
 #pragma unroll
@@ -255,15 +288,16 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
                 const uint32_t r = row - row0;                     // rows below row0 wrap to huge values
                 if (r < nrows) {
 #pragma unroll
-                    for (uint32_t c = 0; c < C; c++) atomicAdd(&tab[r * C + c], w * g[c]);
+                    for (uint32_t c = 0; c < C; c++)
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[r * C + c]), (unsigned long long)(long long)__float2int_rn(w * gs[c]));
                 }
             }
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) {
-        const float v = tab[i];
-        if (v != 0.0f) unsafeAtomicAdd(table + (size_t)row0 * C + i, v);
+        const long long q = tab[i];
+        if (q != 0) unsafeAtomicAdd(table + (size_t)row0 * C + i, (float)((double)q * from_fixed));
     }
 }
 
@@ -351,12 +385,24 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     // spend on flush atomics; min_slices keeps the fine levels' point lists short enough to balance the chip.
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
     if (B < (1u << 16)) wgs = 32;
+    // per-level scale of the fixed-point accumulators: a slot of a small device ring (calls on different streams take different slots)
+    static uint32_t* ring = nullptr;
+    static unsigned ring_pos = 0;
+    constexpr unsigned kSlots = 64;
+    if (!ring && hipMalloc(&ring, kSlots * gf::kMaxLevels * sizeof(uint32_t)) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMalloc failed");
+    uint32_t* lvl_max = ring + (size_t)(ring_pos++ % kSlots) * gf::kMaxLevels;
+    if (hipMemsetAsync(lvl_max, 0, gf::kMaxLevels * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
+    const dim3 mgrid(B >= (1u << 16) ? 64u : 8u, lv.L);
     const dim3 grid(wgs, lv.L), block(kGbThreads);
     switch (C) {
-        case 1: hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices); break;
-        case 2: hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices); break;
-        case 4: hipLaunchKernelGGL((k_grid_backward<D, 4>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices); break;
-        case 8: hipLaunchKernelGGL((k_grid_backward<D, 8>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices); break;
+        case 1: hipLaunchKernelGGL((k_grid_absmax<1>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+                hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
+        case 2: hipLaunchKernelGGL((k_grid_absmax<2>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+                hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
+        case 4: hipLaunchKernelGGL((k_grid_absmax<4>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+                hipLaunchKernelGGL((k_grid_backward<D, 4>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
+        case 8: hipLaunchKernelGGL((k_grid_absmax<8>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+                hipLaunchKernelGGL((k_grid_backward<D, 8>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
         default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
     }
     return gf_check_launch("grid_encode_backward");
