@@ -178,12 +178,107 @@ __global__ void __launch_bounds__(256) k_grid_absmax(const float* __restrict__ g
     const float* g = grad + (size_t)level * B * C;
     const size_t n = (size_t)B * C;
     float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float v = fabsf(g[i]);
-        m = (v == v) ? fmaxf(m, v) : INFINITY;                      // a NaN gradient counts as an overflow (below)
+    auto take = [&](float v) { v = fabsf(v); m = (v == v) ? fmaxf(m, v) : INFINITY; };   // a NaN gradient counts as an overflow (below)
+    const size_t head = ((16 - ((uintptr_t)g & 15)) & 15) / 4 < n ? ((16 - ((uintptr_t)g & 15)) & 15) / 4 : n;   // floats before 16-byte alignment
+    const size_t n4 = (n - head) / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        take(v.x); take(v.y); take(v.z); take(v.w);
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) take(g[threadIdx.x]);
+        const size_t tail0 = head + n4 * 4;
+        if (tail0 + threadIdx.x < n) take(g[tail0 + threadIdx.x]);
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(&lvl_max[level], __float_as_uint(m));
+}
+
+// The point loop of k_grid_backward, specialised on the row rule so that the unrolled corner code carries no workgroup-uniform branches:
+// MODE 1 = power-of-two hash, MODE 2 = dense strides (both through LevelMeta, non-aligned corners), MODE 0 = the generic rule (grid_row).
+// DIRECT = the level does not fit kGbMaxParts partitions: float atomics straight into the table.
+template <uint32_t D, uint32_t C, int MODE, bool DIRECT>
+__device__ __forceinline__ void gb_points(long long* tab, const float* __restrict__ grad, const float* __restrict__ inputs, float* __restrict__ table,
+                                          uint32_t level, uint32_t B, uint32_t b0, uint32_t b1, float scale, uint32_t resolution, uint32_t hashmap_size,
+                                          uint32_t gridtype, bool align_corners, uint32_t interp, const gf::LevelMeta& lm, uint32_t row0, uint32_t nrows,
+                                          float to_fixed) {
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kGbThreads) {
+        float x[D];
+        bool oob = false;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            x[d] = inputs[(size_t)b * D + d];
+            oob |= (x[d] < 0 || x[d] > 1);
+        }
+        if (oob) continue;
+        float g[C];
+        bool any = false;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            g[c] = grad[((size_t)level * B + b) * C + c];
+            any |= g[c] != 0.0f;
+        }
+        if (!any) continue;                                        // samples behind a ray's termination point carry exact zeros
+        float gs[C];                                               // in fixed-point units (|gs| <= 2^30)
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) gs[c] = DIRECT ? g[c] : g[c] * to_fixed;
+        float pos[D];
+        uint32_t pos_grid[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            pos[d] = __builtin_fmaf(x[d], scale, (MODE == 0 && align_corners) ? 0.0f : 0.5f);
+            const float fl = floorf(pos[d]);
+            pos_grid[d] = (uint32_t)fl;
+            pos[d] -= fl;
+            if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+        }
+        // per-axis terms of the row index, both sides of the cell (the corner loop only combines them)
+        uint32_t term[D][2];
+        if constexpr (MODE != 0) {
+            constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t m = MODE == 1 ? (d == 0 ? 1u : (d == 1 ? P1 : P2)) : (d == 0 ? 1u : (d == 1 ? lm.s1 : lm.s2));
+                term[d][0] = pos_grid[d] * m;
+                term[d][1] = term[d][0] + m;
+            }
+        }
+#pragma unroll
+        for (uint32_t corner = 0; corner < (1u << D); corner++) {
+            uint32_t row;
+            if constexpr (MODE == 1) {
+                row = term[0][corner & 1u];
+#pragma unroll
+                for (uint32_t d = 1; d < D; d++) row ^= term[d][(corner >> d) & 1u];
+                row &= lm.mask;
+            } else if constexpr (MODE == 2) {
+                row = term[0][corner & 1u];
+#pragma unroll
+                for (uint32_t d = 1; d < D; d++) row += term[d][(corner >> d) & 1u];
+                row &= lm.mask;
+            } else {
+                uint32_t pl[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) pl[d] = pos_grid[d] + ((corner >> d) & 1u);
+                row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
+            }
+            const uint32_t r = row - row0;                         // rows below row0 wrap to huge values
+            if (DIRECT || r < nrows) {
+                float w = 1.0f;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) w *= (corner & (1u << d)) ? pos[d] : 1 - pos[d];
+                if constexpr (DIRECT) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * gs[c]);
+                } else {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++)
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[r * C + c]), (unsigned long long)(long long)__float2int_rn(w * gs[c]));
+                }
+            }
+        }
+    }
 }
 
 template <uint32_t D, uint32_t C>
@@ -226,74 +321,20 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     // Row index without the generic rule's integer modulo (grid_row): dense levels never reach the table size, wrapped levels have a
     // power-of-two size (grid.py:118-134 caps them at 2^log2_hashmap_size) -- the same reduction the fused lookup uses (LevelMeta).
     gf::LevelMeta lm = {};
-    bool fast = false;                                             // workgroup-uniform
+    int mode = 0;                                                  // workgroup-uniform
     if constexpr (D <= 3) {
         lm = gf::make_level_meta<D>(scale, resolution, offsets, level, gridtype);
-        fast = !align_corners && (lm.mask == 0xFFFFFFFFu || (hashmap_size & (hashmap_size - 1u)) == 0u);
+        if (!align_corners && (lm.mask == 0xFFFFFFFFu || (hashmap_size & (hashmap_size - 1u)) == 0u)) mode = lm.use_hash ? 1 : 2;
     }
     const uint32_t per = (B + slices - 1) / slices;
     const uint32_t b0 = slice * per < B ? slice * per : B, b1 = b0 + per < B ? b0 + per : B;
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kGbThreads) {
-        float x[D];
-        bool oob = false;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            x[d] = inputs[(size_t)b * D + d];
-            oob |= (x[d] < 0 || x[d] > 1);
-        }
-        if (oob) continue;
-        float g[C];
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) g[c] = grad[((size_t)level * B + b) * C + c];
-        float gs[C];                                               // in fixed-point units (|gs| <= 2^30)
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) gs[c] = g[c] * to_fixed;
-        float pos[D];
-        uint32_t pos_grid[D];
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            pos[d] = __builtin_fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
-            const float fl = floorf(pos[d]);
-            pos_grid[d] = (uint32_t)fl;
-            pos[d] -= fl;
-            if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
-        }
-#pragma unroll
-        for (uint32_t corner = 0; corner < (1u << D); corner++) {
-            float w = 1.0f;
-            uint32_t pl[D];
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) {
-                if ((corner & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pos_grid[d]; }
-                else { w *= pos[d]; pl[d] = pos_grid[d] + 1; }
-            }
-            uint32_t row;
-            if (fast) {
-                constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
-                if (lm.use_hash) {
-                    row = pl[0] ^ (pl[D > 1 ? 1 : 0] * P1);
-                    if constexpr (D == 3) row ^= pl[2] * P2;
-                } else {
-                    row = pl[0] + pl[D > 1 ? 1 : 0] * lm.s1;
-                    if constexpr (D == 3) row += pl[2] * lm.s2;
-                }
-                row &= lm.mask;
-            } else {
-                row = gf::grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pl);
-            }
-            if (direct) {
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
-            } else {
-                const uint32_t r = row - row0;                     // rows below row0 wrap to huge values
-                if (r < nrows) {
-#pragma unroll
-                    for (uint32_t c = 0; c < C; c++)
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[r * C + c]), (unsigned long long)(long long)__float2int_rn(w * gs[c]));
-                }
-            }
-        }
-    }
+#define GF_GB_POINTS(MODE, DIRECT) gb_points<D, C, MODE, DIRECT>(tab, grad, inputs, table, level, B, b0, b1, scale, resolution, hashmap_size, gridtype, \
+                                                               align_corners, interp, lm, row0, nrows, to_fixed)
+    if (direct) GF_GB_POINTS(0, true);
+    else if (mode == 1) GF_GB_POINTS(1, false);
+    else if (mode == 2) GF_GB_POINTS(2, false);
+    else GF_GB_POINTS(0, false);
+#undef GF_GB_POINTS
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nrows * C; i += kGbThreads) {
         const long long q = tab[i];
@@ -392,7 +433,7 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     if (!ring && hipMalloc(&ring, kSlots * gf::kMaxLevels * sizeof(uint32_t)) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMalloc failed");
     uint32_t* lvl_max = ring + (size_t)(ring_pos++ % kSlots) * gf::kMaxLevels;
     if (hipMemsetAsync(lvl_max, 0, gf::kMaxLevels * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
-    const dim3 mgrid(B >= (1u << 16) ? 64u : 8u, lv.L);
+    const dim3 mgrid(B >= (1u << 16) ? 128u : 8u, lv.L);
     const dim3 grid(wgs, lv.L), block(kGbThreads);
     switch (C) {
         case 1: hipLaunchKernelGGL((k_grid_absmax<1>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
