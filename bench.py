@@ -247,6 +247,13 @@ def main():
             "roofline": roofline,
             "parity": parity,
         }
+        if roofline and not args.fast and roofline.get("samples_per_frame") and world == 1:
+            # The same algorithmic FLOPs priced against the WHOLE frame time of the timed region (several frames in flight: the uneven end of one
+            # launch -- 12 % of the kernel alone, DESIGN.md 4.2 -- is filled by the next frame's workgroups, but the frame also pays for the
+            # three small kernels).  A lower bound of what the head kernel sustains in the pipelined product configuration.
+            tf = roofline["samples_per_frame"] * FLOP_PER_HEAD_SAMPLE * (K / dt) / 1e12
+            roofline["pipelined"] = {"achieved": tf, "frac": tf / roofline["peak"], "unit": roofline["unit"],
+                                     "note": "algorithmic FLOPs per frame x measured fps; `achieved` / `frac` above are the kernel alone, one frame in flight"}
         if args.png_frames > 0 and world == 1:
             line["with_png"] = png_leg(pipe, Wm, min(args.png_frames, K))
         if not args.no_stress and world == 1 and impl == "fused":

@@ -107,7 +107,7 @@ struct HeadArgs {
     float cam_o[3]; uint32_t pose_mode;   // rays generated from a pose share one origin: it travels by value, no per-ray origin array
 #ifdef GF_TRACE
     uint32_t* trace;
-    unsigned long long* spans;   // [2 phases][512 workgroups][start tick, end tick, rounds, XCC id]
+    unsigned long long* spans;   // [2 phases][512 workgroups][start tick, end tick, rounds | samples << 32, XCC id, start realtime, end realtime (100 MHz), exit tick, exit realtime]; 'end' = end of the last round
 #endif
 #ifdef GF_DIAG
     float* diag;                 // [N][diag_stride][kDiagWords] per-sample record, or NULL
@@ -880,6 +880,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     const bool owner = tid < kPool;
 #ifdef GF_TRACE
     const unsigned long long span_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long span_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // ---- phase set-up (uniform) ----
@@ -938,6 +939,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     bool queue_open = true;         // uniform
 #ifdef GF_TRACE
     uint32_t tr_round = 0;
+    unsigned long long span_t1 = span_t0, span_r1 = span_r0;   // end of the last round
 #endif
 
 #ifndef GF_NO_SETPRIO
@@ -1142,6 +1144,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         if (a.trace && blockIdx.x < kTraceWGs && tr_round < kTraceRounds && tid < kTraceSlots)
             a.trace[((a.phase * kTraceWGs + blockIdx.x) * kTraceRounds + tr_round) * kTraceSlots + tid] = s.tr[tid];
         tr_round++;
+        span_t1 = __builtin_amdgcn_s_memtime(); span_r1 = __builtin_amdgcn_s_memrealtime();
 #endif
     }
 
@@ -1152,8 +1155,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     }
 #ifdef GF_TRACE
     if (tid == 0 && a.spans) {   // per-workgroup lifetime (s_memtime offsets differ between CUs: only differences are meaningful)
-        unsigned long long* sp = a.spans + ((size_t)a.phase * 512 + blockIdx.x) * 4;
-        sp[0] = span_t0; sp[1] = __builtin_amdgcn_s_memtime(); sp[2] = st_rounds; sp[3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID */);
+        unsigned long long* sp = a.spans + ((size_t)a.phase * 512 + blockIdx.x) * 8;
+        sp[0] = span_t0; sp[1] = span_t1; sp[2] = (unsigned long long)st_rounds | ((unsigned long long)st_samples << 32);
+        sp[3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID */); sp[4] = span_r0; sp[5] = span_r1;
+        sp[6] = __builtin_amdgcn_s_memtime(); sp[7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     if (tid == 0) {

@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(kTB) k_composite_train_backward(const float* _
     const float gws = grad_weights_sum[index], gas = grad_ambient_sum[index];
     const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
     const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2], ws_final = weights_sum[index];
-    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    float T = 1.0f, r = 0, g = 0, b = 0;
     for (uint32_t s = 0; s < num_steps; s++) {
 #pragma clang fp contract(off)
         const size_t p = (size_t)offset + s;
@@ -394,7 +394,6 @@ __global__ void __launch_bounds__(kTB) k_composite_train_backward(const float* _
         const float alpha = 1.0f - __expf(-sigmas[p] * dt);
         const float weight = alpha * T;
         r += weight * c0; g += weight * c1; b += weight * c2;
-        ws += weight;
         T *= 1.0f - alpha;
         grad_rgbs[p * 3] = gi0 * weight; grad_rgbs[p * 3 + 1] = gi1 * weight; grad_rgbs[p * 3 + 2] = gi2 * weight;
         grad_ambient[p] = gas;

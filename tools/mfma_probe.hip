@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_faithful(const float* __restrict__ W
     for (int t = 0; t < 4; t++) for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
     const char* Ws = reinterpret_cast<const char*>(W) + (size_t)wave * 78 * 1024;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: ticks / realtime = the true shader clock
     float4 q[3], b[4];
     for (int g = 0; g < 3; g++) q[g] = float4{seed, seed * 0.5f, seed * 0.25f, seed * 0.125f};
     for (int t = 0; t < 4; t++) b[t] = float4{seed, -seed, seed * 0.3f, seed * 0.7f};
@@ -117,6 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_faithful(const float* __restrict__ W
     if (blockIdx.x == 0 && tid == 0) {   // shader ticks this workgroup lived: ticks / wall time = what s_memtime counts
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         reinterpret_cast<unsigned long long*>(out + 512 * 256)[0] = t_end - t_start;
+        reinterpret_cast<unsigned long long*>(out + 512 * 256)[2] = __builtin_amdgcn_s_memrealtime() - r_start;
     }
 }
 
@@ -134,10 +136,12 @@ double run_faithful(int grid, const float* W, float* out, int iters, float seed,
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)grid * 4 * iters * 48 * 16 * 4096.0 * reps;
-    unsigned long long ticks = 0;
+    unsigned long long ticks = 0, real = 0;
     hipMemcpy(&ticks, out + 512 * 256, 8, hipMemcpyDeviceToHost);
-    printf("   [s_memtime: %llu ticks per workgroup lifetime, %.1f us per launch -> %.3f GHz; %.2f ticks per MFMA]\n", ticks, ms * 1e3 / reps,
-           (double)ticks / (ms * 1e-3 / reps) / 1e9, (double)ticks / ((double)iters * 48 * 16 * (grid > 256 ? 2 : 1)));
+    hipMemcpy(&real, reinterpret_cast<char*>(out + 512 * 256) + 16, 8, hipMemcpyDeviceToHost);
+    printf("   [s_memtime: %llu ticks per workgroup lifetime, %.1f us per launch -> %.3f GHz; %.2f ticks per MFMA; ticks / s_memrealtime -> %.3f GHz]\n", ticks,
+           ms * 1e3 / reps, (double)ticks / (ms * 1e-3 / reps) / 1e9, (double)ticks / ((double)iters * 48 * 16 * (grid > 256 ? 2 : 1)),
+           real ? (double)ticks / (double)real * 0.1 : 0.0);
     return flop / (ms * 1e-3) / 1e12;
 }
 

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frame", type=int, default=10)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--rounds", type=int, default=0, help="print every traced round of the first N workgroups (start, duration, gap to the previous round, samples, pool)")
+    ap.add_argument("--spans", default=None, help="save the per-workgroup [start tick, end tick, rounds | samples << 32, XCC, start / end realtime] array (.npy)")
     ap.add_argument("--fast", action="store_true", help="trace the f16 fast-tier kernel (render_precision='fast')")
     args = ap.parse_args()
     import numpy as np
@@ -70,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     L.gf_trace_set(C.c_void_p(buf.data_ptr()))
     buf.zero_()
-    spans = torch.zeros(2 * 512 * 4, dtype=torch.int64, device=dev)
+    spans = torch.zeros(2 * 512 * 8, dtype=torch.int64, device=dev)
     L.gf_trace_set_spans.argtypes = [C.c_void_p]
     L.gf_trace_set_spans(C.c_void_p(spans.data_ptr()))
     with torch.no_grad():
@@ -85,7 +87,12 @@ def main():
     t = buf.cpu().numpy().astype(np.int64).reshape(2, nwg, nrounds, nslots) & 0xFFFFFFFF
     print(f"frame {args.frame} {args.size}x{args.size}: phase ms = {ms[0]:.3f} {ms[1]:.3f}; stats = {json.dumps(fs)}")
     report = {"phase_ms": [ms[0], ms[1]], "stats": fs, "phases": []}
-    sp = spans.cpu().numpy().reshape(2, 512, 4)
+    sp = spans.cpu().numpy().reshape(2, 512, 8)
+    if args.spans:
+        np.save(args.spans, sp)
+    sp = sp.copy()
+    wg_samples = sp[:, :, 2] >> 32
+    sp[:, :, 2] &= 0xFFFFFFFF
     for ph in range(2):
         live = sp[ph][sp[ph][:, 1] != 0]
         if not len(live):
@@ -96,6 +103,33 @@ def main():
               f"(mean {life.mean():.0f}); max lifetime over {ms[ph]:.3f} ms -> shader clock >= {life.max() / (ms[ph] * 1e-3) / 1e9:.3f} GHz; "
               f"rounds min/mean/max {live[:, 2].min()}/{live[:, 2].mean():.1f}/{live[:, 2].max()}; perfectly balanced the phase would take "
               f"{100 * life.mean() / life.max():.1f}% of its time")
+        # the constant 100 MHz counter (s_memrealtime) next to the shader-clock counter: the true clock of every workgroup's lifetime, and
+        # when the workgroups really start and stop inside the launch
+        rt = (live[:, 5] - live[:, 4]).astype(np.float64)
+        clk = life[rt > 0] / rt[rt > 0] * 0.1
+        t0, t1 = live[:, 4].min(), live[:, 5].max()
+        print(f"         true shader clock over a workgroup's life (ticks / 100 MHz realtime): min {clk.min():.3f} p50 {np.median(clk):.3f} max {clk.max():.3f} GHz; "
+              f"first start -> last end {(t1 - t0) / 100:.1f} us of the {ms[ph] * 1e3:.1f} us between the HIP events; "
+              f"starts spread over {(live[:, 4].max() - t0) / 100:.1f} us, ends over {(t1 - live[:, 5].min()) / 100:.1f} us; "
+              f"workgroups leave the kernel {(live[:, 7].min() - t0) / 100:.1f} .. {(live[:, 7].max() - t0) / 100:.1f} us after the first start")
+        report.setdefault("spans", []).append({"phase": ph, "clock_ghz_p50": float(np.median(clk)), "first_start_to_last_end_us": float((t1 - t0) / 100),
+                                               "event_us": float(ms[ph] * 1e3), "start_spread_us": float((live[:, 4].max() - t0) / 100),
+                                               "end_spread_us": float((t1 - live[:, 5].min()) / 100)})
+    for w in range(args.rounds):
+        tp0 = t[0][w]
+        idx = np.nonzero(tp0[:, SLOT_END] != 0)[0]
+        if not len(idx):
+            continue
+        base0 = int(tp0[idx[0], 0])
+        print(f"workgroup {w}: round (start kticks, duration kticks, gap kticks, samples, pool, n, march kticks)")
+        prev_end = base0
+        for r in idx:
+            st0, en = int(tp0[r, 0]), int(tp0[r, SLOT_END])
+            print(f"   {r:2d} {((st0 - base0) & 0xFFFFFFFF) / 1e3:8.1f} {((en - st0) & 0xFFFFFFFF) / 1e3:7.1f} {((st0 - prev_end) & 0xFFFFFFFF) / 1e3:7.1f} "
+                  f"{int(tp0[r, SLOT_MV]):4d} {int(tp0[r, SLOT_NPOOL]):4d} {int(tp0[r, SLOT_N]):2d} {((int(tp0[r, 3]) - int(tp0[r, 2])) & 0xFFFFFFFF) / 1e3:7.1f}")
+            prev_end = en
+            if ((en - st0) & 0xFFFFFFFF) > 400000:   # a slow round: every stage
+                print("        stages (kticks): " + " ".join(f"{a}-{b}:{((int(tp0[r, b]) - int(tp0[r, a])) & 0xFFFFFFFF) / 1e3:.1f}" for (a, b) in NAMES if tp0[r, a] and tp0[r, b]))
     for ph in range(2):
         tp = t[ph]
         used = tp[:, :, SLOT_END] != 0
