@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     __shared__ long long tab[kGbLdsEntries];
     const uint32_t level = blockIdx.y;
     const float gmax = __uint_as_float(lvl_max[level]);
-    if (!(gmax > 0.0f)) return;                                    // an all-zero gradient level adds nothing
+    if (!(gmax > 1e-30f)) return;                                  // an all-zero gradient level adds nothing (nor does one below 1e-30: 2^30 / gmax must stay finite)
     if (!(gmax < INFINITY)) {                                      // inf / NaN in the gradient (fp16 loss scaling overflowed): the float scatter would
         if (blockIdx.x == 0 && threadIdx.x == 0)                   // have put a non-finite value into the table, which is what GradScaler looks for
             unsafeAtomicAdd(grad_grid + (size_t)offsets[level] * C, __uint_as_float(0x7fc00000u));

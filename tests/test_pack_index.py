@@ -1,0 +1,88 @@
+"""Host logic of the weight re-packing: the index maps that turn a weight update into one device-side gather (fused._pack_index,
+train_field._bwd_stream_index) against the host packers / the documented stream layout.  CPU only: the packers are host code of the library."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from geneface_amd import fused, train_field
+from geneface_amd.lib import check, lib
+
+HEAD_SHAPES = [(128, 96), (128, 128), (2, 128), (128, 64), (128, 128), (129, 128), (128, 148), (3, 128)]   # a1 a2 a3 s1 s2 s3 c1 c2 (May)
+TORSO_SHAPES = [(64, 106), (64, 64), (2, 64), (32, 138), (32, 32), (4, 32)]
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _random(shapes, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal(s).astype(np.float32) for s in shapes]
+
+
+def _gather(idx, arrays):
+    flat = np.concatenate([np.zeros(1, np.float32)] + [a.reshape(-1) for a in arrays])
+    return flat[idx.numpy()]
+
+
+def test_head_pack_index_reproduces_the_host_packer():
+    L = lib()
+    n = L.gf_head_pack_floats()
+    pack = lambda arr, out: check(L.gf_head_pack(*[_hp(a) for a in arr], None, _hp(out)))
+    idx = fused._pack_index(pack, HEAD_SHAPES, n)
+    assert idx.shape == (n,) and int(idx.max()) == sum(int(np.prod(s)) for s in HEAD_SHAPES)
+    ws = _random(HEAD_SHAPES, 1)
+    want = np.zeros(n, np.float32)
+    pack(ws, want)
+    got = _gather(idx, ws)
+    assert np.array_equal(got, want)
+    # every weight the kernels read on the matrix pipe or the VALU is somewhere in the pack (the cond / identity columns are folded into
+    # per-frame biases on the device instead): a1[:, :32], a2, a3, s1, s2, s3, c1[:, :144], c2
+    used = np.zeros(int(idx.max()) + 1, bool)
+    used[idx.numpy()] = True
+    off = 1
+    for shp, cols in zip(HEAD_SHAPES, (32, 128, 128, 64, 128, 128, 144, 128)):
+        block = used[off:off + shp[0] * shp[1]].reshape(shp)
+        assert block[:, :cols].all() and not block[:, cols:].any()
+        off += shp[0] * shp[1]
+
+
+def test_torso_pack_index_reproduces_the_host_packer():
+    L = lib()
+    n = L.gf_torso_pack_floats()
+    pack = lambda arr, out: check(L.gf_torso_pack(*[_hp(a) for a in arr], _hp(out)))
+    idx = fused._pack_index(pack, TORSO_SHAPES, n)
+    ws = _random(TORSO_SHAPES, 2)
+    want = np.zeros(n, np.float32)
+    pack(ws, want)
+    assert np.array_equal(_gather(idx, ws), want)
+
+
+def test_backward_stream_index_is_the_transposed_blocks():
+    """stream[wave][layer][group][lane][i] = Wt[32 wave + (lane & 31)][8 group + 4 (lane >> 5) + i], Wt = the layer's weight block transposed and
+    zero-padded to 128 x 128 (include/geneface_hip.h: gf_field_backward)."""
+    L = lib()
+    idx = train_field._bwd_stream_index(HEAD_SHAPES)
+    assert idx.numel() == L.gf_field_bwd_stream_floats()
+    ws = _random(HEAD_SHAPES, 3)
+    stream = _gather(idx, ws).reshape(4, 6, 16, 64, 4)
+    a1, a2, a3, s1, s2, s3, c1, c2 = ws
+    blocks = [c1[:, 16:144], s3[1:129, :], s2, s1, a2, a1[:, :32]]       # forward [out, in] blocks in the order the backward kernel walks them
+    for k, W in enumerate(blocks):
+        Wt = np.zeros((128, 128), np.float32)
+        Wt[:W.shape[1], :W.shape[0]] = W.T                                # [forward input n][forward output o]
+        for wave in range(4):
+            for lane in (0, 5, 31, 32, 63):
+                for g in (0, 7, 15):
+                    n_, o_ = 32 * wave + (lane & 31), 8 * g + 4 * (lane >> 5)
+                    assert np.array_equal(stream[wave, k, g, lane], Wt[n_, o_:o_ + 4]), (k, wave, lane, g)
+    # nothing else of the weights is in the stream
+    assert int((idx > 0).sum()) == sum(b.size for b in blocks)
+
+
+def test_tall_product_matches_the_plain_one():
+    g = torch.randn(10000, 5)
+    x = torch.randn(10000, 7)
+    assert torch.allclose(train_field._tall_tn(g, x), g.t() @ x, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(train_field._tall_tn(g[:100], x[:100]), g[:100].t() @ x[:100], rtol=1e-5, atol=1e-4)
