@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: one hardware queue per frame in flight (geneface_amd/__init__.py)
 
 FLOP_PER_HEAD_SAMPLE = 178_688   # 2*(96*128+128*128+128*2 + 64*128+128*128+128*129 + 148*128+128*3)
 FLOP_PER_TORSO_PIXEL = 32_768    # 2*(104*64+64*64+64*2 + 136*32+32*32+32*4)
@@ -242,7 +243,7 @@ def main():
                                    + f"; frame-sharded over {world} GPU(s)",
                        "impl": impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
                        "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}",
-                       "frames_in_flight": pipe.in_flight if impl == "fused" else 1,
+                       "frames_in_flight": pipe.in_flight if impl == "fused" else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "repeats": len(dts), "timing": "median of `repeats` passes of exactly `steps` frames, each between barrier + synchronize pairs"},
             "roofline": roofline,
             "parity": parity,

@@ -8,6 +8,8 @@ Mirrors the data-parallel structure of inference/nerfs/base_nerf_infer.py in the
 One process per GPU (torchrun / torch.distributed, backend nccl == RCCL over xGMI); no per-frame
 communication.  Landmark post-processing lives in lm3d.py, model classes in radnerf*.py.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -69,11 +71,18 @@ class FramePipeline:
         self.intrinsics = [float(v) for v in seq["intrinsics"]]
         self.bg = torch.from_numpy(np.ascontiguousarray(seq["bg_img"])).float().view(1, -1, 3).to(dev)
         self.bg_coords = utils.get_bg_coords(self.H, self.W, dev)
-        # frames enqueued concurrently (streams, frame slots, host buffers).  Measured optimum on MI355X: three for the strict fp32
-        # head kernel (its persistent grid drains slowly: 701 -> 724 fps over two), two for the fast tier (more only adds contention).
+        # frames enqueued concurrently (streams, frame slots, host buffers).  Measured on MI355X: the strict fp32 head
+        # kernel's persistent grid drains slowly, the next frames' workgroups fill the CUs it leaves: 2 / 3 in flight = 690 / 723 fps, and a
+        # fourth helps (746) only when it gets a hardware queue of its own (GPU_MAX_HW_QUEUES >= 8, which the package sets by default when it
+        # is imported before the HIP runtime starts; with the runtime's default of 4 queues four in flight give 685).  Fast tier: 3 (1 845 ->
+        # 1 990 fps over two; more only adds contention).
         # Any count gives the same bytes on both tiers (tests/test_gpu_render.py::test_frames_in_flight_do_not_interfere).
         if in_flight is None:
-            in_flight = 2 if getattr(model, "render_precision", "fp32") == "fast" else 3
+            try:
+                queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+            except ValueError:
+                queues = 4
+            in_flight = 3 if getattr(model, "render_precision", "fp32") == "fast" else (4 if queues >= 8 else 3)
         self.in_flight = max(1, int(in_flight)) if overlap else 1
         pinned_outputs = pinned_outputs or max(2, self.in_flight)
         self._pinned = [torch.empty(self.H, self.W, 3, dtype=torch.uint8).pin_memory() for _ in range(pinned_outputs)] \
