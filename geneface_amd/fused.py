@@ -529,7 +529,7 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
 class _PipeBuffers:
     def __init__(self, pipe):
         dev, N = pipe.device, pipe.H * pipe.W
-        slots = max(2, getattr(pipe, "in_flight", 2))
+        slots = max(2, getattr(pipe, "max_in_flight", getattr(pipe, "in_flight", 2)))
         self.rgb = [torch.empty(N, 3, dtype=torch.float32, device=dev) for _ in range(slots)]
         self.depth = [torch.empty(N, dtype=torch.float32, device=dev) for _ in range(slots)]
         self.rgb8 = [torch.empty(pipe.H, pipe.W, 3, dtype=torch.uint8, device=dev) for _ in range(slots)]

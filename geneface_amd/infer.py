@@ -77,16 +77,26 @@ class FramePipeline:
         # is imported before the HIP runtime starts; with the runtime's default of 4 queues four in flight give 685).  Fast tier: 3 (1 845 ->
         # 1 990 fps over two; more only adds contention).
         # Any count gives the same bytes on both tiers (tests/test_gpu_render.py::test_frames_in_flight_do_not_interfere).
+        self._grow_to = 0               # > 0: depth to move to after the first rotation if the scene turns out to be a saturating one
         if in_flight is None:
             try:
                 queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
             except ValueError:
                 queues = 4
-            in_flight = 3 if getattr(model, "render_precision", "fp32") == "fast" else (4 if queues >= 8 else 3)
+            in_flight = 3
+            # The fourth frame only pays when the frames are light on phase 1: a thin-density scene (37 % of the hit rays survive their
+            # first max_steps samples, 1.2 M samples per frame) loses 4.5 % with it (536 -> 512 fps), the saturating fixture (6 %) gains
+            # 2 %.  So: start with three, look at the first finished frame's survivor count, then decide once.
+            if getattr(model, "render_precision", "fp32") != "fast" and queues >= 8 and overlap and pinned_outputs is None \
+                    and (impl or model.render_impl) == "fused" and self.device.type == "cuda":
+                self._grow_to = 4
         self.in_flight = max(1, int(in_flight)) if overlap else 1
-        pinned_outputs = pinned_outputs or max(2, self.in_flight)
+        self.max_in_flight = max(self.in_flight, self._grow_to)
+        pinned_outputs = pinned_outputs or max(2, self.max_in_flight)
         self._pinned = [torch.empty(self.H, self.W, 3, dtype=torch.uint8).pin_memory() for _ in range(pinned_outputs)] \
             if dev.type == "cuda" else [torch.empty(self.H, self.W, 3, dtype=torch.uint8)]
+        self._depth = len(self._pinned) if not self._grow_to else max(2, self.in_flight)   # host slots in rotation
+        self._rendered = 0
         self._events = [None] * len(self._pinned)
         self._slot = 0
         # fused path: consecutive frames rotate over `in_flight` side streams (and as many frame slots), so frame i+1 overlaps the
@@ -95,7 +105,7 @@ class FramePipeline:
         if dev.type == "cuda" and self.impl == "fused":
             # overlap=False keeps every frame on ONE side stream: kernels of consecutive frames never share the GPU, which is
             # what per-kernel profiling (rocprofv3 durations, HIP-event timing) wants; throughput runs use two
-            self._streams = [torch.cuda.Stream(dev) for _ in range(self.in_flight)]
+            self._streams = [torch.cuda.Stream(dev) for _ in range(self.max_in_flight)]
             for st in self._streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
 
@@ -118,13 +128,16 @@ class FramePipeline:
     def render_frame(self, i: int) -> torch.Tensor:
         """One step of the frame loop: returns the pinned-host uint8 [H,W,3] RGB frame (valid after `wait(slot)` /
         a stream sync; double-buffered so the D2H copy of frame i overlaps the kernels of frame i+1)."""
+        if self._grow_to and self._rendered == self._depth:   # the first rotation is enqueued: its first frame decides the depth
+            self._decide_depth()
+        self._rendered += 1
         slot = self._slot
-        self._slot = (slot + 1) % len(self._pinned)
+        self._slot = (slot + 1) % self._depth
         if self._events[slot] is not None:
             self._events[slot].synchronize()   # the host side of this slot's previous frame has been handed out and may be reused
         if self.impl == "fused":
             from .fused import render_frame_fused
-            with torch.cuda.stream(self._streams[slot % len(self._streams)]):
+            with torch.cuda.stream(self._streams[slot % self.in_flight]):
                 rgb8 = render_frame_fused(self, i, slot % max(2, self.in_flight))
                 self._pinned[slot].copy_(rgb8, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -140,15 +153,27 @@ class FramePipeline:
             self._events[slot] = ev
         return self._pinned[slot]
 
+    def _decide_depth(self):
+        """Once per pipeline (in_flight=None on >= 8 hardware queues): a fourth frame in flight if few rays outlive phase 0."""
+        grow, self._grow_to = self._grow_to, 0
+        from .fused import get_state
+        if self._events[0] is not None:
+            self._events[0].synchronize()
+        ctrl = get_state(self.model).workspace(self.H * self.W, 0)[1].cpu()
+        n_hit, n_surv = int(ctrl[1]), int(ctrl[2])
+        if n_surv * 100 < 15 * max(n_hit, 1):
+            self._slot = self._depth          # the new slot goes next, then the rotation continues over all of them
+            self.in_flight = self._depth = grow
+
     def stream(self, indices):
         """Frame loop with the pipeline kept full: yields (i, uint8 [H,W,3] numpy view of the pinned buffer) once frame i has reached
         host memory, while the following frames are already enqueued.  The view is only valid until the next iteration (the slot is
         reused): consumers copy it or hand it to an encoder that does (png.FrameWriter.submit)."""
-        pending, depth = [], len(self._pinned)
+        pending = []
         for i in indices:
             buf = self.render_frame(i)
-            pending.append((i, buf, self._events[(self._slot - 1) % depth]))
-            if len(pending) == depth:          # the oldest slot is the next one to be reused: drain it first
+            pending.append((i, buf, self._events[(self._slot - 1) % self._depth]))
+            if len(pending) >= self._depth:    # the oldest slot is the next one to be reused: drain it first
                 j, b, ev = pending.pop(0)
                 if ev is not None:
                     ev.synchronize()

@@ -665,6 +665,36 @@ def test_frames_in_flight_do_not_interfere(in_flight, precision):
     assert got == len(order)
 
 
+@pytest.mark.parametrize("thin", [False, True])
+def test_pipeline_depth_follows_the_scene(thin, monkeypatch):
+    """in_flight=None on a process with eight hardware queues: the pipeline starts with three frames in flight and takes a fourth after the
+    first rotation if few rays outlive phase 0 (the saturating fixture), and keeps three on a thin-density scene.  Frames are what each gives
+    alone either way, bit for bit, across the switch."""
+    from geneface_amd.infer import FramePipeline
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = HP.may_hparams(True)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True, sigma_row_scale=0.02 if thin else 1.0), strict=True)
+    model.render_impl = "fused"
+    model = model.to(DEV).eval()
+    seq = sequence(4, 160, 160)
+    solo = FramePipeline(model, hp, seq, DEV, impl="fused", overlap=False)
+    want = []
+    for i in range(4):
+        f = solo.render_frame(i)
+        solo.wait()
+        want.append(f.clone().numpy())
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused")
+    assert pipe.in_flight == 3 and pipe.max_in_flight == 4
+    order = [0, 1, 2, 3, 3, 1, 0, 2] * 4
+    for n, ((i, frame), k) in enumerate(zip(pipe.stream(order), order)):
+        assert i == k and np.array_equal(frame, want[k]), (thin, n)
+    assert pipe.in_flight == (3 if thin else 4)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fast"])
 def test_full_size_frames_are_reproducible(precision):
     """Run-to-run reproducibility where it was once lost: at 512x512 the persistent head grid puts two workgroups on every CU (a 160x160
