@@ -2,6 +2,8 @@
 //   grid : /root/reference/modules/radnerfs/encoders/gridencoder/src/gridencoder.cu:88-244, launch :370-400
 //   SH   : .../encoders/shencoder/src/shencoder.cu:28-68 (degree <= 4), launch :385-391
 //   freq : .../encoders/freqencoder/src/freqencoder.cu:30-58, launch :96-110
+#include <atomic>
+
 #include "common.hpp"
 #include "grid_core.hpp"
 #include "sh_core.hpp"
@@ -427,11 +429,14 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
     if (B < (1u << 16)) wgs = 32;
     // per-level scale of the fixed-point accumulators: a slot of a small device ring (calls on different streams take different slots)
-    static uint32_t* ring = nullptr;
-    static unsigned ring_pos = 0;
+    static uint32_t* rings[64] = {};   // one per device of the process (allocated on first use, never freed)
+    static std::atomic<unsigned> ring_pos{0};
     constexpr unsigned kSlots = 64;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: no current device");
+    uint32_t*& ring = rings[dev];
     if (!ring && hipMalloc(&ring, kSlots * gf::kMaxLevels * sizeof(uint32_t)) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMalloc failed");
-    uint32_t* lvl_max = ring + (size_t)(ring_pos++ % kSlots) * gf::kMaxLevels;
+    uint32_t* lvl_max = ring + (size_t)(ring_pos.fetch_add(1u) % kSlots) * gf::kMaxLevels;
     if (hipMemsetAsync(lvl_max, 0, gf::kMaxLevels * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
     const dim3 mgrid(B >= (1u << 16) ? 128u : 8u, lv.L);
     const dim3 grid(wgs, lv.L), block(kGbThreads);
