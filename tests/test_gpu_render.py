@@ -214,19 +214,21 @@ def test_fused_other_grid_configs_vs_oracle(grid_type, interp):
     check(out_ops, ref, True)
 
 
-def test_full_size_fused_vs_ops_and_invariants():
-    """BASELINE.json's full size (512x512 head+torso), where the CPU oracle takes ~6 s per frame: the two GPU execution
+@pytest.mark.parametrize("size", [512, 1024])
+def test_full_size_fused_vs_ops_and_invariants(size):
+    """BASELINE.json's full size (512x512 head+torso) and four times that (2^20 rays: the largest frame the viewer asks for), where the CPU
+    oracle takes 6 - 25 s per frame: the two GPU execution
     strategies (reference loop structure over stand-alone ops vs the fused two-phase kernels) must produce the same picture,
     and size-independent properties of the path must hold: the schedule replayed on the device equals the one the op-by-op
     loop actually ran; pixels whose ray misses the occupancy are exactly the blended background; weights stay in [0, 1]."""
     from geneface_amd.fused import frame_stats
     hp, sd, model = build(True, "ops")
-    fi = frame_inputs(sequence(4, 512, 512), 1)
+    fi = frame_inputs(sequence(4, size, size), 1)
     out_ops = render_gpu(model, hp, fi)
     sched_ops = [s for _, s in model.last_schedule]
     model.render_impl = "fused"
     out = render_gpu(model, hp, fi)
-    fs = frame_stats(model.last_ctrl, 512 * 512, hp["max_steps"])
+    fs = frame_stats(model.last_ctrl, size * size, hp["max_steps"])
     assert [n for _, n in fs["schedule"]] == sched_ops
     assert fs["budget"] == fs["budget_device"] == sum(sched_ops)
     a, b = out["rgb_map"].float().cpu(), out_ops["rgb_map"].float().cpu()
