@@ -59,16 +59,41 @@ def get_bg_coords(H, W, device):
     return torch.cat([xs.reshape(-1, 1), ys.reshape(-1, 1)], dim=-1).unsqueeze(0)
 
 
-def get_rays(poses, intrinsics, H, W, N=-1):
-    """All-pixel pinhole rays: pixel centres at +0.5, unit directions rotated by pose[:3,:3], row-major order."""
-    if N > 0:
-        raise NotImplementedError("get_rays: random / patch / rect sampling is a training feature (SURVEY.md 8f-2)")
+def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
+    """Pinhole rays (modules/radnerfs/utils.py:282-363): pixel centres at +0.5, unit directions rotated by pose[:3,:3].
+    N = -1: every pixel, row-major.  Training modes, same draws from torch's global generator as the reference makes: N > 0 random pixels
+    (duplicates possible), patch_size > 1: N // patch_size^2 random patches (top-left corners in [0, H - p) x [0, W - p)), rect =
+    (row0, row1, col0, col1): every pixel of that rectangle (the lip-finetune crop).  Returns i, j (pixel centres), inds, rays_o, rays_d,
+    all [B, N, ...]."""
     device = poses.device
     B = poses.shape[0]
     fx, fy, cx, cy = intrinsics
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device), indexing="ij")
-    i = i.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
-    j = j.t().reshape([1, H * W]).expand([B, H * W]) + 0.5
+    if rect is not None:
+        r0, r1, c0, c1 = rect
+        N = (r1 - r0) * (c1 - c0)
+    if N > 0:
+        N = min(N, H * W)
+        if patch_size > 1:
+            num_patch = N // (patch_size ** 2)
+            rows = torch.randint(0, H - patch_size, size=[num_patch], device=device)
+            cols = torch.randint(0, W - patch_size, size=[num_patch], device=device)
+            p = torch.arange(patch_size, device=device)
+            rr = (rows[:, None, None] + p[None, :, None]).expand(num_patch, patch_size, patch_size)
+            cc = (cols[:, None, None] + p[None, None, :]).expand(num_patch, patch_size, patch_size)
+            inds = (rr * W + cc).reshape(-1)
+            inds = inds.expand([B, inds.numel()])
+        elif rect is not None:
+            r0, r1, c0, c1 = rect
+            rr = torch.arange(max(r0, 0), min(r1, H), device=device)
+            cc = torch.arange(max(c0, 0), min(c1, W), device=device)
+            inds = (rr[:, None] * W + cc[None, :]).reshape(1, -1)
+        else:
+            inds = torch.randint(0, H * W, size=[N], device=device)
+            inds = inds.expand([B, N])
+    else:
+        inds = torch.arange(H * W, device=device).expand([B, H * W])
+    i = (inds % W).float() + 0.5      # the reference gathers these from a [H, W] meshgrid: small integers, exact in fp32 either way
+    j = torch.div(inds, W, rounding_mode="floor").float() + 0.5
     zs = torch.ones_like(i)
     xs = (i - cx) / fx * zs
     ys = (j - cy) / fy * zs
@@ -76,7 +101,7 @@ def get_rays(poses, intrinsics, H, W, N=-1):
     directions = directions / torch.norm(directions, dim=-1, keepdim=True)
     rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
     rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
-    return {"i": i, "j": j, "inds": torch.arange(H * W, device=device).expand([B, H * W]), "rays_o": rays_o, "rays_d": rays_d}
+    return {"i": i, "j": j, "inds": inds, "rays_o": rays_o, "rays_d": rays_d}
 
 
 def smooth_camera_path(poses: np.ndarray, kernel_size=7) -> np.ndarray:

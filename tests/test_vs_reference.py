@@ -79,6 +79,15 @@ def test_rays_poses_bgcoords_match_reference_utils():
     for a in (mine["rays_d"], rd):
         assert torch.equal(a, ref["rays_d"])
     assert torch.equal(mine["rays_o"], ref["rays_o"]) and torch.equal(ro, ref["rays_o"])
+    # the training-time sampling modes draw the same pixels from the same generator state
+    poses2 = torch.from_numpy(seq["poses"][:2])
+    for kw in (dict(N=500), dict(N=4096, patch_size=8), dict(N=-1, rect=(10, 30, 5, 41)), dict(N=10 ** 6)):
+        torch.manual_seed(11)
+        ref = U.get_rays(poses2 if "rect" not in kw else pose, seq["intrinsics"], 64, 48, **kw)
+        torch.manual_seed(11)
+        mine = ours.get_rays(poses2 if "rect" not in kw else pose, seq["intrinsics"], 64, 48, **kw)
+        for k in ("inds", "i", "j", "rays_o", "rays_d"):
+            assert mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]), (kw, k)
     assert torch.equal(ours.get_bg_coords(64, 64, "cpu"), U.get_bg_coords(64, 64, "cpu"))
     assert torch.equal(R.get_bg_coords(64, 64), U.get_bg_coords(64, 64, "cpu"))
     poses = torch.from_numpy(seq["poses"])
