@@ -291,12 +291,12 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     __shared__ long long tab[kGbLdsEntries];
     const uint32_t level = blockIdx.y;
     const float gmax = __uint_as_float(lvl_max[level]);
-    if (!(gmax > 1e-30f)) return;                                  // an all-zero gradient level adds nothing (nor does one below 1e-30: 2^30 / gmax must stay finite)
     if (!(gmax < INFINITY)) {                                      // inf / NaN in the gradient (fp16 loss scaling overflowed): the float scatter would
         if (blockIdx.x == 0 && threadIdx.x == 0)                   // have put a non-finite value into the table, which is what GradScaler looks for
             unsafeAtomicAdd(grad_grid + (size_t)offsets[level] * C, __uint_as_float(0x7fc00000u));
         return;
     }
+    if (!(gmax > 1e-30f)) return;                                  // an all-zero gradient level adds nothing (nor does one below 1e-30: 2^30 / gmax must stay finite)
     const float to_fixed = kGbFixedOne / gmax;
     const double from_fixed = (double)gmax / (double)kGbFixedOne;
     const uint32_t off = (uint32_t)offsets[level];
@@ -423,31 +423,37 @@ __global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __r
 
 template <uint32_t D>
 int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, const int* offsets, float* grad_grid, uint32_t B,
-                        const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
+                        const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s, const uint32_t* level_max = nullptr) {
     // workgroups per level (grid.x): partitions x slices, the surplus exits at once.  flush_budget = table floats x slices a level may
     // spend on flush atomics; min_slices keeps the fine levels' point lists short enough to balance the chip.
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
     if (B < (1u << 16)) wgs = 32;
-    // per-level scale of the fixed-point accumulators: a slot of a small device ring (calls on different streams take different slots)
-    static uint32_t* rings[64] = {};   // one per device of the process (allocated on first use, never freed)
-    static std::atomic<unsigned> ring_pos{0};
-    constexpr unsigned kSlots = 64;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: no current device");
-    uint32_t*& ring = rings[dev];
-    if (!ring && hipMalloc(&ring, kSlots * gf::kMaxLevels * sizeof(uint32_t)) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMalloc failed");
-    uint32_t* lvl_max = ring + (size_t)(ring_pos.fetch_add(1u) % kSlots) * gf::kMaxLevels;
-    if (hipMemsetAsync(lvl_max, 0, gf::kMaxLevels * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
+    // per-level scale of the fixed-point accumulators: handed in by the caller (the kernel that produced the gradient knows its maxima), or one
+    // max pass over the gradient into a slot of a small device ring (calls on different streams take different slots)
+    const uint32_t* lvl_max = level_max;
+    uint32_t* own_max = nullptr;
+    if (!lvl_max) {
+        static uint32_t* rings[64] = {};   // one per device of the process (allocated on first use, never freed)
+        static std::atomic<unsigned> ring_pos{0};
+        constexpr unsigned kSlots = 64;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: no current device");
+        uint32_t*& ring = rings[dev];
+        if (!ring && hipMalloc(&ring, kSlots * gf::kMaxLevels * sizeof(uint32_t)) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMalloc failed");
+        own_max = ring + (size_t)(ring_pos.fetch_add(1u) % kSlots) * gf::kMaxLevels;
+        if (hipMemsetAsync(own_max, 0, gf::kMaxLevels * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
+        lvl_max = own_max;
+    }
     const dim3 mgrid(B >= (1u << 16) ? 128u : 8u, lv.L);
     const dim3 grid(wgs, lv.L), block(kGbThreads);
     switch (C) {
-        case 1: hipLaunchKernelGGL((k_grid_absmax<1>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+        case 1: if (own_max) hipLaunchKernelGGL((k_grid_absmax<1>), mgrid, dim3(256), 0, s, grad, B, own_max);
                 hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 2: hipLaunchKernelGGL((k_grid_absmax<2>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+        case 2: if (own_max) hipLaunchKernelGGL((k_grid_absmax<2>), mgrid, dim3(256), 0, s, grad, B, own_max);
                 hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 4: hipLaunchKernelGGL((k_grid_absmax<4>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+        case 4: if (own_max) hipLaunchKernelGGL((k_grid_absmax<4>), mgrid, dim3(256), 0, s, grad, B, own_max);
                 hipLaunchKernelGGL((k_grid_backward<D, 4>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 8: hipLaunchKernelGGL((k_grid_absmax<8>), mgrid, dim3(256), 0, s, grad, B, lvl_max);
+        case 8: if (own_max) hipLaunchKernelGGL((k_grid_absmax<8>), mgrid, dim3(256), 0, s, grad, B, own_max);
                 hipLaunchKernelGGL((k_grid_backward<D, 8>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
         default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
     }
@@ -574,6 +580,25 @@ GF_EXPORT int gf_grid_encode_backward(const float* grad, const float* inputs, co
         return gf_check_launch("grid_encode_backward(inputs)");
     }
     return GF_OK;
+}
+
+// gf_grid_encode_backward for a gradient already in [L, B, C] order whose per-level max |g| the caller knows (level_max[L], bit patterns of
+// non-negative floats; gf_field_backward writes them next to the gradient): the table scatter without the max pass, no input gradient.
+GF_EXPORT int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                             uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                             const uint32_t* level_max, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings || !level_max) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_scaled: null pointer");
+    if (gridtype > 1 || interp > 1) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_scaled: gridtype/interp must be 0 or 1");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_scaled: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: return dispatch_backward_c<2>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max);
+        case 3: return dispatch_backward_c<3>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max);
+        default: return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_scaled: D must be 2 or 3");
+    }
 }
 
 GF_EXPORT int gf_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets, float weight, uint32_t B,

@@ -1311,6 +1311,7 @@ struct BwdArgs {
     float *g_hc1, *g_geo, *g_hs2, *g_hs1, *g_ha2, *g_ha1;  // [M,128] each
     float *g_f3, *g_f2;                                    // [16 levels][M][2] each: the layout the table scatter kernel reads
     float *s_hc1, *s_ha1;                                  // [128] each, ZEROED by the caller: column sums of g_hc1 / g_ha1 over the points
+    uint32_t* lvl_max;                                     // or NULL; [2][16] ZEROED by the caller: max |g_f3| / |g_f2| per level (float bit patterns)
     uint32_t M;
 };
 
@@ -1450,6 +1451,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         if (valid) {   // [level][point][channel]: the layout gf_grid_encode_backward indexes (gridencoder.cu:275), no transpose on the host
 #pragma unroll
             for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f2 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf2[2 * l], gf2[2 * l + 1]};
+            if (u.lvl_max) {   // running per-level maxima of this workgroup (bit patterns of |g| order like the values; a NaN ends up on top)
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const uint32_t m0 = __float_as_uint(gf2[2 * l]) & 0x7fffffffu, m1 = __float_as_uint(gf2[2 * l + 1]) & 0x7fffffffu;
+                    atomicMax(&s.hist[16 + 8 * half + l], m0 > m1 ? m0 : m1);
+                }
+            }
         }
         const float x2[2] = {(ambv[0] + 1.0f) / 2.0f, (ambv[1] + 1.0f) / 2.0f};
         float dx[2];
@@ -1490,6 +1498,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
 #pragma unroll
         for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf3[2 * l], gf3[2 * l + 1]};
+        if (u.lvl_max) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                const uint32_t m0 = __float_as_uint(gf3[2 * l]) & 0x7fffffffu, m1 = __float_as_uint(gf3[2 * l + 1]) & 0x7fffffffu;
+                atomicMax(&s.hist[8 * half + l], m0 > m1 ? m0 : m1);
+            }
+        }
     }
     __syncthreads();
 }
@@ -1506,6 +1521,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
         *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
                : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
     }
+    if (tid < 32) s.hist[tid] = 0;   // [0..15] max |d f3| per level, [16..31] max |d f2| (visible behind the first round's barriers)
     const uint32_t chunks = (u.M + kPass - 1) / kPass;
     float cs_hc1[16], cs_ha1[16];
 #pragma unroll
@@ -1534,6 +1550,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
             atomicAdd(&u.s_ha1[feat], va);
         }
     }
+    __syncthreads();
+    if (u.lvl_max && tid < 32 && s.hist[tid]) atomicMax(&u.lvl_max[tid], s.hist[tid]);
 }
 
 // ---------------------------------------------------------------------------------------------------- frame setup
@@ -1857,7 +1875,7 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets; ha.head_pack = f->head_pack;
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     BwdArgs ba = {bwd_stream, g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1,
-                  g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1, M};
+                  g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1, g->level_max, M};
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_backward), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)

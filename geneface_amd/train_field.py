@@ -33,7 +33,7 @@ class GfFieldSaves(C.Structure):
 class GfFieldGrads(C.Structure):
     """ctypes mirror of gf_field_grads_t."""
     _fields_ = [(n, _vp) for n in ("g_sigma", "g_rgb", "g_amb", "sigma", "rgb", "amb", "m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1", "g_zc", "g_h0", "g_za",
-                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2", "s_hc1", "s_ha1")]
+                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2", "s_hc1", "s_ha1", "level_max")]
 
 
 def _bwd_stream_index(shapes):
@@ -73,14 +73,21 @@ def _tall_tn(g, x):
     return gw
 
 
-def _grid_backward(enc, x01, grad, want_input_grad, level_major=False):
+def _grid_backward(enc, x01, grad, want_input_grad, level_major=False, level_max=None):
     """Table gradient (and d/d x01 through a freshly evaluated dy_dx) of GridEncoder `enc` at inputs x01 [M,D] for an output gradient
-    `grad` [M, L*C] (or already [L, M, C] with level_major): the library's backward kernels, without re-entering autograd."""
+    `grad` [M, L*C] (or already [L, M, C] with level_major): the library's backward kernels, without re-entering autograd.  level_max: the
+    per-level max |grad| (int32 view of float bits, [L]) when the producer of `grad` has it -- spares the scatter its max pass."""
     L_ = lib()
     dev = x01.device
     B, D = x01.shape
     L, Cc = enc.num_levels, enc.level_dim
     S = float(np.log2(enc.per_level_scale))
+    if level_max is not None and level_major and not want_input_grad:
+        g_tab = torch.zeros_like(enc.embeddings)
+        check(L_.gf_grid_encode_backward_scaled(ptr(grad, torch.float32), ptr(x01, torch.float32), ptr(enc.offsets, torch.int32), ptr(g_tab, torch.float32),
+                                                B, D, Cc, L, S, int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
+                                                ptr(level_max, torch.int32), current_stream(dev)))
+        return g_tab, None
     dy_dx = gin = None
     if want_input_grad:
         dy_dx = torch.empty(B, L * D * Cc, device=dev, dtype=torch.float32)
@@ -160,6 +167,7 @@ class _HeadField(torch.autograd.Function):
                                                         ("g_ha2", 128), ("g_ha1", 128), ("g_f3", 32), ("g_f2", 32))}
         out["g_h0"] = torch.empty(M, **f32)
         out["s_hc1"], out["s_ha1"] = z(128), z(128)
+        level_max = torch.zeros(32, dtype=torch.int32, device=dev)      # [0:16] max |g_f3| per level, [16:32] max |g_f2| (float bit patterns)
         if M > 0:
             f = fused.GfFrame()
             pe, ae = model.position_embedder, model.ambient_embedder
@@ -170,7 +178,7 @@ class _HeadField(torch.autograd.Function):
             f.head_pack = ptr(st.head_pack)
             g = GfFieldGrads(g_sigma=g_sigma.data_ptr(), g_rgb=g_rgb.data_ptr(), g_amb=g_amb.data_ptr(), sigma=sigma.data_ptr(), rgb=rgb.data_ptr(),
                              amb=amb.data_ptr(), m_hc1=m_hc1.data_ptr(), m_hs2=m_hs2.data_ptr(), m_hs1=m_hs1.data_ptr(), m_ha2=m_ha2.data_ptr(),
-                             m_ha1=m_ha1.data_ptr(), **{n: t.data_ptr() for n, t in out.items()})
+                             m_ha1=m_ha1.data_ptr(), level_max=level_max.data_ptr(), **{n: t.data_ptr() for n, t in out.items()})
             check(lib().gf_field_backward(C.byref(f), ptr(stream, torch.float32), M, C.byref(g), current_stream(dev)))
         g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
@@ -192,8 +200,10 @@ class _HeadField(torch.autograd.Function):
         g_wa1 = torch.cat([_tall_tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         g_cond = (s_ha1 @ wa1[:, 32:]).view_as(cond_feat)
         # ---- grid tables
-        g_amb_tab, _ = _grid_backward(model.ambient_embedder, (amb + 1) / 2, out["g_f2"], False, level_major=True)
-        g_pos_tab, _ = _grid_backward(model.position_embedder, (x + model.bound) / (2 * model.bound), out["g_f3"], False, level_major=True)
+        lm = level_max if M > 0 else None
+        g_amb_tab, _ = _grid_backward(model.ambient_embedder, (amb + 1) / 2, out["g_f2"], False, level_major=True, level_max=None if lm is None else lm[16:])
+        g_pos_tab, _ = _grid_backward(model.position_embedder, (x + model.bound) / (2 * model.bound), out["g_f3"], False, level_major=True,
+                                      level_max=None if lm is None else lm[:16])
         return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
 
 

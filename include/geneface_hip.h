@@ -268,9 +268,16 @@ typedef struct gf_field_grads {
     float* g_hc1; float* g_geo; float* g_hs2; float* g_hs1; float* g_ha2; float* g_ha1;   /* out: [M,128] each, pre-activation gradients */
     float* g_f3; float* g_f2;                                       /* out: [16 levels][M][2] each (the [L,B,C] layout gf_grid_encode_backward reads) */
     float* s_hc1; float* s_ha1;                                     /* out, ZEROED by the caller: [128] column sums of g_hc1 / g_ha1 over the points */
+    uint32_t* level_max;                                            /* out or NULL, ZEROED by the caller: [2][16] max |g_f3| (first 16) and |g_f2| per level,
+                                                                       as bit patterns of non-negative floats: what gf_grid_encode_backward_scaled takes */
 } gf_field_grads_t;
 uint32_t gf_field_bwd_stream_floats(void);
 int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
+/* gf_grid_encode_backward (gridencoder.cu:248-339) for a gradient already in [L, B, C] order whose per-level max |g| is known on the device
+ * (level_max[L]; gf_field_backward produces both): the table scatter without its max pass; no input gradient.  D = 2 or 3. */
+int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                   uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                   const uint32_t* level_max, void* stream);
 uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
 int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
                    uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);
