@@ -281,6 +281,7 @@ __device__ __forceinline__ void obw_store(float* Hw, const floatx16 (&acc)[4]) {
 struct SaveBufs {
     float *f3, *ha1, *ha2, *f2, *hs1, *hs2, *geo, *hc1;   // [M,32] [M,128] [M,128] [M,32] [M,128] [M,128] [M,128] [M,128]
     uint16_t *m_ha1, *m_ha2, *m_hs1, *m_hs2, *m_hc1;      // ReLU masks in ACCUMULATOR layout: [chunk of 128][tile 4][wave 4][lane 64], bit r = register r > 0
+    float* sh;                                            // or NULL: [M,16] the SH basis of the direction (colour L1's other input)
 };
 
 // The values obw_store writes to LDS, also to row (gbase + sample) of a [M,128] matrix: this lane's 4 consecutive floats per (tile, q) --
@@ -526,6 +527,13 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
             const uint32_t slot = s.rrank[d];
             float sh[16];
             gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+            if constexpr (SAVE) {   // every wave evaluates every tile's directions: wave t writes tile t's rows
+                if (sv->sh && t == wave && half == 0 && (uint32_t)(t * 32 + j) < Mv) {
+                    float4* row = reinterpret_cast<float4*>(sv->sh + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) row[q] = float4{sh[4 * q], sh[4 * q + 1], sh[4 * q + 2], sh[4 * q + 3]};
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -1826,7 +1834,7 @@ static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float
         if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1)
             return gf_set_error(GF_ERR_INVALID, "field_forward_train: null save buffer");
         pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1,
-                 saves->m_ha1, saves->m_ha2, saves->m_hs1, saves->m_hs2, saves->m_hc1};
+                 saves->m_ha1, saves->m_ha2, saves->m_hs1, saves->m_hs2, saves->m_hc1, saves->sh};
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -27,7 +27,7 @@ _vp = C.c_void_p
 
 class GfFieldSaves(C.Structure):
     """ctypes mirror of gf_field_saves_t (include/geneface_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1")]
+    _fields_ = [(n, _vp) for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1", "sh")]
 
 
 class GfFieldGrads(C.Structure):
@@ -118,7 +118,7 @@ class _HeadField(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         sigma, rgb, amb = torch.empty(M, **f32), torch.empty(M, 3, **f32), torch.empty(M, 2, **f32)
         sv = {n: torch.empty(M, w, **f32) for n, w in (("f3", 32), ("ha1", 128), ("ha2", 128), ("f2", 32), ("hs1", 128), ("hs2", 128),
-                                                      ("geo", 128), ("hc1", 128))}
+                                                      ("geo", 128), ("hc1", 128), ("sh", 16))}
         chunks = (M + 127) // 128
         masks = {n: torch.empty(chunks * 1024, dtype=torch.int16, device=dev) for n in ("m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1")}
         if M > 0:
@@ -139,14 +139,14 @@ class _HeadField(torch.autograd.Function):
         ctx.model = model
         ctx.has_code = ind_code is not None
         ctx.save_for_backward(x, d, cond_feat, ind_code if ind_code is not None else torch.zeros(0, device=dev), sigma, rgb, amb,
-                              wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, *[sv[n] for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1")],
+                              wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, *[sv[n] for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "sh")],
                               *[masks[n] for n in ("m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1")])
         return sigma, rgb, amb
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_sigma, g_rgb, g_amb):
-        (x, d, cond_feat, ind_code, sigma, rgb, amb, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, f3, ha1, ha2, f2, hs1, hs2, geo, hc1,
+        (x, d, cond_feat, ind_code, sigma, rgb, amb, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, f3, ha1, ha2, f2, hs1, hs2, geo, hc1, sh,
          m_hc1, m_hs2, m_hs1, m_ha2, m_ha1) = ctx.saved_tensors
         from . import fused
         model = ctx.model
@@ -183,7 +183,6 @@ class _HeadField(torch.autograd.Function):
         g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
         # ---- weight gradients: tall products of the pre-activation gradients with the saved activations
-        sh = model.direction_embedder(d)                                          # [M,16] (no gradient: directions are data)
         s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
         g_wc2 = _tall_tn(g_zc, hc1)
         parts = [_tall_tn(g_hc1, sh), _tall_tn(g_hc1, geo)]

@@ -251,6 +251,7 @@ typedef struct gf_field_saves {
     /* optional (all five or none): ReLU masks of ha1, ha2, hs1, hs2, hc1 for gf_field_backward, 2 bytes per lane in the kernels'
      * accumulator layout: uint16 [ceil(M/128)][4 tiles][4 waves][64 lanes], bit r set when the lane's r-th value of that tile is > 0 */
     uint16_t* m_ha1; uint16_t* m_ha2; uint16_t* m_hs1; uint16_t* m_hs2; uint16_t* m_hc1;
+    float* sh;    /* optional: [M,16] SH basis of the directions (the other input of color_net layer 0) */
 } gf_field_saves_t;
 int gf_field_forward_train(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
                            float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream);
