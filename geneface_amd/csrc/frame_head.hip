@@ -594,7 +594,14 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 constexpr int kHS16 = 136;            // halves per activation row
 constexpr int kFS16 = 72;             // halves per row of the 3-D feature buffer (32 used; 144 B: rows 16 B apart in bank space)
 static_assert((kPass * kHS16 + kPass * kFS16 + kPool * 16) * 2 <= kPass * kHS * 4, "f16 activations + 3-D features + SH table fit the fp32 activation buffer");
-constexpr int kWAhead16 = 4;          // A-operand FIFO depth: one group is only NT x 32 cycles of MFMA
+// A-operand FIFO depth of the f16 kernel.  Two, not more: with four the kernel needed 80 bytes of scratch per lane, and a launch that uses scratch
+// at all costs ~45 us more when it runs alone (0.57 -> 0.49 ms of head kernel per frame; the same was seen on a build of the fp32 kernel that
+// spilled 12 bytes: +55 us per launch) -- with frames in flight the cost hides, the frame rate is the same either way, and this kernel spends
+// 5 % of a round on the matrix pipe, so the shallower prefetch costs nothing.
+#ifndef GF_WAHEAD16
+#define GF_WAHEAD16 2
+#endif
+constexpr int kWAhead16 = GF_WAHEAD16;
 struct WPipe16 { float4 q[kWAhead16]; };
 
 template <int G>
