@@ -183,28 +183,31 @@ __device__ __forceinline__ float4 load_group(const char* __restrict__ Ws, uint32
     return *reinterpret_cast<const float4*>(Ws + (size_t)g * 1024 + (size_t)lane16);
 }
 
-// The stream is consumed strictly in order (frame.hpp: G_AMB1 .. G_COL1G), so three registers quads form a FIFO that runs
-// kWAhead groups (>= 2 x 16 MFMAs = 2048 cycles) ahead of the MFMAs, across layer boundaries and barriers: q[g % 3] holds
-// group g from the moment group g - 3 has been issued.
-constexpr int kWAhead = 3;
-struct WPipe { float4 q[kWAhead]; };
+// The stream is consumed strictly in order (frame.hpp: G_AMB1 .. G_COL1G), so a few register quads form a FIFO that runs kAhead groups
+// (of 16 MFMAs = 1 024 cycles with four sample tiles) ahead of the MFMAs, across layer boundaries and barriers: q[g % kAhead] holds group g
+// from the moment group g - kAhead has been issued.  Three ahead in the frame kernels; two in the training kernels, which need the four
+// registers more than the slack (with three they spill, and a launch that uses scratch at all pays for it: DESIGN.md 4.7).
+template <int A>
+struct WPipeT { static constexpr int kAhead = A; float4 q[A]; };
+constexpr int kWAhead = 3, kWAheadTrain = 2;
+using WPipe = WPipeT<kWAhead>;
 
-template <int G>
-__device__ __forceinline__ float4 wpipe_take(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
-    return wp.q[G % kWAhead];
+template <int G, class WP>
+__device__ __forceinline__ float4 wpipe_take(WP& wp, const char* __restrict__ Ws, uint32_t lane16) {
+    return wp.q[G % WP::kAhead];
 }
 // GEND: one past the last group this launch consumes (the density-only field stops before density L3)
-template <int G, int GEND = (int)gf::G_TOTAL>
-__device__ __forceinline__ void wpipe_refill(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16) {
-    if constexpr (G + kWAhead < GEND) wp.q[G % kWAhead] = load_group(Ws, G + kWAhead, lane16);
+template <int G, int GEND = (int)gf::G_TOTAL, class WP>
+__device__ __forceinline__ void wpipe_refill(WP& wp, const char* __restrict__ Ws, uint32_t lane16) {
+    if constexpr (G + WP::kAhead < GEND) wp.q[G % WP::kAhead] = load_group(Ws, G + WP::kAhead, lane16);
 }
 
 // U 4-step groups (first one = group G0 of this wave's stream Ws) of this wave's output block over NT sample tiles.
 // Hb = &H[lane & 31][col0 + 4 * (lane >> 5)]: tile t is 32 rows further, group u eight floats further.
 // Software pipeline, pinned with sched_barrier so the scheduler cannot sink the loads next to their use: while the 16 MFMAs
 // of group u issue, the B operands of group u+1 (LDS) and the A operands of group u+3 (L2) are in flight.
-template <int NT, int G0, int U, int u, int GEND = (int)gf::G_TOTAL>
-__device__ __forceinline__ void obw_step(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4],
+template <int NT, int G0, int U, int u, int GEND = (int)gf::G_TOTAL, class WP>
+__device__ __forceinline__ void obw_step(WP& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4],
                                          const float4 (&b)[NT]) {
     if constexpr (u < U) {
         float4 bn[NT];
@@ -227,8 +230,8 @@ __device__ __forceinline__ void obw_step(WPipe& wp, const char* __restrict__ Ws,
         obw_step<NT, G0, U, u + 1, GEND>(wp, Ws, lane16, Hb, acc, bn);
     }
 }
-template <int NT, int G0, int U, int GEND = (int)gf::G_TOTAL>
-__device__ __forceinline__ void obw_mfma(WPipe& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4]) {
+template <int NT, int G0, int U, int GEND = (int)gf::G_TOTAL, class WP>
+__device__ __forceinline__ void obw_mfma(WP& wp, const char* __restrict__ Ws, uint32_t lane16, const float* Hb, floatx16 (&acc)[4]) {
     float4 b[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4*>(Hb + t * 32 * kHS);
@@ -381,9 +384,9 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     uint32_t dkey = 0xFFFFFFFFu;
 #endif
     floatx16 A[4], S[4];
-    WPipe wp;
+    WPipeT<(SAVE ? kWAheadTrain : kWAhead)> wp;
 #pragma unroll
-    for (int g = 0; g < kWAhead; g++) wp.q[g] = load_group(Ws, g, lane16);   // lands while the grid lookups run
+    for (int g = 0; g < decltype(wp)::kAhead; g++) wp.q[g] = load_group(Ws, g, lane16);   // lands while the grid lookups run
 
     // ---- 3-D grid features -> H[:, 0:32]
     if (tile_on) {
@@ -1333,8 +1336,11 @@ struct BwdArgs {
 // accumulators -> LDS (and row gbase + sample of G), optionally through the ReLU mask of the layer whose pre-activation gradient this is
 template <int NT, bool MASK>
 __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
-                                          int lane, const floatx16 (&acc)[4], float* colsum = nullptr /* this lane's 16 running column sums */) {
+                                          int lane, const floatx16 (&acc)[4], float* colsum = nullptr /* LDS [128]: running column sums of G, or NULL */) {
     const int half = lane >> 5, j = lane & 31;
+    float part[16];   // this lane's share of the column sums of this call (only with colsum)
+#pragma unroll
+    for (int r = 0; r < 16; r++) part[r] = 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         uint32_t bits = 0xFFFFu;
@@ -1350,7 +1356,18 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
             }
             *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
             if (row && ok) *reinterpret_cast<float4*>(row + 8 * q) = v;
-            if (colsum && ok) { colsum[4 * q] += v.x; colsum[4 * q + 1] += v.y; colsum[4 * q + 2] += v.z; colsum[4 * q + 3] += v.w; }
+            if (colsum && ok) { part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w; }
+        }
+    }
+    if (colsum) {
+        // The 32 lanes of a half hold the same 16 features over different samples: one butterfly per call, then the feature's one owner adds it
+        // to the running sum in LDS.  (The sums used to live in 32 registers per lane for the whole kernel, most of its 488 bytes of scratch.)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = part[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (j == 0) colsum[32 * wave + 8 * (r >> 2) + 4 * half + (r & 3)] += v;
         }
     }
 }
@@ -1372,7 +1389,7 @@ __device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, 
 
 template <int NT>
 __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int wave, int lane,
-                                          float (&cs_hc1)[16], float (&cs_ha1)[16]) {
+                                          float* cs_hc1, float* cs_ha1 /* LDS [128] each */) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
     const bool tile_on = wave < NT;
@@ -1386,12 +1403,12 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     asm volatile("" : "+v"(lane16));
     const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
     floatx16 A[4];
-    WPipe wp;
+    WPipeT<kWAheadTrain> wp;
 #pragma unroll
-    for (int g = 0; g < kWAhead; g++) wp.q[g] = load_group(Ws, g, lane16);
+    for (int g = 0; g < kWAheadTrain; g++) wp.q[g] = load_group(Ws, g, lane16);
 
     // ---- colour tail: d z_c = d rgb * rgb (1 - rgb);  H row <- W_c2^T d z_c  (lane half h writes features 64h .. 64h+63)
-    float gh0 = 0.0f, gamb[2] = {0.0f, 0.0f}, ambv[2] = {0.0f, 0.0f};
+    float gh0 = 0.0f;
     if (tile_on) {
         float gz[3] = {0.0f, 0.0f, 0.0f};
         if (valid) {
@@ -1399,8 +1416,6 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
             for (int c = 0; c < 3; c++) { const float r = u.rgb[pt * 3 + c]; gz[c] = u.g_rgb[pt * 3 + c] * r * (1.0f - r); }
             const float sg = u.sigma[pt];
             gh0 = u.g_sigma[pt] * fminf(fmaxf(sg, 3.0590232e-7f), 3269017.37f);   // trunc_exp backward: g * exp(clamp(x, -15, 15))
-            gamb[0] = u.g_amb[pt * 2]; gamb[1] = u.g_amb[pt * 2 + 1];
-            ambv[0] = u.amb[pt * 2]; ambv[1] = u.amb[pt * 2 + 1];
             if (half == 0) { u.g_zc[pt * 3] = gz[0]; u.g_zc[pt * 3 + 1] = gz[1]; u.g_zc[pt * 3 + 2] = gz[2]; u.g_h0[pt] = gh0; }
         }
         if (half == 0) s.sdt[sI] = gh0;        // per-sample scalar the rank-1 term of the sigma layer reads by column
@@ -1454,8 +1469,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     bwd_store<NT, false>(Hw, nullptr, nullptr, gbase, Mv, wave, lane, A);
     __syncthreads();
     // ---- 2-D lookup: d f2 out, input gradient in; ambient tail: d z_a = (d amb + 0.5 d x2) (1 - amb^2);  H row <- W_a3^T d z_a
-    float gf3[16];
     if (tile_on) {
+        float gf3[16];   // d f3 of the sigma branch: parked in its final place in g_f3 until the ambient branch's share arrives (two layers on)
+        float gamb[2] = {0.0f, 0.0f}, ambv[2] = {0.0f, 0.0f};   // loaded here, not with the other per-point scalars: four registers less across four layers
+        if (valid) {
+            gamb[0] = u.g_amb[pt * 2]; gamb[1] = u.g_amb[pt * 2 + 1];
+            ambv[0] = u.amb[pt * 2]; ambv[1] = u.amb[pt * 2 + 1];
+        }
         float gf2[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1464,6 +1484,8 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
             gf2[4 * q] = v2.x; gf2[4 * q + 1] = v2.y; gf2[4 * q + 2] = v2.z; gf2[4 * q + 3] = v2.w;
         }
         if (valid) {   // [level][point][channel]: the layout gf_grid_encode_backward indexes (gridencoder.cu:275), no transpose on the host
+#pragma unroll
+            for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf3[2 * l], gf3[2 * l + 1]};
 #pragma unroll
             for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f2 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf2[2 * l], gf2[2 * l + 1]};
             if (u.lvl_max) {   // running per-level maxima of this workgroup (bit patterns of |g| order like the values; a NaN ends up on top)
@@ -1506,6 +1528,12 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     bwd_store<NT, false>(Hw, nullptr, nullptr, gbase, Mv, wave, lane, A);
     __syncthreads();
     if (tile_on && valid) {
+        float gf3[16];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {   // this lane's own store of two layers ago (same thread, same address: ordered)
+            const float2 p = *reinterpret_cast<const float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2);
+            gf3[2 * l] = p.x; gf3[2 * l + 1] = p.y;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float4 v = *reinterpret_cast<const float4*>(Hrow + 16 * half + 4 * q);
@@ -1538,9 +1566,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
     }
     if (tid < 32) s.hist[tid] = 0;   // [0..15] max |d f3| per level, [16..31] max |d f2| (visible behind the first round's barriers)
     const uint32_t chunks = (u.M + kPass - 1) / kPass;
-    float cs_hc1[16], cs_ha1[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) cs_hc1[r] = cs_ha1[r] = 0.0f;
+    float* cs_hc1 = s.sx;   // [128] column sums of d h_c1 / d h_a1 over this workgroup's points (-> gradients of the identity code and of
+    float* cs_ha1 = s.sy;   // cond_feat): the sample staging arrays are free in this kernel
+    if (tid < 128) { cs_hc1[tid] = 0.0f; cs_ha1[tid] = 0.0f; }
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
         __syncthreads();
         const uint32_t gbase = chunk * kPass;
@@ -1552,18 +1580,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
         else if (nt == 2) bwd_round<2>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
         else bwd_round<1>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
     }
-    // column sums (-> gradients of the identity code and of cond_feat): this lane's 16 features over its sample column, all rounds; the 32
-    // lanes of a half hold the same features -> one butterfly, then one atomic per feature and workgroup
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float vc = cs_hc1[r], va = cs_ha1[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { vc += __shfl_xor(vc, o); va += __shfl_xor(va, o); }
-        if ((lane & 31) == 0) {
-            const int feat = 32 * wave + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            atomicAdd(&u.s_hc1[feat], vc);
-            atomicAdd(&u.s_ha1[feat], va);
-        }
+    __syncthreads();
+    if (tid < 128) {   // one atomic per feature and workgroup
+        atomicAdd(&u.s_hc1[tid], cs_hc1[tid]);
+        atomicAdd(&u.s_ha1[tid], cs_ha1[tid]);
     }
     __syncthreads();
     if (u.lvl_max && tid < 32 && s.hist[tid]) atomicMax(&u.lvl_max[tid], s.hist[tid]);
