@@ -32,6 +32,27 @@ from .ckpt_utils import load_ckpt
 from .infer import FramePipeline, broadcast_model_, shard_range
 
 
+def load_background_image(path: str, H: int, W: int) -> np.ndarray:
+    """`infer_bg_img_fname` naming a file (tasks/radnerfs/dataset_utils.py:69-74): the picture as float32 RGB [H, W, 3] in [0, 1], resized to the
+    dataset's resolution when it differs (the reference: cv2.imread + INTER_AREA; here Pillow's box filter when shrinking -- the same area
+    average for integer factors -- and bilinear when enlarging).  Without Pillow only PNGs of exactly H x W written as 8-bit RGB load."""
+    try:
+        from PIL import Image
+    except ImportError:
+        from .png import decode_rgb8
+        with open(path, "rb") as fh:
+            img = decode_rgb8(fh.read())
+        if img.shape[:2] != (H, W):
+            raise ValueError(f"{path}: {img.shape[1]}x{img.shape[0]}, the dataset is {W}x{H} (resizing needs Pillow)")
+        return img.astype(np.float32) / 255.0
+    with Image.open(path) as im:
+        im = im.convert("RGB")
+        if im.size != (W, H):
+            shrink = im.size[0] >= W and im.size[1] >= H
+            im = im.resize((W, H), Image.BOX if shrink else Image.BILINEAR)
+        return np.asarray(im, dtype=np.float32) / 255.0
+
+
 class RADNeRFPoseSource:
     """What inference needs from `RADNeRFDataset('trainval', training=False)`: smoothed ngp poses, intrinsics, background,
     landmark statistics.  `ds_dict` is the dict stored in data/binary/videos/<id>/trainval_dataset.npy
@@ -50,7 +71,7 @@ class RADNeRFPoseSource:
         elif name == "black":
             bg = np.zeros((self.H, self.W, 3), dtype=np.float32)
         else:
-            raise NotImplementedError("infer_bg_img_fname: image files need cv2, which this image does not ship")
+            bg = load_background_image(name, self.H, self.W)
         self.bg_img = bg.reshape(-1, 3).astype(np.float32)
         self.idexp_lm3d_mean = np.asarray(ds_dict["idexp_lm3d_mean"], dtype=np.float32)
         self.idexp_lm3d_std = np.asarray(ds_dict["idexp_lm3d_std"], dtype=np.float32)

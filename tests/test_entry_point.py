@@ -32,7 +32,7 @@ def _ds_dict(T=9, H=64, W=64, seed=3):
             "idexp_lm3d_std": (1 + 0.1 * rng.random(size=(1, 68, 3))).astype(np.float32)}, ngp
 
 
-def test_pose_source_follows_dataset_init():
+def test_pose_source_follows_dataset_init(tmp_path):
     hp = HP.may_hparams(True)
     dd, ngp = _ds_dict()
     src = RADNeRFPoseSource(dd, hp)
@@ -48,6 +48,14 @@ def test_pose_source_follows_dataset_init():
     src2 = RADNeRFPoseSource(dd, hp2)
     assert float(src2.bg_img.min()) == 1.0
     np.testing.assert_allclose(src2.poses, raw, atol=1e-6)
+    # a background picture from a file (dataset_utils.py:69-74): same size as the dataset, and twice as large (area-averaged down)
+    from geneface_amd.png import encode_rgb8
+    pic = np.random.default_rng(3).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    (tmp_path / "bg.png").write_bytes(encode_rgb8(pic))
+    (tmp_path / "bg2x.png").write_bytes(encode_rgb8(np.repeat(np.repeat(pic, 2, axis=0), 2, axis=1)))
+    for name in ("bg.png", "bg2x.png"):
+        src3 = RADNeRFPoseSource(dd, dict(hp, infer_bg_img_fname=str(tmp_path / name)))
+        assert src3.bg_img.dtype == np.float32 and np.array_equal(np.round(src3.bg_img * 255).astype(np.uint8).reshape(64, 64, 3), pic), name
 
 
 def test_cond_from_input_and_pose_lookup(tmp_path):
