@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, head-kernel timeline, rocprofv3 kernel stats, PMC passes.
-# usage: tools/gpu_round.sh <tag> [steps...]   (steps: test bench trace prof pmc; default all)
+# usage: tools/gpu_round.sh <tag> [steps...]   (steps: test bench benchfast trace prof pmc train clock ab:<variant> abm:<v1>,<v2>; default: test bench trace prof pmc)
 set -u
 TAG=${1:-r1}; shift || true
 STEPS=${*:-test bench trace prof pmc}
@@ -30,6 +30,12 @@ for s in $STEPS; do
                GF_HIP_LIB=$L timeout 300 python bench.py --steps 60 --warmup 10 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('AB lib=%-10s fps=%.1f frac=%.4f kernel_ms=%.4f' % ('${lib:-base}', d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_frame']))" | tee -a $OUT/abm.txt
              done
            done ;;
+    train) # training tier: step rate (fused Adam), the same with AMP, and the per-kernel profile of the fp32 step
+           timeout 300 python tools/bench_train.py 2>/dev/null | tail -1 > $OUT/bench_train.json; cut -c1-200 $OUT/bench_train.json
+           timeout 300 python tools/bench_train.py --amp 2>/dev/null | tail -1 > $OUT/bench_train_amp.json; cut -c1-200 $OUT/bench_train_amp.json
+           (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_train -o k --output-format csv -- python $REPO/tools/bench_train.py --steps 32 --warmup 16 > $OUT/prof_train.log 2>&1); head -8 $OUT/prof_train/k_kernel_stats.csv | cut -c1-160 ;;
+    clock) # shader clock inside the head kernel vs a steady MFMA probe, with the firmware's view (amd-smi)
+           timeout 300 bash tools/clock_probe.sh $TAG/clock 8000 2>&1 | tail -30 ;;
     trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     tracev:*) V=${s#tracev:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 300 python tools/trace_head.py > $OUT/trace_$V.txt 2>&1; grep -E "phase ms|lifetime|round =" $OUT/trace_$V.txt ;;
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
