@@ -42,7 +42,14 @@ def _torch_load(path):
         allow += [type(np.dtype(t)) for t in ("float64", "float32", "int64")]
         with torch.serialization.safe_globals(allow):
             return torch.load(path, map_location="cpu", weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError, AttributeError):
+    except (pickle.UnpicklingError, RuntimeError, AttributeError) as e:
+        # The full unpickler can execute code: say that it is about to run, and why the restricted load refused the file (the message names
+        # the global it blocked).  GENEFACE_AMD_SAFE_LOAD_ONLY=1 turns the fallback off for deployments that load third-party files.
+        if os.environ.get("GENEFACE_AMD_SAFE_LOAD_ONLY", "") not in ("", "0"):
+            raise RuntimeError(f"{path}: the restricted unpickler refused this checkpoint and GENEFACE_AMD_SAFE_LOAD_ONLY is set: {e}") from e
+        import warnings
+        warnings.warn(f"{path}: restricted checkpoint load failed ({str(e).splitlines()[0][:200]}); falling back to the full unpickler, as the "
+                      f"reference does (utils/commons/ckpt_utils.py:13) -- load only checkpoints you trust", RuntimeWarning, stacklevel=2)
         return torch.load(path, map_location="cpu", weights_only=False)
 
 

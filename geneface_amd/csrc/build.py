@@ -22,12 +22,16 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch=
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 
 
-# Per-file flags.  frame_head.hip is built WITHOUT the SLP vectoriser, i.e. without packed-FP32 VALU instructions (v_pk_fma_f32 /
-# v_pk_mul_f32): in k_head_phase<true> the low half of one v_pk_fma_f32 of the 2-D grid lookup -- the one fed by a broadcast-form
+# EVERY translation unit is built WITHOUT the SLP vectoriser, i.e. without packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 /
+# v_pk_add_f32).  In k_head_phase<true> the low half of one v_pk_fma_f32 of the 2-D grid lookup -- the one fed by a broadcast-form
 # v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,1] -- intermittently lost its product in lanes 32..63 whenever two workgroups shared a CU
-# (tools/fast_diag.py).  Scalar FMAs compute the same values (the packed form was only ever two independent FMAs) at the
-# same measured frame rate (fp32 719 vs 717 fps, fast tier 1890 vs 1845 fps, interleaved A/B on one box).
-PER_FILE = {"frame_head.hip": ("-fno-slp-vectorize",)}
+# (tools/fast_diag.py).  The mechanism is not established, so since round 3 the instruction class is banned from the whole
+# library, not just from the kernel it was caught in (encoders.hip's k_encode8<2> held two instances of exactly that pair):
+# tests/test_build_invariants.py disassembles every code object and asserts the count is zero.  Scalar FMAs compute the same values (the
+# packed form was only ever two independent FMAs); measured cost: head fp32 719 vs 717 fps, fast tier 1890 vs 1845 fps (round 2, A/B on
+# one box), stand-alone ops and the training step within noise (round 3, profiles/round3/).
+COMMON.append("-fno-slp-vectorize")
+PER_FILE = {}
 
 
 def sources():
@@ -77,5 +81,5 @@ def build(force: bool = False, verbose: bool = False, trace: bool = False, varia
 
 if __name__ == "__main__":
     _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
-    _defs = tuple(a for a in sys.argv[1:] if a.startswith("-D"))
+    _defs = tuple(a for a in sys.argv[1:] if a.startswith(("-D", "-f")))   # e.g. --variant slp -fslp-vectorize for an A/B library
     print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, variant=_variant, defines=_defs))

@@ -20,6 +20,17 @@ int gf_check_launch(const char* what) {
     return GF_OK;
 }
 
+int gf_raise_lds_limit(GfLdsAttr& st, const void* fn, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gf_set_error(GF_ERR_HIP, "%s: hipGetDevice failed", what);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&st.done, __ATOMIC_ACQUIRE) & bit) return GF_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return gf_set_error(GF_ERR_HIP, "%s: cannot raise the dynamic LDS limit to %d bytes on device %d", what, bytes, dev);
+    __atomic_fetch_or(&st.done, bit, __ATOMIC_RELEASE);
+    return GF_OK;
+}
+
 GF_EXPORT const char* gf_last_error(void) { return g_last_error; }
 
 GF_EXPORT const char* gf_version(void) { return "geneface_hip 0.1 (gfx950)"; }

@@ -15,6 +15,10 @@ enum {
 
 int gf_set_error(int code, const char* fmt, ...);
 int gf_check_launch(const char* what);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to ONE device: remembered per call site and per device, so a process that
+// drives several GPUs raises the limit on each of them (a bit per device ordinal).
+struct GfLdsAttr { unsigned long long done = 0; };
+int gf_raise_lds_limit(GfLdsAttr& st, const void* fn, int bytes, const char* what);
 
 static inline hipStream_t gf_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -69,8 +69,17 @@ __device__ void conv1d_k3(const float* __restrict__ w /*LDS*/, const float* __re
     }
 }
 
-__global__ void __launch_bounds__(kThreads) k_cond_encode(const gf_cond_t a) {
+// One workgroup per frame: workgroup k serves frame k of a batch whose windows, poses and outputs are stacked along the leading axis
+// (gf_cond_encode_batch; gf_cond_encode is the batch of one).  A frame's arithmetic does not depend on the batch it is part of.
+__global__ void __launch_bounds__(kThreads) k_cond_encode(gf_cond_t a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    {
+        const size_t k = blockIdx.x;
+        a.cond += k * a.S * a.T * a.C;
+        a.cond_feat += k * a.dim_aud;
+        if (a.amb_bias) a.amb_bias += k * 128;
+        if (a.torso_bias) { a.torso_bias += k * 96; a.pose6 += k * 6; }
+    }
     float* wbuf = reinterpret_cast<float*>(smem_raw);
     float* act0 = wbuf + kWFloats;
     float* act1 = act0 + kActFloats;
@@ -215,20 +224,22 @@ GF_EXPORT int gf_cond_check(const gf_cond_t* c) {
 
 // cond [S, T, C] -> cond_feat [dim_aud] (= RADNeRF.cal_cond_feat with with_att, radnerf.py:61-71) and, when the output pointers
 // are given, the folded first-layer biases of the fused field kernels.  Enqueues one launch on `stream`.
-GF_EXPORT int gf_cond_encode(const gf_cond_t* c, void* stream) {
+GF_EXPORT int gf_cond_encode(const gf_cond_t* c, void* stream) { return gf_cond_encode_batch(c, 1, stream); }
+
+// The same for n_frames frames in ONE launch (one workgroup per frame): cond [n, S, T, C], pose6 [n, 6] -> cond_feat [n, dim_aud],
+// amb_bias [n, 128], torso_bias [n, 96].  Row k is bit-identical to what gf_cond_encode writes for frame k alone.  The frame loop calls it
+// once per pass over its shard (all landmark windows are resident before the loop), so no frame waits for its own 70 us single-workgroup launch.
+GF_EXPORT int gf_cond_encode_batch(const gf_cond_t* c, uint32_t n_frames, void* stream) {
     if (!c || !c->cond || !c->cond_feat) return gf_set_error(GF_ERR_INVALID, "cond_encode: null pointer");
+    if (n_frames == 0) return GF_OK;
     const int rc = gf_cond_check(c);
     if (rc) return rc;
     if (c->amb_bias && !c->W_cond) return gf_set_error(GF_ERR_INVALID, "cond_encode: amb_bias needs W_cond");
     if (c->torso_bias && (!c->W_tconst || !c->pose6 || (c->code_dim && !c->torso_code)))
         return gf_set_error(GF_ERR_INVALID, "cond_encode: torso_bias needs W_tconst, pose6 and the identity code");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_cond_encode), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "cond_encode: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_cond_encode, dim3(1), dim3(kThreads), kSmemBytes, gf_stream(stream), *c);
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_cond_encode), kSmemBytes, "cond_encode")) return e;
+    hipLaunchKernelGGL(k_cond_encode, dim3(n_frames), dim3(kThreads), kSmemBytes, gf_stream(stream), *c);
     return gf_check_launch("cond_encode");
 }
 

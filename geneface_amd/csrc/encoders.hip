@@ -165,13 +165,20 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
 // A level too large for kGbMaxParts partitions (log2_hashmap_size > 17 at C = 2) falls back to direct global atomics.
 // Round 2: the LDS accumulators are 64-bit FIXED POINT.  tools/lds_atomic_probe.hip: ds_add_f32 retires 0.38 adds per clock and CU on gfx950
 // (exactly the rate the float version of this kernel ran at), ds_add_u32 11.6 and ds_add_u64 6.7 -- the float atomic is ~20x slower than the
-// integer ones.  Every contribution w * g is scaled by 2^30 / max|g| of its level (k_grid_absmax, one pass over the gradient), rounded to an
-// int32 and added as int64: no overflow below 2^33 contributions per entry, a quantum of 1e-9 of the level's largest gradient (below the
-// fp32 running sum's own rounding), and -- integer adds commute -- a table partial that no longer depends on the order the points arrive in.
+// integer ones.  Every contribution w * g is scaled by 2^40 / max|g| of its level (k_grid_absmax, one pass over the gradient), rounded and
+// added as int64: no overflow below 2^23 full-size contributions per entry, a quantum of 9e-13 of the level's largest gradient, and -- integer
+// adds commute -- a table partial that does not depend on the order the points arrive in.  Round 3: the scale was 2^30 with int32 rounding, which
+// turned every contribution below 5e-10 of the level's maximum into an exact zero; the reference trains these tables with Adam eps = 1e-15
+// (tasks/radnerfs/radnerf.py:63) precisely so that rarely-hit entries with tiny gradients still take full-size steps.  Now a contribution
+// below 2^14 quanta (1.5e-8 of the maximum) goes to the table as a float atomic instead, so every entry keeps fp32 RELATIVE accuracy over
+// the whole dynamic range (tests/test_gpu_train.py::test_grid_backward_keeps_tiny_gradients: 14 decades against an fp64 scatter).
 constexpr uint32_t kGbThreads = 1024;
 constexpr uint32_t kGbLdsEntries = 16384;   // int64 accumulators: 128 KiB, one workgroup per CU
 constexpr uint32_t kGbMaxParts = 8;
-constexpr float kGbFixedOne = 1073741824.0f;   // 2^30
+constexpr float kGbFixedOne = 1099511627776.0f;   // 2^40: one quantum = 9e-13 of the level's largest gradient; 2^23 contributions of full size fit an int64
+constexpr float kGbSmall = 16384.0f;              // contributions below 2^14 quanta (1.5e-8 of the largest gradient) would lose more than 2^-15 of their
+                                                  // value to the rounding: they take a float atomic into the table instead (rare; keeps every entry's
+                                                  // RELATIVE accuracy, which is what Adam with eps = 1e-15 -- tasks/radnerfs/radnerf.py:63 -- steps by)
 
 // per-level max |grad| (bit pattern of a non-negative float orders like the uint): lvl_max[L] zeroed by the caller
 template <uint32_t C>
@@ -222,7 +229,7 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
             any |= g[c] != 0.0f;
         }
         if (!any) continue;                                        // samples behind a ray's termination point carry exact zeros
-        float gs[C];                                               // in fixed-point units (|gs| <= 2^30)
+        float gs[C];                                               // in fixed-point units (|gs| <= 2^40)
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) gs[c] = DIRECT ? g[c] : g[c] * to_fixed;
         float pos[D];
@@ -275,8 +282,11 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
                     for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(table + (size_t)row * C + c, w * gs[c]);
                 } else {
 #pragma unroll
-                    for (uint32_t c = 0; c < C; c++)
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&tab[r * C + c]), (unsigned long long)(long long)__float2int_rn(w * gs[c]));
+                    for (uint32_t c = 0; c < C; c++) {
+                        const float v = w * gs[c];
+                        if (fabsf(v) >= kGbSmall) atomicAdd(reinterpret_cast<unsigned long long*>(&tab[r * C + c]), (unsigned long long)__float2ll_rn(v));
+                        else if (g[c] != 0.0f) unsafeAtomicAdd(table + (size_t)row * C + c, w * g[c]);
+                    }
                 }
             }
         }
@@ -296,8 +306,9 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
             unsafeAtomicAdd(grad_grid + (size_t)offsets[level] * C, __uint_as_float(0x7fc00000u));
         return;
     }
-    if (!(gmax > 1e-30f)) return;                                  // an all-zero gradient level adds nothing (nor does one below 1e-30: 2^30 / gmax must stay finite)
-    const float to_fixed = kGbFixedOne / gmax;
+    if (!(gmax > 0.0f)) return;                                    // an all-zero gradient level adds nothing
+    // 2^40 / gmax must stay finite: a level whose largest gradient is below 1e-25 scatters through the float path alone (to_fixed = 0)
+    const float to_fixed = gmax > 1e-25f ? kGbFixedOne / gmax : 0.0f;
     const double from_fixed = (double)gmax / (double)kGbFixedOne;
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;

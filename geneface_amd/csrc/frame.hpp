@@ -25,6 +25,8 @@ constexpr uint32_t kCtrlSamples = 4;   // [2] field evaluations per phase
 constexpr uint32_t kCtrlRounds = 6;    // [2] workgroup rounds per phase
 constexpr uint32_t kCtrlTiles = 8;     // [2] 32-sample MFMA tiles executed per phase
 constexpr uint32_t kCtrlBudget = 10;   // total per-ray sample budget B the reference's n_step schedule arrives at
+constexpr uint32_t kCtrlComposited = 12;   // [2] samples the compositor consumed per phase (<= kCtrlSamples: a ray that terminates inside a round
+                                          //     leaves the rest of its slots of that round evaluated but unused)
 constexpr uint32_t kCtrlHist = 16;     // [kMaxSteps + 2] rays that terminate at cumulative sample index d (d = 1 .. max_steps)
 constexpr uint32_t kCtrlWords = 128;
 

@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
     }
     if (tid < kHistBins) s.hist[tid] = 0;
+    if (tid == 0) s.misc[9] = 0;     // samples composited by this workgroup (statistics)
 
     // pooled ray of this lane (owners only): everything the marcher and the compositor carry between rounds
     int ray = -1;
@@ -1136,6 +1137,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             }
             const bool finished = !died && r_done == budget;
             if (died || finished) {
+                atomicAdd(&s.misc[9], r_done);   // statistics: what this ray's compositor consumed in this phase
                 a.weights_sum[ray] = acc.weight_sum;
                 a.depth[ray] = acc.depth;
                 a.image[(size_t)ray * 3 + 0] = acc.r; a.image[(size_t)ray * 3 + 1] = acc.g; a.image[(size_t)ray * 3 + 2] = acc.b;
@@ -1183,6 +1185,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], st_samples);
         atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], st_rounds);
         atomicAdd(&a.ctrl[gf::kCtrlTiles + a.phase], st_tiles);
+        atomicAdd(&a.ctrl[gf::kCtrlComposited + a.phase], s.misc[9]);
     }
 }
 
@@ -1697,7 +1700,7 @@ int check_frame(const gf_frame_t* f) {
     return GF_OK;
 }
 
-int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 4 events around the two phase kernels */) {
+int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 6 events around the two phase kernels (0..3) and k_frame_init (4, 5) */) {
     const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
     const uint32_t N = f->n_rays;
     if (hipMemsetAsync(w.ctrl, 0, gf::kCtrlWords * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "frame: hipMemsetAsync failed");
@@ -1721,7 +1724,9 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     }
     ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.far_occ = w.far_occ; ia.rays_t = w.rays_t;
     ia.weights_sum = w.weights_sum; ia.depth = w.depth; ia.image = w.image; ia.hit_list = w.alive_b; ia.ctrl = w.ctrl; ia.N = N;
+    if (ev) (void)hipEventRecord(ev[4], s);
     hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, 256u)), dim3(256), 0, s, ia);
+    if (ev) (void)hipEventRecord(ev[5], s);
 
     HeadArgs ha;
     ha.mp = ia.mp;
@@ -1749,12 +1754,10 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
 
     const bool fast = f->precision == 1;
     ha.head_pack16 = f->head_pack16;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[fast]) {
+    static GfLdsAttr lds[2];
+    {
         const void* fn = fast ? reinterpret_cast<const void*>(k_head_phase<true>) : reinterpret_cast<const void*>(k_head_phase<false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "frame: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set[fast] = true;
+        if (const int e = gf_raise_lds_limit(lds[fast], fn, kSmemBytes, "frame")) return e;
     }
     // persistent grid: 2 workgroups per CU x 256 CUs, never more workgroups than pools' worth of rays
     const uint32_t pools = gf_div_up(N, (uint32_t)kPool);
@@ -1827,12 +1830,8 @@ GF_EXPORT int gf_grid_density(const gf_frame_t* f, const float* noise_or_null, f
     ha.head_pack = f->head_pack; ha.amb_bias = f->amb_bias;
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     GridArgs ga = {noise_or_null, tmp_grid, f->cascade, f->grid_size, density_scale};
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_density), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "grid_density: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set = true;
-    }
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_grid_density), kSmemBytes, "grid_density")) return e;
     const uint64_t total = (uint64_t)f->cascade * f->grid_size * f->grid_size * f->grid_size;
     if (total >= (1ull << 32)) return gf_set_error(GF_ERR_UNSUPPORTED, "grid_density: more than 2^32 cells");
     const uint32_t chunks = (uint32_t)((total + kPass - 1) / kPass);
@@ -1863,13 +1862,9 @@ static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float
         pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1,
                  saves->m_ha1, saves->m_ha2, saves->m_hs1, saves->m_hs2, saves->m_hc1, saves->sh};
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_points<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "field_forward: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set = true;
-    }
+    static GfLdsAttr lds[2];
+    if (const int e = gf_raise_lds_limit(lds[0], reinterpret_cast<const void*>(k_field_points<false>), kSmemBytes, "field_forward")) return e;
+    if (const int e = gf_raise_lds_limit(lds[1], reinterpret_cast<const void*>(k_field_points<true>), kSmemBytes, "field_forward")) return e;
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
     const dim3 grid(chunks < 512u ? chunks : 512u);
     if (saves) hipLaunchKernelGGL(k_field_points<true>, grid, dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
@@ -1911,12 +1906,8 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     BwdArgs ba = {bwd_stream, g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1,
                   g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1, g->level_max, M};
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_field_backward), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "field_backward: cannot raise the dynamic LDS limit to %d bytes", kSmemBytes);
-        attr_set = true;
-    }
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_field_backward), kSmemBytes, "field_backward")) return e;
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
     hipLaunchKernelGGL(k_field_backward, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
     return gf_check_launch("field_backward");
@@ -1958,11 +1949,12 @@ GF_EXPORT int gf_render_head(const gf_frame_t* f, void* stream) {
 }
 
 // Same work as gf_render_head's two field kernels, bracketed by HIP events on `stream`; synchronises, then reports
-// their durations (ms): phase_ms_host[0] = first max_steps samples, [1] = the remaining B - max_steps.  Measurement only.
+// their durations (ms): phase_ms_host[0] = first max_steps samples, [1] = the remaining B - max_steps, [2] = k_frame_init (the marcher's
+// empty-space walk; north_star asks for its rate).  phase_ms_host has room for 4 floats.  Measurement only.
 GF_EXPORT int gf_render_head_timed(const gf_frame_t* f, void* stream, float* phase_ms_host, uint32_t* n_phases_host) {
     int rc = check_frame(f);
     if (rc) return rc;
-    static hipEvent_t ev[4];
+    static hipEvent_t ev[6];
     static bool made = false;
     if (!made) {
         for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return gf_set_error(GF_ERR_HIP, "hipEventCreate failed");
@@ -1972,11 +1964,11 @@ GF_EXPORT int gf_render_head_timed(const gf_frame_t* f, void* stream, float* pha
     rc = launch_head(f, s, ev);
     if (rc) return rc;
     if (hipStreamSynchronize(s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "hipStreamSynchronize failed");
-    for (uint32_t i = 0; i < 2; i++) {
+    for (uint32_t i = 0; i < 3; i++) {
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
         phase_ms_host[i] = ms;
     }
-    *n_phases_host = 2;
+    *n_phases_host = 3;
     return GF_OK;
 }

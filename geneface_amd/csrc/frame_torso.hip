@@ -184,12 +184,8 @@ GF_EXPORT int gf_render_torso(const gf_frame_t* f, void* stream) {
     if (gf::fill_grid_levels(a.lv, 16, f->torso_S, f->base_res)) return gf_set_error(GF_ERR_INVALID, "torso: bad grid levels");
     a.out_rgb = f->out_rgb; a.out_depth = f->out_depth; a.out_alpha = f->out_torso_alpha; a.out_torso_rgb = f->out_torso_rgb;
     a.out_deform = f->out_deform; a.out_rgb8 = f->out_rgb8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_torso_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTorsoSmem) != hipSuccess)
-            return gf_set_error(GF_ERR_HIP, "torso: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_torso_finish), (int)kTorsoSmem, "torso")) return e;
     hipLaunchKernelGGL(k_torso_finish, dim3(gf_div_up(f->n_rays, (uint32_t)kThreads)), dim3(kThreads), kTorsoSmem, gf_stream(stream), a);
     return gf_check_launch("render_torso");
 }

@@ -380,24 +380,37 @@ def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_al
     f.out_deform = ptr(out_deform) if out_deform is not None else None
 
 
+def cond_encode_batch(model, st, cond_wins, poses6=None):
+    """gf_cond_encode_batch: the condition encoder + both bias folds for n frames in ONE launch on the current stream.
+    cond_wins [n, S, T, C] fp32 contiguous, poses6 [n, 6] or None -> (cond_feat [n, A], amb_bias [n, 128], torso_bias [n, 96] or None);
+    row k is bit-identical to the single-frame launch on frame k.  None when the encoder is not the AudioNet + AudioAttNet pair the kernel
+    implements (or the window is outside its limits): the caller then uses the torch modules."""
+    c = st.cond
+    if c is None or cond_wins.dim() != 4 or tuple(cond_wins.shape[1:]) != (c.S, c.T, c.C) or cond_wins.dtype != torch.float32 \
+            or not cond_wins.is_contiguous():
+        return None
+    n, dev = cond_wins.shape[0], cond_wins.device
+    cond_feat = torch.empty(n, c.dim_aud, dtype=torch.float32, device=dev)
+    amb_bias = torch.empty(n, 128, dtype=torch.float32, device=dev)
+    torso_bias = torch.empty(n, 96, dtype=torch.float32, device=dev) if poses6 is not None else None
+    call = GfCond.from_buffer_copy(c)
+    call.cond, call.cond_feat, call.amb_bias = ptr(cond_wins), ptr(cond_feat), ptr(amb_bias)
+    if poses6 is not None:
+        p6 = poses6.reshape(n, 6).float().contiguous()
+        call.pose6, call.torso_bias = ptr(p6), ptr(torso_bias)
+    else:
+        call.torso_bias = None
+    check(lib().gf_cond_encode_batch(C.byref(call), n, current_stream(dev)))
+    return cond_feat, amb_bias, torso_bias
+
+
 def _per_frame_vectors(model, st, cond, poses6=None):
     """cond encoder + the per-frame bias folds: one HIP launch (gf_cond_encode) on the current stream; the torch modules only
     when the encoder is not the AudioNet + AudioAttNet pair (or the window shape is outside the kernel's limits)."""
-    c = st.cond
-    if c is not None and tuple(cond.shape) == (c.S, c.T, c.C) and cond.dtype == torch.float32 and cond.is_contiguous():
-        dev = cond.device
-        cond_feat = torch.empty(c.dim_aud, dtype=torch.float32, device=dev)
-        amb_bias = torch.empty(128, dtype=torch.float32, device=dev)
-        torso_bias = torch.empty(96, dtype=torch.float32, device=dev) if poses6 is not None else None
-        call = GfCond.from_buffer_copy(c)
-        call.cond, call.cond_feat, call.amb_bias = ptr(cond), ptr(cond_feat), ptr(amb_bias)
-        if poses6 is not None:
-            p6 = poses6.reshape(-1).float().contiguous()
-            call.pose6, call.torso_bias = ptr(p6), ptr(torso_bias)
-        else:
-            call.torso_bias = None
-        check(lib().gf_cond_encode(C.byref(call), current_stream(dev)))
-        return cond_feat, amb_bias, torso_bias
+    if cond.dim() == 3:
+        r = cond_encode_batch(model, st, cond[None], poses6)
+        if r is not None:
+            return r[0][0], r[1][0], (r[2][0] if r[2] is not None else None)
     cond_feat = model.cal_cond_feat(cond).reshape(-1).float()
     amb_bias = torch.mv(st.W_cond, cond_feat)
     torso_bias = None
@@ -522,7 +535,8 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
         sched.append((n_alive, n_step))
         cum += n_step
     return {"schedule": sched, "budget": cum, "budget_device": int(c[10]), "n_hit": int(c[1]), "n_survivors": int(c[2]),
-            "samples": (int(c[4]), int(c[5])), "rounds": (int(c[6]), int(c[7])), "tiles": (int(c[8]), int(c[9]))}
+            "samples": (int(c[4]), int(c[5])), "rounds": (int(c[6]), int(c[7])), "tiles": (int(c[8]), int(c[9])),
+            "composited": (int(c[12]), int(c[13]))}
 
 
 # --------------------------------------------------------------------------------------------- frame-loop step
@@ -547,7 +561,11 @@ def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
         bufs = pipe._fused_bufs = _PipeBuffers(pipe)
     N = pipe.H * pipe.W
     torso = st.has_torso
-    _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
+    pre = pipe.prepared(i) if hasattr(pipe, "prepared") else None
+    if pre is not None:          # the pass's batched launch (FramePipeline.prepare) already holds this frame's vectors
+        amb_bias, torso_bias = pre
+    else:
+        _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
     _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], hp.get("T_thresh", 1e-4), amb_bias, bufs.bg, bufs.rgb[slot], bufs.depth[slot],
                  rgb8, slot)   # the reference forwards **hparams to render(): a T_thresh key overrides the 1e-4 default (renderer.py:263)
     f.img_h, f.img_w = pipe.H, pipe.W
@@ -586,7 +604,8 @@ def profile_frames(pipe, first, n_frames, flop_per_sample, peak_tflops):
     that time."""
     phase_ms = (C.c_float * 4)()
     n_ph = C.c_uint32(0)
-    tot_ms, tot_samples, launches, per_frame = 0.0, 0, 0, []
+    tot_ms, tot_samples, tot_comp, launches, per_frame = 0.0, 0, 0, 0, []
+    init_ms, hit_rays = 0.0, 0
     N = pipe.H * pipe.W
     with torch.no_grad():
         for i in range(first, first + n_frames):
@@ -598,14 +617,20 @@ def profile_frames(pipe, first, n_frames, flop_per_sample, peak_tflops):
             samples = fs["samples"][0] + fs["samples"][1]
             tot_ms += ms
             tot_samples += samples
+            tot_comp += fs["composited"][0] + fs["composited"][1]
+            init_ms += phase_ms[2]
+            hit_rays += fs["n_hit"]
             launches += 2
-            per_frame.append({"phase_ms": [round(phase_ms[0], 4), round(phase_ms[1], 4)], "samples": list(fs["samples"]),
-                              "tiles": list(fs["tiles"]), "rounds": list(fs["rounds"]), "budget": fs["budget_device"],
+            per_frame.append({"phase_ms": [round(phase_ms[0], 4), round(phase_ms[1], 4)], "init_ms": round(phase_ms[2], 4), "samples": list(fs["samples"]),
+                              "composited": list(fs["composited"]), "tiles": list(fs["tiles"]), "rounds": list(fs["rounds"]), "budget": fs["budget_device"],
                               "reference_schedule": fs["schedule"], "n_hit": fs["n_hit"], "n_survivors": fs["n_survivors"]})
     achieved = tot_samples * flop_per_sample / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     tiles = sum(sum(p["tiles"]) for p in per_frame)
+    nf = max(n_frames, 1)
     return {"bound": "mfma", "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved / peak_tflops,
             "traffic": None, "kernel": "k_head_phase (march + field + composite; 2 launches per frame)",
-            "launches": launches, "avg_launch_ms": tot_ms / max(launches, 1), "kernel_ms_per_frame": tot_ms / max(n_frames, 1),
-            "samples_per_frame": tot_samples / max(n_frames, 1), "tile_fill": tot_samples / max(32 * tiles, 1),
-            "flop_per_sample": flop_per_sample, "frames_profiled": n_frames, "example_frame": per_frame[0] if per_frame else None}
+            "launches": launches, "avg_launch_ms": tot_ms / max(launches, 1), "kernel_ms_per_frame": tot_ms / nf,
+            "samples_per_frame": tot_samples / nf, "samples_composited_per_frame": tot_comp / nf, "tile_fill": tot_samples / max(32 * tiles, 1),
+            "flop_per_sample": flop_per_sample, "frames_profiled": n_frames, "example_frame": per_frame[0] if per_frame else None,
+            "marcher": {"kernel": "k_frame_init (ray generation, slab tests, the march through empty space to the first occupied sample; 1 launch per frame)",
+                        "ms": init_ms / nf, "rays": N, "hit_rays": hit_rays / nf}}

@@ -112,6 +112,48 @@ class FramePipeline:
     def __len__(self):
         return len(self.frame_ids)
 
+    # ---- per-pass batched condition encoder (fused path): cal_cond_feat of tasks/radnerfs/radnerf.py:119-128 for a block of frames at once
+    def prepare(self, first: int, stop: int):
+        """Encode the landmark windows of frames [first, stop) of this shard in ONE launch (gf_cond_encode_batch) and keep the per-frame
+        vectors the frame kernels read (amb_bias [n,128], torso_bias [n,96]).  render_frame(i) then skips its own single-workgroup
+        encoder launch (70 us alone, 0.6 ms beside four persistent head grids, and on the critical path of the frame's stream).  Same
+        bytes either way (tests/test_gpu_render.py::test_prepared_pass_is_bit_identical).  No-op for the op-by-op path."""
+        self._pre = None
+        if self.impl != "fused" or self.device.type != "cuda" or stop <= first:
+            return
+        from .fused import cond_encode_batch, get_state
+        st = get_state(self.model)
+        if getattr(self, "_prep_stream", None) is None:
+            self._prep_stream = torch.cuda.Stream(self.device)
+        ps = self._prep_stream
+        ps.wait_stream(torch.cuda.current_stream(self.device))
+        for fs in self._streams:          # frames of the previous pass may still be reading the rows this launch's buffers replace
+            ps.wait_stream(fs)
+        with torch.cuda.stream(ps), torch.no_grad():
+            r = cond_encode_batch(self.model, st, self.cond_wins[first:stop], self.pose6[first:stop] if st.has_torso else None)
+            if r is None:
+                return                     # an encoder the kernel does not implement: every frame runs the torch modules as before
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": r[2], "stamp": st.stamp, "event": ev, "waited": set()}
+
+    def prepared(self, i: int):
+        """(amb_bias [128], torso_bias [96] or None) of frame i from the current pass's batched launch, or None.  Called on the frame's
+        stream, which is made to wait for the batch once."""
+        pre = getattr(self, "_pre", None)
+        if pre is None or not (pre["first"] <= i < pre["stop"]):
+            return None
+        from .fused import get_state
+        if get_state(self.model).stamp != pre["stamp"]:      # the weights changed since the batch was encoded
+            self._pre = None
+            return None
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream not in pre["waited"]:
+            cur.wait_event(pre["event"])
+            pre["waited"].add(cur.cuda_stream)
+        k = i - pre["first"]
+        return pre["amb"][k], (pre["torso"][k] if pre["torso"] is not None else None)
+
     def sample(self, i: int) -> dict:
         """The `sample` dict tasks/radnerfs/radnerf.py:119-126 reads (rays materialised, like the reference's dataset)."""
         rays = utils.get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
@@ -170,6 +212,9 @@ class FramePipeline:
         host memory, while the following frames are already enqueued.  The view is only valid until the next iteration (the slot is
         reused): consumers copy it or hand it to an encoder that does (png.FrameWriter.submit)."""
         pending = []
+        indices = list(indices)
+        if indices and indices == list(range(indices[0], indices[-1] + 1)) and self.prepared(indices[0]) is None:
+            self.prepare(indices[0], indices[-1] + 1)      # every window of the block is resident: one encoder launch for all of them
         for i in indices:
             buf = self.render_frame(i)
             pending.append((i, buf, self._events[(self._slot - 1) % self._depth]))

@@ -214,7 +214,8 @@ class LM3d_RADNeRFInfer:
     # ------------------------------------------------------------------ frame loop (base_nerf_infer.py:81-193)
     def forward_system(self, batches, world_size: int = None, tmp_imgs_dir: str = None, collect: bool = True):
         """base_nerf_infer.py:182-193.  Three ways in, one block partition (:150-155):
-          * a process group already exists (torchrun): this process renders ITS block and returns it;
+          * a process group already exists (torchrun): this process renders ITS block; rank 0 returns the whole sequence (the blocks are
+            gathered through per-rank files, as in the spawn path), the other ranks their own block;
           * `world_size` (default: the number of GPU ids in CUDA_VISIBLE_DEVICES) > 1: spawn one process per GPU, each renders and
             writes its block, the parent returns the concatenated frames (collect=True) or the image directory, like the reference;
           * otherwise: this process renders everything.
@@ -222,11 +223,28 @@ class LM3d_RADNeRFInfer:
         import torch.distributed as dist
         tmp_imgs_dir = tmp_imgs_dir if tmp_imgs_dir is not None else getattr(self, "inp", {}).get("tmp_imgs_dir")
         if dist.is_available() and dist.is_initialized():
-            self.proc_rank = dist.get_rank()
-            _, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, self.proc_rank, dist.get_world_size(),
-                                   tmp_imgs_dir, self.pipeline_cls, collect)
+            self.proc_rank, world = dist.get_rank(), dist.get_world_size()
+            lo, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, self.proc_rank, world,
+                                    tmp_imgs_dir, self.pipeline_cls, collect)
+            if not collect or world == 1:
+                dist.barrier()
+                return out if collect else tmp_imgs_dir
+            # Same contract as the spawn path: rank 0 gets the WHOLE sequence back (it is the rank that post-processes, base_nerf_infer.py:267).
+            # One node by design, so the blocks travel as .npy files in a directory rank 0 names (no pickling of 300 MB blocks through the
+            # collective layer); the other ranks return their own block.
+            import shutil
+            import tempfile
+            box = [tempfile.mkdtemp(prefix="gf_blocks_") if self.proc_rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            np.save(os.path.join(box[0], f"block_{lo:07d}.npy"), out)
             dist.barrier()
-            return out if collect else tmp_imgs_dir
+            if self.proc_rank == 0:
+                try:
+                    out = np.concatenate([np.load(os.path.join(box[0], f)) for f in sorted(os.listdir(box[0]))], axis=0)
+                finally:
+                    shutil.rmtree(box[0], ignore_errors=True)
+            dist.barrier()
+            return out
         world = int(world_size) if world_size is not None else (self.num_gpus if self.use_ddp else 1)
         if world <= 1:
             _, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, 0, 1, tmp_imgs_dir, self.pipeline_cls, collect)

@@ -31,6 +31,16 @@ def _rand_like(x, generator=None):
     return torch.rand(x.shape, generator=generator, device=generator.device, dtype=x.dtype).to(x.device)
 
 
+def _mark_written(*tensors):
+    """A kernel of the library wrote these tensors through raw pointers: bump their version counters, as an in-place torch op would, so
+    that anything keyed on `_version` (geneface_amd.fused.get_state's staleness check of the packed copies and of the occupancy box) sees it."""
+    for t in tensors:
+        try:
+            torch.autograd.graph.increment_version(t)
+        except AttributeError:      # older torch: an in-place no-op does the same
+            t.add_(0)
+
+
 class NeRFRenderer(nn.Module):
     #: execution strategy of render(): "fused", "ops", or "auto" = fused whenever the call is inside what the fused
     #: kernels cover (no perturbation, max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
@@ -105,6 +115,7 @@ class NeRFRenderer(nn.Module):
         from .lib import check, current_stream, lib, ptr
         check(lib().gf_mark_untrained_grid(ptr(p44, torch.float32), int(p44.shape[0]), fx, fy, cx, cy, int(self.cascade), int(self.grid_size),
                                            float(self.bound), ptr(self.density_grid, torch.float32), current_stream(dev)))
+        _mark_written(self.density_grid)
 
     def _cell_jitter(self, S, generator):
         """U[0,1) jitter for every cascade cell, [cascade, G^3, 3] in meshgrid order.  With a generator the numbers are drawn block by
@@ -154,6 +165,7 @@ class NeRFRenderer(nn.Module):
         stats = torch.empty(2, dtype=torch.float32, device=dev)
         check(L.gf_grid_update(ptr(self.density_grid, torch.float32), ptr(tmp_grid, torch.float32), C, G, float(decay), float(self.density_thresh),
                                ptr(self.density_bitfield, torch.uint8), ws.data_ptr(), ptr(stats), current_stream(dev)))
+        _mark_written(self.density_grid, self.density_bitfield)   # raw-pointer writes: tell autograd's version counters (fused.get_state watches them)
         self.mean_density = float(stats[0].item())
         self.iter_density += 1
         total_step = min(16, self.local_step)

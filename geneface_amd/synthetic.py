@@ -237,7 +237,7 @@ def make_bg_img(H: int, W: int) -> np.ndarray:
     return np.clip(img, 0, 1).astype(np.float32)
 
 
-def make_sequence(T: int, H: int = 512, W: int = 512, hp: dict = None, seed: int = 0) -> dict:
+def make_sequence(T: int, H: int = 512, W: int = 512, hp: dict = None, seed: int = 0, radius: float = None) -> dict:
     """Everything `run_model` needs for T frames except rays (host numpy; rays are generated per frame):
     cond_wins [T,5,1,204], poses [T,4,4] (smoothed, ngp axes), intrinsics [4], bg_img [H*W,3]."""
     from .lm3d import cond_windows, normalize_and_smooth
@@ -245,7 +245,7 @@ def make_sequence(T: int, H: int = 512, W: int = 512, hp: dict = None, seed: int
     hp = hp or {}
     lm = make_landmarks(T, seed=11 + seed)
     lm_norm = normalize_and_smooth(lm, 0.0, 1.0, hp.get("infer_lm3d_clamp_std", 2.5))
-    poses = make_poses(T, seed=7 + seed)
+    poses = make_poses(T, seed=7 + seed) if radius is None else make_poses(T, seed=7 + seed, radius=radius)   # radius < 3.35: the head fills the frame
     if hp.get("infer_smooth_camera_path", True):
         poses = smooth_camera_path(poses.copy(), hp.get("infer_smooth_camera_path_kernel_size", 7)).astype(np.float32)
     return {

@@ -206,6 +206,10 @@ typedef struct gf_cond_t {
 uint64_t gf_cond_sizeof(void);
 int gf_cond_check(const gf_cond_t* cond);            /* HOST: can gf_cond_encode serve this encoder / window? (no launch) */
 int gf_cond_encode(const gf_cond_t* cond, void* stream);
+/* n_frames frames in one launch (one workgroup each): cond [n,S,T,C], pose6 [n,6] -> cond_feat [n,dim_aud], amb_bias [n,128], torso_bias [n,96];
+ * row k equals gf_cond_encode on frame k alone, bit for bit.  What the frame loop of base_nerf_infer.py:81-106 runs per frame
+ * (tasks/radnerfs/radnerf.py:119-128 -> cal_cond_feat) hoisted in front of the loop: every window of the shard is resident by then. */
+int gf_cond_encode_batch(const gf_cond_t* cond, uint32_t n_frames, void* stream);
 
 uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
@@ -308,7 +312,8 @@ int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_ho
 int gf_render_head(const gf_frame_t* frame, void* stream);
 /* torso pass + final blend (radnerf_torso.py:156-198); gf_render_head must precede it on the same stream */
 int gf_render_torso(const gf_frame_t* frame, void* stream);
-/* measurement only: gf_render_head's two field launches bracketed by HIP events on `stream`; synchronises */
+/* measurement only: gf_render_head's launches bracketed by HIP events on `stream`; synchronises.  phase_ms_host [4]: [0], [1] the two field
+ * launches (k_head_phase), [2] k_frame_init (ray generation + the march through empty space); *n_phases_host = 3 */
 int gf_render_head_timed(const gf_frame_t* frame, void* stream, float* phase_ms_host, uint32_t* n_phases_host);
 
 #ifdef __cplusplus

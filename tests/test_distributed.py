@@ -123,3 +123,45 @@ def test_forward_system_spawns_one_rank_per_gpu_world2_gloo(tmp_path, monkeypatc
     inf1.pipeline_cls, inf1.use_ddp = StubPipeline, False
     frames1 = inf1.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": "", "tmp_imgs_dir": str(tmp_path / "imgs1")})
     np.testing.assert_array_equal(frames1, frames)
+
+
+def _torchrun_style_rank(rank, world, port, out_dir, cond_path, T, H, W):
+    """What a rank of `torchrun ... lm3d_radnerf_infer` does: the process group exists BEFORE the entry point is constructed."""
+    import numpy as np
+    from helpers import StubPipeline
+    from geneface_amd import synthetic as S
+    from geneface_amd.lm3d_radnerf_infer import LM3d_RADNeRFInfer, RADNeRFPoseSource
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_entry_point import _ds_dict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hp = HP.may_hparams(True)
+    dd, _ = _ds_dict(T=T, H=H, W=W)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True, seed=7 + rank), strict=True)     # replicas differ until the broadcast
+    inf = LM3d_RADNeRFInfer(hp, model=model, dataset=RADNeRFPoseSource(dd, hp), device="cpu")
+    inf.pipeline_cls = StubPipeline
+    out_name = os.path.join(out_dir, "out.npy")
+    frames = inf.infer_once({"cond_name": cond_path, "out_video_name": out_name, "audio_source_name": "", "tmp_imgs_dir": os.path.join(out_dir, "imgs")})
+    np.save(os.path.join(out_dir, f"ret_{rank}.npy"), frames)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forward_system_under_an_existing_process_group_gathers_on_rank0(tmp_path):
+    """under torchrun rank 0 used to write ITS block to out_video_name as if it were the sequence.  Now both multi-GPU entry
+    paths return the same thing on rank 0: every frame, in order, rendered from rank 0's weights."""
+    import numpy as np
+    from geneface_amd import synthetic as S
+    T, H, W, world = 11, 16, 16, 2
+    cond_path = str(tmp_path / "lm.npy")
+    np.save(cond_path, S.make_landmarks(T).astype(np.float32)[None])
+    mp.spawn(_torchrun_style_rank, args=(world, _free_port(), str(tmp_path), cond_path, T, H, W), nprocs=world, join=True)
+    full = np.load(tmp_path / "out.npy")
+    assert full.shape == (T, H, W, 3)
+    assert [int(full[i, 0, 0, 0]) for i in range(T)] == list(range(T))           # StubPipeline encodes the global frame index in channel 0
+    assert len({int(full[i, 0, 0, 1]) for i in range(T)}) == 1                     # one weight checksum: rank 0's, on both ranks' frames
+    np.testing.assert_array_equal(np.load(tmp_path / "ret_0.npy"), full)           # rank 0 returns the whole sequence
+    r1 = np.load(tmp_path / "ret_1.npy")
+    np.testing.assert_array_equal(r1, full[T // world:])                           # the other rank its own block
+    assert sorted(os.listdir(tmp_path / "imgs")) == [f"{i:05d}.png" for i in range(T)]

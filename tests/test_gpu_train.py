@@ -296,6 +296,43 @@ def test_training_branch_under_fp16_autocast():
     assert n >= 20 and scaler.get_scale() >= 1024.0                               # no inf/nan step was skipped
 
 
+def test_grid_backward_keeps_tiny_gradients():
+    """the table scatter accumulates in fixed point scaled by the level's LARGEST gradient.  Entries that only ever receive tiny
+    gradients (samples behind T ~ 1e-4, rarely hit hash rows) must still get them with fp32 relative accuracy -- the reference trains the
+    tables with Adam eps = 1e-15 (tasks/radnerfs/radnerf.py:63) so that exactly those entries take full-size steps.  Three bands of one
+    dense 2-D grid receive gradients of relative size 1, 1e-7 and 1e-14; per-entry error against the oracle's scatter, relative to the
+    entry's own sum of |contributions|."""
+    from geneface_amd.encoders.gridencoder import GridEncoder
+    D, B = 2, 120_000
+    enc = GridEncoder(input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=512, gridtype="tiled").to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x01 = torch.rand(B, D, generator=g)
+    band = torch.randint(0, 3, (B,), generator=g)
+    x01[:, 0] = (x01[:, 0] * 0.27 + band * 0.36).clamp(0, 1)             # bands [0, .27], [.36, .63], [.72, .99]: no cell of any level is shared
+    scale = torch.tensor([1.0, 1e-7, 1e-14])[band]
+    grad = torch.randn(B, 32, generator=g) * scale[:, None]
+    x = (x01 * 2 - 1).to(DEV)
+    out = enc(x, bound=1)
+    (out * grad.to(DEV)).sum().backward()
+    got = enc.embeddings.grad.cpu()
+    off, emb = enc.offsets.cpu(), enc.embeddings.detach().cpu()
+    S = float(torch.log2(torch.tensor(enc.per_level_scale, dtype=torch.float64)))
+    x01c = ((x.cpu() + 1) / 2).contiguous()
+    dy, gi = torch.empty(B, 16 * D * 2), torch.zeros(B, D)
+    ref, mass = torch.zeros_like(emb), torch.zeros_like(emb)
+    glbc = grad.view(B, 16, 2).permute(1, 0, 2).contiguous()
+    o_ref = torch.empty(16, B, 2)
+    K.gridencoder.grid_encode_forward(x01c, emb, off, o_ref, B, D, 2, 16, S, 16, dy, enc.gridtype_id, False, enc.interp_id)
+    K.gridencoder.grid_encode_backward(glbc, x01c, emb, off, ref, B, D, 2, 16, S, 16, dy, gi, enc.gridtype_id, False, enc.interp_id)
+    K.gridencoder.grid_encode_backward(glbc.abs(), x01c, emb, off, mass, B, D, 2, 16, S, 16, dy, gi, enc.gridtype_id, False, enc.interp_id)
+    hit = mass > 0
+    rel = ((got - ref).abs()[hit] / mass[hit])
+    assert float(rel.max()) < 2e-5, float(rel.max())
+    tiny = hit & (mass < 1e-10)                                            # entries fed by the 1e-14 band alone
+    assert int(tiny.sum()) > 10_000 and int((got[tiny] != 0).sum()) > 0.99 * int((ref[tiny] != 0).sum())
+    assert not got[~hit].any()
+
+
 @pytest.mark.parametrize("bad", [float("inf"), float("nan")])
 def test_non_finite_gradients_reach_the_tables(bad):
     """A GradScaler decides from the parameter gradients whether a step overflowed.  The table scatter accumulates in fixed point scaled by
