@@ -222,6 +222,16 @@ class LM3d_RADNeRFInfer:
         Returns uint8 [n, H, W, 3] (host) of the frames this call is responsible for, or `tmp_imgs_dir` when collect=False."""
         import torch.distributed as dist
         tmp_imgs_dir = tmp_imgs_dir if tmp_imgs_dir is not None else getattr(self, "inp", {}).get("tmp_imgs_dir")
+        shard = getattr(self, "inp", {}).get("shard")
+        if shard is not None:
+            # inp["shard"] = (rank, world_size): this process renders exactly the block rank `rank` of a `world_size`-GPU job would (:150-155) and
+            # nothing else -- for launchers that start every rank as an independent process (no process group; every replica loads the
+            # same checkpoint), and for measuring one GPU's share of a sharded sequence on one GPU.
+            rank, world = int(shard[0]), int(shard[1])
+            if not 0 <= rank < world:
+                raise ValueError(f"shard {shard}: need 0 <= rank < world_size")
+            _, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, rank, world, tmp_imgs_dir, self.pipeline_cls, collect)
+            return out if collect else tmp_imgs_dir
         if dist.is_available() and dist.is_initialized():
             self.proc_rank, world = dist.get_rank(), dist.get_world_size()
             lo, out = _render_block(self.model, self.hparams, self.dataset, batches, self.device, self.proc_rank, world,

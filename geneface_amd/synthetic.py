@@ -252,3 +252,24 @@ def make_sequence(T: int, H: int = 512, W: int = 512, hp: dict = None, seed: int
         "cond_wins": cond_windows(lm_norm, hp.get("cond_win_size", 1), hp.get("smo_win_size", 5)),
         "poses": poses, "intrinsics": intrinsics(H, W), "bg_img": make_bg_img(H, W).reshape(-1, 3), "H": H, "W": W,
     }
+
+
+def make_dataset_dict(T: int = 9, H: int = 64, W: int = 64, seed: int = 3):
+    """A `trainval_dataset.npy`-shaped dict (data_gen/nerf/binarizer.py:175-199: train_samples / val_samples with AD-NeRF convention 4x4 `c2w`,
+    H, W, focal, cx, cy, uint8 bg_img, landmark statistics) for the synthetic orbit camera, and the ngp-axes poses it encodes -- what
+    geneface_amd.lm3d_radnerf_infer.RADNeRFPoseSource reads in place of the real file."""
+    rng = np.random.default_rng(seed)
+    ngp = make_poses(T)
+    scale = 4.0
+    c2w = []
+    for p in ngp:                                         # invert nerf_matrix_to_ngp: rows (y,z,x) <- (x,y,z), t / scale
+        m = np.eye(4, dtype=np.float32)
+        m[0, :3], m[1, :3], m[2, :3] = [p[2, 0], -p[2, 1], -p[2, 2]], [p[0, 0], -p[0, 1], -p[0, 2]], [p[1, 0], -p[1, 1], -p[1, 2]]
+        m[0, 3], m[1, 3], m[2, 3] = p[2, 3] / scale, p[0, 3] / scale, p[1, 3] / scale
+        c2w.append(m)
+    K = intrinsics(H, W)
+    samples = [{"c2w": m, "idx": i} for i, m in enumerate(c2w)]
+    return {"train_samples": samples[:T - 2], "val_samples": samples[T - 2:], "H": H, "W": W, "focal": float(K[0]), "cx": float(K[2]),
+            "cy": float(K[3]), "bg_img": (make_bg_img(H, W).reshape(H, W, 3) * 255).astype(np.uint8),
+            "idexp_lm3d_mean": rng.normal(size=(1, 68, 3)).astype(np.float32) * 0.1,
+            "idexp_lm3d_std": (1 + 0.1 * rng.random(size=(1, 68, 3))).astype(np.float32)}, ngp

@@ -58,16 +58,22 @@ class _Anything(types.ModuleType):
         return _Placeholder
 
 
-def install():
-    """Idempotently make `import modules.radnerfs...` work from /root/reference on CPU."""
-    if not available():
+def install(root: str = None, backend: str = "oracle"):
+    """Idempotently make `import modules.radnerfs...` work from /root/reference on CPU.
+    root: another place to import the reference's Python from (the staged archive oracle/_refpy/geneface_refpy.zip on the GPU box).
+    backend "oracle": the four extension names resolve to the C oracle (CPU).  backend "compat": they are left to
+    geneface_amd.compat.install(), i.e. the reference's Python then drives the PRODUCT's kernels on the GPU -- the one configuration in
+    which product code and this test infrastructure meet, and only inside tests/."""
+    root = root or REFERENCE_ROOT
+    if root == REFERENCE_ROOT and not available():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
-    sys.modules.setdefault("_raymarching_face", _module_from_class("_raymarching_face", _k.raymarching_face))
-    sys.modules.setdefault("_gridencoder", _module_from_class("_gridencoder", _k.gridencoder))
-    sys.modules.setdefault("_shencoder", _module_from_class("_shencoder", _k.shencoder))
-    sys.modules.setdefault("_freqencoder", _module_from_class("_freqencoder", _k.freqencoder))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    if backend == "oracle":
+        sys.modules.setdefault("_raymarching_face", _module_from_class("_raymarching_face", _k.raymarching_face))
+        sys.modules.setdefault("_gridencoder", _module_from_class("_gridencoder", _k.gridencoder))
+        sys.modules.setdefault("_shencoder", _module_from_class("_shencoder", _k.shencoder))
+        sys.modules.setdefault("_freqencoder", _module_from_class("_freqencoder", _k.freqencoder))
     for name in _STUB_NAMES:
         try:
             importlib.import_module(name)

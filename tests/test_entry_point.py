@@ -13,23 +13,7 @@ from geneface_amd import synthetic as S
 from geneface_amd.lm3d_radnerf_infer import LM3d_RADNeRFInfer, RADNeRFPoseSource
 
 
-def _ds_dict(T=9, H=64, W=64, seed=3):
-    """A trainval_dataset.npy-shaped dict (data_gen/nerf/binarizer.py:175-199) with AD-NeRF convention c2w matrices."""
-    rng = np.random.default_rng(seed)
-    ngp = S.make_poses(T)                                 # ngp-axes poses of the synthetic orbit camera
-    scale = 4.0
-    c2w = []
-    for p in ngp:                                         # invert nerf_matrix_to_ngp: rows (y,z,x) <- (x,y,z), t / scale
-        m = np.eye(4, dtype=np.float32)
-        m[0, :3], m[1, :3], m[2, :3] = [p[2, 0], -p[2, 1], -p[2, 2]], [p[0, 0], -p[0, 1], -p[0, 2]], [p[1, 0], -p[1, 1], -p[1, 2]]
-        m[0, 3], m[1, 3], m[2, 3] = p[2, 3] / scale, p[0, 3] / scale, p[1, 3] / scale
-        c2w.append(m)
-    K = S.intrinsics(H, W)
-    samples = [{"c2w": m, "idx": i} for i, m in enumerate(c2w)]
-    return {"train_samples": samples[:T - 2], "val_samples": samples[T - 2:], "H": H, "W": W, "focal": float(K[0]), "cx": float(K[2]),
-            "cy": float(K[3]), "bg_img": (S.make_bg_img(H, W).reshape(H, W, 3) * 255).astype(np.uint8),
-            "idexp_lm3d_mean": rng.normal(size=(1, 68, 3)).astype(np.float32) * 0.1,
-            "idexp_lm3d_std": (1 + 0.1 * rng.random(size=(1, 68, 3))).astype(np.float32)}, ngp
+_ds_dict = S.make_dataset_dict      # a trainval_dataset.npy-shaped dict with AD-NeRF convention c2w matrices, and the ngp poses it encodes
 
 
 def test_pose_source_follows_dataset_init(tmp_path):
@@ -112,8 +96,9 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         ref = R.render(sd, hp, ro, rd, torch.from_numpy(samples[i]["cond_wins"]), bgc, R.convert_poses(pose), bg, torso=True)
         ref8 = (ref["rgb_map"] * 255).view(64, 64, 3).to(torch.uint8)
         got = torch.from_numpy(frames[i])
-        assert ((got.int() - ref8.int()).abs() <= 1).float().mean().item() > 0.995
-        assert psnr(got.float() / 255, ref8.float() / 255) > 45
+        d = (got.int() - ref8.int()).abs()
+        assert int(d.max()) <= 1 and (d == 0).float().mean().item() > 0.999
+        assert psnr(got.float() / 255, ref8.float() / 255) > 55
 
 
 def _save_reference_checkpoint(path, model_sd, step, extra_children=True):
@@ -248,3 +233,34 @@ def test_orbit_camera_pose_and_intrinsics():
     assert np.allclose(other.pose, q, atol=1e-5)
     other.update_intrinsics([1365.3, 1365.3, 256, 256])
     assert abs(other.fovy - 21.24) < 0.01 and other.W == 512
+
+
+@pytest.mark.gpu
+def test_infer_once_shard_is_the_ranks_block_of_the_whole_run(tmp_path):
+    """inp["shard"] = (rank, world): one process renders exactly the frames rank `rank` of a `world`-GPU job would (base_nerf_infer.py:150-155)
+    -- the per-GPU share of BASELINE.json configs[3] on one GPU (tools/shard_run.py measures it at 375 of 3000 frames, 512x512).  Same bytes as
+    the same frames of the unsharded run, PNG names are GLOBAL frame indices."""
+    from geneface_amd.png import decode_rgb8
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = HP.may_hparams(True)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True), strict=True)
+    T = 23
+    dd, _ = _ds_dict(T=T, H=64, W=64)
+    inf = LM3d_RADNeRFInfer(hp, model=model, dataset=RADNeRFPoseSource(dd, hp), device="cuda:0")
+    cond_path = os.path.join(tmp_path, "lm.npy")
+    np.save(cond_path, S.make_landmarks(T).astype(np.float32)[None])
+    whole = inf.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": ""})
+    assert whole.shape == (T, 64, 64, 3)
+    seen = []
+    for rank in range(3):
+        imgs = os.path.join(tmp_path, f"imgs{rank}")
+        part = inf.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": "", "tmp_imgs_dir": imgs, "shard": (rank, 3)})
+        lo, hi = rank * (T // 3), ((rank + 1) * (T // 3) if rank < 2 else T)
+        np.testing.assert_array_equal(part, whole[lo:hi])
+        assert sorted(os.listdir(imgs)) == [f"{i:05d}.png" for i in range(lo, hi)]
+        np.testing.assert_array_equal(decode_rgb8(open(os.path.join(imgs, f"{lo:05d}.png"), "rb").read()), whole[lo])
+        seen.extend(range(lo, hi))
+    assert seen == list(range(T))
+    with pytest.raises(ValueError):
+        inf.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": "", "shard": (3, 3)})

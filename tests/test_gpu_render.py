@@ -44,7 +44,7 @@ def check(out, ref, torso):
     u8 = (rgb * 255).to(torch.uint8).int() - (rgb_ref * 255).to(torch.uint8).int()
     assert (u8.abs() <= 1).float().mean().item() > 0.999
     dref = ref["depth_map"] if torch.is_tensor(ref["depth_map"]) else torch.from_numpy(ref["depth_map"])
-    assert (out["depth_map"].cpu() - dref).abs().max().item() < 2e-3
+    assert (out["depth_map"].cpu() - dref).abs().max().item() < 2e-4      # measured 4e-5
     if torso:
         for k, tol in (("torso_alpha_map", 2e-5), ("torso_rgb_map", 2e-5)):
             r = ref[k] if torch.is_tensor(ref[k]) else torch.from_numpy(ref[k])
@@ -83,6 +83,11 @@ def test_frame_256_vs_oracle(impl):
         # reference marches (its iterations evaluate a dying ray's whole n_step chunk; the pool rounds waste fewer)
         total, hi, lo = sum(fs["samples"]), sum(t["n_valid"] for t in trace), sum(t["n_composited"] for t in trace)
         assert lo - max(16, 1e-3 * lo) <= total <= hi + max(16, 1e-3 * hi), (lo, total, hi)
+        # what the compositor consumed is the reference's composited count (up to the rays whose transmittance sits within rounding of
+        # T_thresh), and the samples evaluated beyond it -- the rest of a dying ray's slots in its last round -- stay under 5 %
+        comp = sum(fs["composited"])
+        assert abs(comp - lo) <= max(16, 1e-3 * lo), (comp, lo)
+        assert total - comp <= 0.05 * total, (total, comp)
         assert fs["n_hit"] == trace[1]["n_alive"] or abs(fs["n_hit"] - trace[0]["n_valid"]) == 0
     elif hasattr(model, "last_schedule") and model.last_schedule:
         # the n_step schedule is a discrete function of the alive counts: it must be identical; the counts themselves may
@@ -148,8 +153,8 @@ def test_field_forward_one_launch_vs_oracle():
 @pytest.mark.parametrize("torso", [False, True])
 def test_frame_pipeline_pose_mode_vs_oracle(torso):
     """FramePipeline (the frame loop of base_nerf_infer.py:81-106): rays generated inside the kernel from the pose,
-    uint8 frame copied to pinned host memory.  Rays can differ from torch's get_rays in the last ulp, so this is a
-    PSNR / LSB check rather than a max-abs one."""
+    uint8 frame copied to pinned host memory.  Rays can differ from torch's get_rays in the last ulp and the output is truncated to
+    bytes, so the bar is: no byte off by more than 1 LSB, >= 99.9 % of the bytes identical, PSNR >= 55 dB."""
     from geneface_amd.infer import FramePipeline
     hp, sd, model = build(torso, "fused")
     seq = sequence(4, 128, 128)
@@ -161,13 +166,14 @@ def test_frame_pipeline_pose_mode_vs_oracle(torso):
         ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
         ref8 = (ref["rgb_map"] * 255).view(128, 128, 3).to(torch.uint8)
         diff = (frame.int() - ref8.int()).abs()
-        assert (diff <= 1).float().mean().item() > 0.995
-        assert psnr(frame.float() / 255, ref8.float() / 255) > 45
+        assert int(diff.max()) <= 1 and (diff == 0).float().mean().item() > 0.999       # the bar of the 512x512 tests below
+        assert psnr(frame.float() / 255, ref8.float() / 255) > 55
         # the ops-path pipeline must give the same picture
         pipe_ops = FramePipeline(model, hp, seq, DEV, impl="ops")
         frame_ops = pipe_ops.render_frame(i).clone()
         torch.cuda.synchronize()
-        assert ((frame_ops.int() - frame.int()).abs() <= 1).float().mean().item() > 0.995
+        d2 = (frame_ops.int() - frame.int()).abs()
+        assert int(d2.max()) <= 1 and (d2 == 0).float().mean().item() > 0.999
 
 
 def test_cond_encode_kernel_vs_oracle():
@@ -721,3 +727,103 @@ def test_full_size_frames_are_reproducible(precision):
     order = [0, 1, 2, 3, 3, 1, 0, 2] * 15
     for n, ((i, frame), k) in enumerate(zip(pipe.stream(order), order)):
         assert np.array_equal(frame, want[k]), (precision, "in flight", n)
+
+
+# ----------------------------------------------------------------------------------------------- round 3: the configs at their real shape
+def _identity_model(seed, impl="fused"):
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = model_fixture(True)[0]
+    sd = S.make_state_dict(hp, True, seed=seed)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m.render_impl = impl
+    return hp, sd, m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("seed", [0, 1000])
+def test_frame_loop_512_head_torso_vs_oracle(seed):
+    """BASELINE.json configs[2] (seed 0, the bench fixture) and configs[4] (seed 1000: second identity -- other weights, another occupancy
+    shape) at the headline shape: 512x512 head+torso through BOTH seams against the CPU oracle -- the module API with explicit rays
+    (fp32 rgb / depth / torso maps, strict tolerance) and the pose-mode frame loop (in-kernel rays, uint8 to pinned host memory)."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = _identity_model(seed)
+    seq = sequence(4, 512, 512, seed=5 if seed else 0)
+    fi = frame_inputs(seq, 1)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+    check(render_gpu(model, hp, fi), ref, True)
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused")
+    frame = pipe.render_frame(1)
+    pipe.wait()
+    ref8 = (ref["rgb_map"] * 255).view(512, 512, 3).to(torch.uint8)
+    d = (frame.int() - ref8.int()).abs()
+    assert int(d.max()) <= 1 and (d == 0).float().mean().item() > 0.999
+    assert psnr(frame.float() / 255, ref8.float() / 255) > 55
+
+
+def test_prepared_pass_is_bit_identical():
+    """FramePipeline.prepare: ONE condition-encoder launch for a whole pass (gf_cond_encode_batch, a workgroup per frame) instead of one
+    single-workgroup launch per frame.  Row k of the batch is the single launch's result bit for bit, so are the frames -- alone, in
+    flight, and through stream(), which prepares its block by itself."""
+    from geneface_amd import fused
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(True, "fused")
+    seq = sequence(12, 160, 160)
+    st = fused.get_state(model)
+    conds = torch.from_numpy(seq["cond_wins"]).float().to(DEV)
+    pipe0 = FramePipeline(model, hp, seq, DEV, impl="fused", overlap=False)
+    feat, amb, tb = fused.cond_encode_batch(model, st, conds, pipe0.pose6)
+    for k in (0, 5, 11):
+        f1, a1, t1 = fused._per_frame_vectors(model, st, conds[k], pipe0.pose6[k:k + 1])
+        assert torch.equal(f1, feat[k]) and torch.equal(a1, amb[k]) and torch.equal(t1, tb[k])
+        assert torch.equal(f1, model.cal_cond_feat(conds[k]).reshape(-1)) or (f1 - model.cal_cond_feat(conds[k]).reshape(-1)).abs().max() < 1e-5
+    want = []
+    for i in range(12):
+        f = pipe0.render_frame(i)
+        pipe0.wait()
+        want.append(f.clone().numpy())
+    for in_flight in (1, 3):
+        pipe = FramePipeline(model, hp, seq, DEV, impl="fused", in_flight=in_flight)
+        for rep in range(3):
+            pipe.prepare(2, 12)                                   # frames 0, 1 stay outside the prepared block: they take the per-frame launch
+            assert pipe.prepared(1) is None and pipe.prepared(2) is not None
+            for i in range(12):
+                fr = pipe.render_frame(i)
+                pipe.wait()
+                assert np.array_equal(fr.numpy(), want[i]), (in_flight, rep, i)
+        pipe2 = FramePipeline(model, hp, seq, DEV, impl="fused", in_flight=in_flight)
+        for (i, frame), k in zip(pipe2.stream(range(12)), range(12)):
+            assert i == k and np.array_equal(frame, want[k])
+        assert pipe2.prepared(0) is not None                       # stream() encoded its block in one launch
+
+
+def test_ops_path_and_stand_alone_encoders_are_reproducible():
+    """run-to-run identity outside the fused head kernel, at sizes that put two and more workgroups on every CU --
+    the op-by-op render path at 512x512 (stand-alone marcher, encoders, field, compositor, torso) and the stand-alone encoders on a
+    million points.  (The library carries no packed-FP32 instruction any more: tests/test_build_invariants.py.)"""
+    from geneface_amd.encoders.freqencoder import FreqEncoder
+    from geneface_amd.encoders.gridencoder import GridEncoder
+    from geneface_amd.encoders.shencoder import SHEncoder
+    hp, sd, model = build(True, "ops")
+    fi = frame_inputs(sequence(4, 512, 512), 2)
+    first = render_gpu(model, hp, fi)
+    for rep in range(5):
+        out = render_gpu(model, hp, fi)
+        for k in ("rgb_map", "depth_map", "torso_alpha_map", "torso_rgb_map"):
+            assert torch.equal(out[k], first[k]), (rep, k)
+    g = torch.Generator().manual_seed(3)
+    B = 1 << 20
+    for D, gridtype in ((3, "hash"), (2, "hash"), (2, "tiled")):
+        enc = GridEncoder(input_dim=D, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16, desired_resolution=2048, gridtype=gridtype).to(DEV)
+        with torch.no_grad():
+            enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1).to(DEV))
+            x = (torch.rand(B, D, generator=g) * 2 - 1).to(DEV)
+            ref = enc(x, bound=1)
+            for rep in range(8):
+                assert torch.equal(enc(x, bound=1), ref), (D, gridtype, rep)
+    with torch.no_grad():
+        d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(DEV)
+        sh, fq = SHEncoder().to(DEV), FreqEncoder(input_dim=3, degree=4).to(DEV)
+        r1, r2 = sh(d), fq(d)
+        for rep in range(8):
+            assert torch.equal(sh(d), r1) and torch.equal(fq(d), r2), rep
