@@ -393,7 +393,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
     job.close()
 
 
-HEAVY_RADIUS, HEAVY_SIGMA_SCALE = 2.55, 0.3
+HEAVY_RADIUS, HEAVY_SIGMA_SCALE = 2.75, 0.3
 
 
 def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_idx, what, radius=None):

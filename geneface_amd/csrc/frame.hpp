@@ -91,6 +91,26 @@ constexpr uint32_t H16_COL1G = H16_COL1S + 1;  // 8
 constexpr uint32_t H16_TOTAL = H16_COL1G + 8;  // 39 groups = 39 KiB per wave and round
 constexpr uint32_t HP16_HALVES = 4 * H16_TOTAL * 64 * 8;   // the VALU rows / constant bias stay fp32 (HP_SMALL of the fp32 pack)
 
+// ---------------- packed head weights, split path (gf_frame_t.precision = 2): fp32 values as two-term f16 splits ----------------
+// Every fp32 weight w travels as hi = half(w) and lo' = half((w - hi) * 2^11): w = hi + lo' * 2^-11 to 2^-24 relative (both terms are
+// rounded to nearest, the products of two halves are exact in the fp32 accumulators).  The activations are split the same way in LDS,
+// and one product term set is three v_mfma_f32_32x32x16_f16 per 16 input features and tile:
+//   acc1 += hi_w * hi_x;   acc2 += lo'_w * hi_x + hi_w * lo'_x;   result = acc1 + acc2 * 2^-11      (lo'_w * lo'_x * 2^-22 is dropped: 2^-24 relative)
+// Same ownership as the other two streams; per group and lane 16 halves = [8 x hi | 8 x lo'] of
+//   W[row0 + 32w + (lane&31)][col0 + 16u + 8*(lane>>5) + i]   (two 16-byte loads per lane and group).
+// Density L1 is ONE K = 64 layer here: the lane pair that gathered a sample's 3-D features keeps them in registers across the ambient net
+// and writes them beside the 2-D features, so the activation buffer is the only large LDS array (same 528-byte rows as the fp32 path).
+constexpr uint32_t SP_AMB1 = 0;              // 2 groups (K = 32): ambient L1 over the 3-D grid features
+constexpr uint32_t SP_AMB2 = SP_AMB1 + 2;    // 8
+constexpr uint32_t SP_SIG1 = SP_AMB2 + 8;    // 4 (K = 64): density L1, columns [3-D 0..31 | 2-D 32..63]
+constexpr uint32_t SP_SIG2 = SP_SIG1 + 4;    // 8
+constexpr uint32_t SP_SIG3 = SP_SIG2 + 8;    // 8
+constexpr uint32_t SP_COL1S = SP_SIG3 + 8;   // 1 (SH, K = 16)
+constexpr uint32_t SP_COL1G = SP_COL1S + 1;  // 8
+constexpr uint32_t SP_TOTAL = SP_COL1G + 8;  // 39 groups = 78 KiB per wave and round (the fp32 stream's size)
+constexpr uint32_t HPS_HALVES = 4 * SP_TOTAL * 64 * 16;
+constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
+
 // ---------------- packed torso weights (floats) ----------------
 // MFMA streams as above with NOB out-blocks.  Frequency-encoded pixel coordinate enc(x) has 42 entries, padded to 48:
 // lane half h supplies enc index 24h + t (t < 24; indices >= 42 are zero on both sides).

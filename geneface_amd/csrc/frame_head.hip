@@ -97,6 +97,7 @@ struct HeadArgs {
     const float* amb_table; const int* amb_offsets;
     const float* head_pack; const float* amb_bias;
     const uint16_t* head_pack16;   // fast path only
+    const uint16_t* head_pack_split;   // split path only
     const float* rays_o; const float* rays_d; const float* far_occ;
     float* rays_t; float* weights_sum; float* depth; float* image;
     const int* queue;   // phase 0: hit list, phase 1: survivor list
@@ -889,7 +890,279 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     GF_STAMP(36);
 }
 
-template <bool FAST>
+
+// ---------------------------------------------------------------------------------------------------- split path (fp32 values on the f16 matrix pipe)
+// precision = 2.  The fp32 kernel is bound by the f32 matrix rate (64 cycles per 32x32x2 MFMA: 80 K cycles of pipe per wave and round); the
+// f16 instruction moves eight times the k-depth in half the cycles.  Here every fp32 value -- weight or activation -- is carried as
+//   v = hi + lo' * 2^-11,   hi = half(v) (round to nearest, |v| < 2^-14 -> 0),   lo' = half((v - hi) * 2^11)
+// which represents v to 2^-24 relative (the scaled lo' keeps the residual in the f16 NORMAL range down to |v| = 3e-8, so nothing depends on
+// how the matrix pipe treats f16 denormals), products of two halves are exact in the fp32 accumulators, and
+//   w * x = hi_w hi_x + (lo'_w hi_x + hi_w lo'_x) 2^-11 + O(2^-22)
+// costs three v_mfma_f32_32x32x16_f16 per 16 input features and tile (acc1 for the first term, acc2 for the two cross terms): 468 MFMAs of 32
+// cycles per wave and round instead of 1 248 of 64.  Errors against the fp32 kernel are of the size of its own rounding (different
+// summation order, 2^-24 per product): the strict tolerance of BASELINE.md section 4 (max|d rgb| <= 1e-4) holds with the same margin
+// (tests/test_gpu_render.py, every strict test runs on this tier too).  NOT fp32 bit patterns: the default stays precision 0.
+// Values beyond the f16 range: a weight is refused at pack time (gf_head_pack_split); an activation saturates its hi term at 65504 and
+// overflows lo' -> inf / NaN in the frame (visible, never silent) -- hidden activations of these networks are O(1..100).
+// Layout: the activation buffer holds rows of [128 x hi | 128 x lo' | 8 pad] halves = 528 bytes, the fp32 rows' size and bank pattern.
+constexpr int kHSS = 264;             // halves per split activation row
+static_assert(kHSS * 2 == kHS * 4, "split rows are exactly the fp32 rows");
+struct WPipeS { float4 q[2][2]; };    // two groups ahead, [hi | lo'] each
+
+__device__ __forceinline__ void load_group_s(float4 (&dst)[2], const char* __restrict__ Ws, uint32_t g, uint32_t lane32) {
+    const float4* p = reinterpret_cast<const float4*>(Ws + (size_t)g * 2048 + (size_t)lane32);
+    dst[0] = p[0];
+    dst[1] = p[1];
+}
+template <int G>
+__device__ __forceinline__ void wpipes_refill(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32) {
+    if constexpr (G + 2 < (int)gf::SP_TOTAL) load_group_s(wp.q[G % 2], Ws, G + 2, lane32);
+}
+
+// v -> (hi, lo'): see the header comment.  RELU folds max(v, 0) and the saturation into one v_med3_f32.
+template <bool RELU>
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    const float c = __builtin_amdgcn_fmed3f(v, RELU ? 0.0f : -65504.0f, 65504.0f);
+    const float ch = fabsf(c) < 6.103515625e-05f ? 0.0f : c;       // no f16 denormal in the hi term
+    hi = (_Float16)ch;
+    lo = (_Float16)((c - (float)hi) * gf::kSplitScale);
+}
+
+// U groups (K = 16 each) of this wave's output block over nt tiles.  Hb = &H[lane & 31][8 * (lane >> 5)] (hi part; lo' 128 halves on).
+template <int G0, int U, int u>
+__device__ __forceinline__ void obws_step(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
+                                          floatx16 (&a2)[4], int nt) {
+    if constexpr (u < U) {
+        // B operands one tile ahead of the MFMAs that consume them (two tiles' worth of registers, not four: the accumulators of the two
+        // product terms already take 128 of the 256 a lane has at two workgroups per CU)
+        half8 bh = *reinterpret_cast<const half8*>(Hb + 16 * u), bl = *reinterpret_cast<const half8*>(Hb + 16 * u + 128);
+        const half8 wh = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][0]), wl = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][1]);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < nt) {
+                half8 nh = bh, nl = bl;
+                if (t + 1 < nt) {
+                    nh = *reinterpret_cast<const half8*>(Hb + (t + 1) * 32 * kHSS + 16 * u);
+                    nl = *reinterpret_cast<const half8*>(Hb + (t + 1) * 32 * kHSS + 16 * u + 128);
+                }
+                a1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2[t], 0, 0, 0);
+                a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2[t], 0, 0, 0);
+                bh = nh; bl = nl;
+            }
+        wpipes_refill<G0 + u>(wp, Ws, lane32);
+        __builtin_amdgcn_sched_barrier(0);
+        obws_step<G0, U, u + 1>(wp, Ws, lane32, Hb, a1, a2, nt);
+    }
+}
+template <int G0, int U>
+__device__ __forceinline__ void obws_mfma(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
+                                          floatx16 (&a2)[4], int nt) {
+    obws_step<G0, U, 0>(wp, Ws, lane32, Hb, a1, a2, nt);
+}
+
+// accumulators -> split activations.  Hw = &H[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves, twice.
+template <bool RELU>
+__device__ __forceinline__ void obws_store(_Float16* Hw, const floatx16 (&a1)[4], const floatx16 (&a2)[4], int nt) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (t < nt) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                half4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    _Float16 hh, ll;
+                    split_f16<RELU>(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]), hh, ll);
+                    h[i] = hh; l[i] = ll;
+                }
+                *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q) = h;
+                *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q + 128) = l;
+            }
+        }
+}
+
+template <int NOUT>
+__device__ __forceinline__ void rows_from_lds_split(const _Float16* Hrow, const float* rows, int half, float (&res)[NOUT]) {
+    float sum[NOUT];
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) sum[c] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const half8 xh = *reinterpret_cast<const half8*>(Hrow + 64 * half + 8 * i);
+        const half8 xl = *reinterpret_cast<const half8*>(Hrow + 64 * half + 8 * i + 128);
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = __builtin_fmaf((float)xl[k], gf::kSplitInv, (float)xh[k]);
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) {
+            const float4 w0 = *reinterpret_cast<const float4*>(rows + c * 128 + 64 * half + 8 * i);
+            const float4 w1 = *reinterpret_cast<const float4*>(rows + c * 128 + 64 * half + 8 * i + 4);
+            sum[c] = __builtin_fmaf(w0.x, x[0], sum[c]);
+            sum[c] = __builtin_fmaf(w0.y, x[1], sum[c]);
+            sum[c] = __builtin_fmaf(w0.z, x[2], sum[c]);
+            sum[c] = __builtin_fmaf(w0.w, x[3], sum[c]);
+            sum[c] = __builtin_fmaf(w1.x, x[4], sum[c]);
+            sum[c] = __builtin_fmaf(w1.y, x[5], sum[c]);
+            sum[c] = __builtin_fmaf(w1.z, x[6], sum[c]);
+            sum[c] = __builtin_fmaf(w1.w, x[7], sum[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NOUT; c++) res[c] = sum[c] + __shfl_xor(sum[c], 32);
+}
+
+// 16 fp32 features of a lane pair's sample -> split halves at dst (hi) and dst + 128 (lo')
+__device__ __forceinline__ void store16s(_Float16* dst, const float (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        half8 h, l;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            _Float16 hh, ll;
+            split_f16<false>(f[8 * q + i], hh, ll);
+            h[i] = hh; l[i] = ll;
+        }
+        reinterpret_cast<half8*>(dst)[q] = h;
+        reinterpret_cast<half8*>(dst + 128)[q] = l;
+    }
+}
+
+__device__ __forceinline__ void obws_init(const float* bias16_or_null, floatx16 (&a1)[4], floatx16 (&a2)[4]) {
+    if (bias16_or_null) obw_bias<4>(bias16_or_null, a1); else obw_zero<4>(a1);
+    obw_zero<4>(a2);
+}
+
+__device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t sI = (uint32_t)(wave * 32 + j);
+    const bool tile_on = wave < nt;
+    const bool valid = sI < Mv;
+    const uint32_t sC = valid ? sI : (uint32_t)(wave * 32);
+    const uint32_t raw = tile_on ? s.d2r[sC] : 0u;
+    _Float16* H16 = reinterpret_cast<_Float16*>(s.H);
+    _Float16* Hrow = H16 + sI * kHSS;
+    const _Float16* Hb = H16 + j * kHSS + 8 * half;
+    _Float16* Hw = H16 + j * kHSS + 32 * wave + 4 * half;
+    const char* Ws = reinterpret_cast<const char*>(a.head_pack_split) + (size_t)wave * gf::SP_TOTAL * 2048;   // wave-uniform
+    uint32_t lane32 = (uint32_t)lane * 32u;
+    asm volatile("" : "+v"(lane32));
+    const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
+    floatx16 A1[4], A2[4];
+    WPipeS wp;
+    load_group_s(wp.q[0], Ws, 0, lane32);
+    load_group_s(wp.q[1], Ws, 1, lane32);
+
+    // ---- 3-D grid features -> H[:, 0:32]; the lane pair keeps them (fp32) for density L1
+    float pf[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) pf[i] = 0.0f;
+    if (tile_on) {
+        const float b2 = 2 * a.bound;
+        const float x3[3] = {(s.sx[raw] + a.bound) / b2, (s.sy[raw] + a.bound) / b2, (s.sz[raw] + a.bound) / b2};
+        gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
+        store16s(Hrow + 16 * half, pf);
+    }
+    __syncthreads();
+    // ---- ambient L1 (cond_feat folded into the bias)
+    obws_init(s.P + P_AMBBIAS + wave * 32 + half * 16, A1, A2);
+    obws_mfma<gf::SP_AMB1, 2>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<true>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- ambient L2
+    obws_init(nullptr, A1, A2);
+    obws_mfma<gf::SP_AMB2, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<true>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 32:64]; the kept 3-D features -> H[:, 0:32]
+    if (tile_on) {
+        float ambient[2];
+        rows_from_lds_split<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+        const float th[2] = {tanhf(ambient[0]), tanhf(ambient[1])};
+        const float x2[2] = {(th[0] + 1.0f) / 2.0f, (th[1] + 1.0f) / 2.0f};
+        float af[16];
+        gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
+        store16s(Hrow + 16 * half, pf);
+        store16s(Hrow + 32 + 16 * half, af);
+    }
+    __syncthreads();
+    // ---- density L1: K = 64
+    obws_init(nullptr, A1, A2);
+    obws_mfma<gf::SP_SIG1, 4>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<true>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- density L2
+    obws_init(nullptr, A1, A2);
+    obws_mfma<gf::SP_SIG2, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<true>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
+    float sigma = 0.0f;
+    if (tile_on) {
+        float h0[1];
+        rows_from_lds_split<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+        sigma = expf(h0[0]);
+    }
+    obws_init(nullptr, A1, A2);
+    obws_mfma<gf::SP_SIG3, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<false>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
+    obws_init(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1, A2);
+    {
+        const half8 wh = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][0]), wl = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][1]);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (t < nt) {
+                uint32_t d = (uint32_t)(t * 32 + j);
+                d = d < Mv ? d : Mv - 1u;
+                const uint32_t slot = s.rrank[d];
+                float sh[16];
+                gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+                half8 sh_h, sh_l;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    // both candidates pass through an opaque move first: otherwise the select of two array elements becomes ONE element at a
+                    // lane-dependent index, and the 16-entry array moves to scratch
+                    float v0 = sh[i], v1 = sh[8 + i];
+                    asm("" : "+v"(v0));
+                    asm("" : "+v"(v1));
+                    _Float16 hh, ll;
+                    split_f16<false>(half ? v1 : v0, hh, ll);
+                    sh_h[i] = hh; sh_l[i] = ll;
+                }
+                A1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_h, A1[t], 0, 0, 0);
+                A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, sh_h, A2[t], 0, 0, 0);
+                A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_l, A2[t], 0, 0, 0);
+            }
+        wpipes_refill<gf::SP_COL1S>(wp, Ws, lane32);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    obws_mfma<gf::SP_COL1G, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    __syncthreads();
+    obws_store<true>(Hw, A1, A2, nt);
+    __syncthreads();
+    // ---- colour L2 + sigmoid
+    if (tile_on) {
+        float c[3];
+        rows_from_lds_split<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+        if (valid && half == 0) {
+            s.sx[raw] = sigma;
+            s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
+            s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
+            s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
+        }
+    }
+    __syncthreads();
+}
+
+// MODE: 0 = fp32 (strict, bit-reproducible fp32 arithmetic), 1 = fast (f16 operands), 2 = split (fp32 values as two-term f16 splits)
+template <int MODE>
 __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
@@ -1098,8 +1371,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             __syncthreads();   // dense map published
             GF_STAMP(6);
             const uint32_t nt = (Mv + 31) / 32;
-            if constexpr (FAST) {
+            if constexpr (MODE == 1) {
                 field_round16(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
+            } else if constexpr (MODE == 2) {
+                field_round_split(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
             } else {
                 if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
                 else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);
@@ -1695,8 +1970,9 @@ int check_frame(const gf_frame_t* f) {
     if (f->max_steps == 0 || f->cascade == 0 || f->grid_size == 0 || f->grid_size > 1024) return gf_set_error(GF_ERR_INVALID, "frame: bad marcher configuration");
     if (f->max_steps > gf::kMaxSteps) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u needs the op-by-op path", gf::kMaxSteps);
     if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "frame: gridtype/interp must be 0 or 1");
-    if (f->precision > 1) return gf_set_error(GF_ERR_INVALID, "frame: precision must be 0 (fp32) or 1 (fast)");
+    if (f->precision > 2) return gf_set_error(GF_ERR_INVALID, "frame: precision must be 0 (fp32), 1 (fast) or 2 (split)");
     if (f->precision == 1 && !f->head_pack16) return gf_set_error(GF_ERR_INVALID, "frame: precision = 1 needs head_pack16");
+    if (f->precision == 2 && !f->head_pack_split) return gf_set_error(GF_ERR_INVALID, "frame: precision = 2 needs head_pack_split");
     return GF_OK;
 }
 
@@ -1752,12 +2028,14 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ha.poison = g_diag_cfg[0]; ha.poison_round = g_diag_cfg[1]; ha.pool_cap_override = g_diag_cfg[3];
 #endif
 
-    const bool fast = f->precision == 1;
+    const uint32_t mode = f->precision;
     ha.head_pack16 = f->head_pack16;
-    static GfLdsAttr lds[2];
+    ha.head_pack_split = f->head_pack_split;
+    static GfLdsAttr lds[3];
     {
-        const void* fn = fast ? reinterpret_cast<const void*>(k_head_phase<true>) : reinterpret_cast<const void*>(k_head_phase<false>);
-        if (const int e = gf_raise_lds_limit(lds[fast], fn, kSmemBytes, "frame")) return e;
+        const void* fn = mode == 1 ? reinterpret_cast<const void*>(k_head_phase<1>)
+                       : mode == 2 ? reinterpret_cast<const void*>(k_head_phase<2>) : reinterpret_cast<const void*>(k_head_phase<0>);
+        if (const int e = gf_raise_lds_limit(lds[mode], fn, kSmemBytes, "frame")) return e;
     }
     // persistent grid: 2 workgroups per CU x 256 CUs, never more workgroups than pools' worth of rays
     const uint32_t pools = gf_div_up(N, (uint32_t)kPool);
@@ -1772,8 +2050,9 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
         ha.phase = phase;
         ha.queue = phase ? w.alive_a : w.alive_b;
         if (ev) (void)hipEventRecord(ev[2 * phase], s);
-        if (fast) hipLaunchKernelGGL(k_head_phase<true>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
-        else hipLaunchKernelGGL(k_head_phase<false>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        if (mode == 1) hipLaunchKernelGGL(k_head_phase<1>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        else if (mode == 2) hipLaunchKernelGGL(k_head_phase<2>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        else hipLaunchKernelGGL(k_head_phase<0>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
         if (ev) (void)hipEventRecord(ev[2 * phase + 1], s);
     }
     return gf_check_launch("render_head");

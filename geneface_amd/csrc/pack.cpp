@@ -98,6 +98,42 @@ GF_EXPORT int gf_head_pack16(const float* amb0, const float* amb1, const float* 
     return GF_OK;
 }
 
+// Split path (gf_frame_t.precision = 2): the same matrices as two-term f16 splits (layout and arithmetic: frame.hpp, SP_*).
+// out_halves [gf_head_pack_split_halves()].  A weight beyond the f16 range cannot be split: GF_ERR_UNSUPPORTED (the caller stays on fp32).
+GF_EXPORT uint32_t gf_head_pack_split_halves(void) { return gf::HPS_HALVES; }
+
+GF_EXPORT int gf_head_pack_split(const float* amb0, const float* amb1, const float* sig0, const float* sig1, const float* sig2, const float* col0,
+                                 uint16_t* out_halves) {
+    using namespace gf;
+    if (!amb0 || !amb1 || !sig0 || !sig1 || !sig2 || !col0 || !out_halves) return gf_set_error(GF_ERR_INVALID, "head_pack_split: null pointer");
+    memset(out_halves, 0, sizeof(uint16_t) * HPS_HALVES);
+    bool ok = true;
+    auto layer = [&](uint32_t g0, uint32_t groups, const float* W, uint32_t ld, uint32_t row0, uint32_t col0) {
+        for (uint32_t w = 0; w < 4; w++)
+            for (uint32_t u = 0; u < groups; u++)
+                for (uint32_t l = 0; l < 64; l++)
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const float v = W[(size_t)(row0 + 32 * w + (l & 31u)) * ld + col0 + 16 * u + 8 * (l >> 5) + i];
+                        if (!(v >= -65504.0f && v <= 65504.0f)) ok = false;
+                        _Float16 hi = (_Float16)v;
+                        if (v > -6.103515625e-05f && v < 6.103515625e-05f) hi = (_Float16)0.0f;      // no f16 denormals in the hi term (see split_f16, frame_head.hip)
+                        const _Float16 lo = (_Float16)((v - (float)hi) * kSplitScale);
+                        uint16_t* dst = out_halves + (((size_t)w * SP_TOTAL + g0 + u) * 64 + l) * 16;
+                        memcpy(dst + i, &hi, sizeof(uint16_t));
+                        memcpy(dst + 8 + i, &lo, sizeof(uint16_t));
+                    }
+    };
+    layer(SP_AMB1, 2, amb0, 96, 0, 0);
+    layer(SP_AMB2, 8, amb1, 128, 0, 0);
+    layer(SP_SIG1, 4, sig0, 64, 0, 0);
+    layer(SP_SIG2, 8, sig1, 128, 0, 0);
+    layer(SP_SIG3, 8, sig2, 128, 1, 0);
+    layer(SP_COL1S, 1, col0, 148, 0, 0);
+    layer(SP_COL1G, 8, col0, 148, 0, 16);
+    if (!ok) return gf_set_error(GF_ERR_UNSUPPORTED, "head_pack_split: a weight is outside the f16 range (|w| > 65504 or not finite): use precision 0");
+    return GF_OK;
+}
+
 // Axis-aligned world-space box around every occupied cell of the Morton-ordered occupancy bitfield (HOST pointer):
 // cell (x,y,z) of cascade c covers ((v + {0,1}) / H * 2 - 1) * min(2^c, bound) per axis (raymarching.cu:883-892).  A sample
 // position outside this box lies in an unoccupied cell at every cascade, so the marcher can never emit a sample beyond

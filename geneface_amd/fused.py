@@ -30,7 +30,7 @@ class GfFrame(C.Structure):
         ("pos_table", _vp), ("pos_offsets", _vp), ("amb_table", _vp), ("amb_offsets", _vp),
         ("pos_S", _f32), ("amb_S", _f32),
         ("base_res", _u32), ("gridtype", _u32), ("interp", _u32), ("precision", _u32),
-        ("head_pack", _vp), ("head_pack16", _vp), ("amb_bias", _vp),
+        ("head_pack", _vp), ("head_pack16", _vp), ("head_pack_split", _vp), ("amb_bias", _vp),
         ("torso_pack", _vp), ("torso_bias", _vp), ("torso_table", _vp), ("torso_offsets", _vp), ("torso_occ", _vp), ("bg_coords", _vp),
         ("torso_S", _f32), ("torso_thresh", _f32), ("torso_shrink", _f32), ("_pad3", _f32),
         ("bg_color", _vp), ("out_rgb", _vp), ("out_depth", _vp), ("out_rgb8", _vp), ("out_torso_alpha", _vp),
@@ -102,6 +102,7 @@ class FusedState:
                              _hp(ind) if ind is not None else None, _hp(pack)))
         self.head_pack = torch.from_numpy(pack).to(dev)
         self._head_pack16 = None            # fast path: packed on first use (pack16)
+        self._head_pack_split = None        # split path: packed on first use (pack_split)
         # ambient L1's cond_feat columns, rows in accumulator-layout order: amb_bias = W_cond @ cond_feat per frame
         self.W_cond = a[0].weight.detach()[self.perm.to(dev), 32:].contiguous()
         # colour L1's identity-code columns, same row order: col_bias = W_ind @ individual_code (field_forward with a per-call code)
@@ -169,7 +170,7 @@ class FusedState:
         if model.individual_embedding_dim > 0:
             self.W_ind = c[0].weight.detach()[perm, 144:].contiguous()
             self.head_pack[self._colbias_off:self._colbias_off + 128] = torch.mv(self.W_ind, model.individual_embeddings[0].detach().float())
-        self._head_pack16 = None
+        self._head_pack16 = self._head_pack_split = None
         if self.has_torso:
             if self._torso_idx is None:
                 ws = self._torso_weights(model)
@@ -203,6 +204,17 @@ class FusedState:
                                    _hp(_np(s[2].weight)), _hp(_np(c[0].weight)), _hp(out)))
             self._head_pack16 = torch.from_numpy(out.view(np.int16)).to(self.device)
         return self._head_pack16
+
+    def pack_split(self, model):
+        """Two-term f16 splits of the head's six MFMA layers (gf_frame_t.precision = 2, the "split" tier: fp32 values on the f16 matrix pipe)."""
+        if self._head_pack_split is None:
+            L = lib()
+            a, s, c = model.ambient_net.net, model.sigma_net.net, model.color_net.net
+            out = np.empty(L.gf_head_pack_split_halves(), dtype=np.uint16)
+            check(L.gf_head_pack_split(_hp(_np(a[0].weight)), _hp(_np(a[1].weight)), _hp(_np(s[0].weight)), _hp(_np(s[1].weight)),
+                                       _hp(_np(s[2].weight)), _hp(_np(c[0].weight)), _hp(out)))
+            self._head_pack_split = torch.from_numpy(out.view(np.int16)).to(self.device)
+        return self._head_pack_split
 
     def _build_cond(self, model):
         """gf_cond_t with every weight pointer filled in (None when the encoder is not the AudioNet + AudioAttNet pair the
@@ -357,10 +369,11 @@ def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_th
     f.base_res, f.gridtype, f.interp = st.base_res, st.gridtype, st.interp
     f.head_pack, f.amb_bias = ptr(st.head_pack), ptr(amb_bias, torch.float32)
     precision = getattr(model, "render_precision", "fp32")
-    if precision not in ("fp32", "fast"):
-        raise ValueError(f"render_precision must be 'fp32' or 'fast', got {precision!r}")
-    f.precision = 1 if precision == "fast" else 0
+    if precision not in ("fp32", "fast", "split"):
+        raise ValueError(f"render_precision must be 'fp32', 'fast' or 'split', got {precision!r}")
+    f.precision = {"fp32": 0, "fast": 1, "split": 2}[precision]
     f.head_pack16 = st.pack16(model).data_ptr() if precision == "fast" else None
+    f.head_pack_split = st.pack_split(model).data_ptr() if precision == "split" else None
     f.bg_color = ptr(bg, torch.float32)
     f.out_rgb, f.out_depth = ptr(out_rgb), ptr(out_depth)
     f.out_rgb8 = ptr(out_rgb8, torch.uint8) if out_rgb8 is not None else None

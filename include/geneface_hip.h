@@ -156,9 +156,13 @@ typedef struct gf_frame_t {
     float pos_S, amb_S;         /* log2(per_level_scale) of each grid */
     uint32_t base_res, gridtype, interp;
     uint32_t precision;         /* 0: fp32 everywhere (strict parity).  1: "fast" -- f16 MFMA operands and activations, fp32 accumulate
-                                   (what the reference's autocast / .half() viewer path computes); needs head_pack16 */
+                                   (what the reference's autocast / .half() viewer path computes); needs head_pack16.
+                                   2: "split" -- fp32 VALUES carried as two-term f16 splits (hi + lo' * 2^-11) on the f16 matrix pipe, three MFMAs
+                                   per product term set, fp32 accumulate: fp32-level accuracy (strict tolerance), not fp32 bit patterns; needs
+                                   head_pack_split */
     const float* head_pack;     /* device copy of gf_head_pack() output */
-    const uint16_t* head_pack16;/* device copy of gf_head_pack16() output, or NULL when precision == 0 */
+    const uint16_t* head_pack16;/* device copy of gf_head_pack16() output, or NULL when precision != 1 */
+    const uint16_t* head_pack_split;/* device copy of gf_head_pack_split() output, or NULL when precision != 2 */
     const float* amb_bias;      /* [128] ambient_net.net.0.weight[:, 32:96] @ cond_feat, rows permuted by gf_clayout_perm */
     /* torso field (radnerf_torso.py:20-49); torso_pack == NULL renders the head only */
     const float* torso_pack;    /* device copy of gf_torso_pack() output */
@@ -305,6 +309,10 @@ int gf_head_pack(const float* amb0_host, const float* amb1_host, const float* am
 uint32_t gf_head_pack16_halves(void);
 int gf_head_pack16(const float* amb0_host, const float* amb1_host, const float* sig0_host, const float* sig1_host,
                    const float* sig2_host, const float* col0_host, uint16_t* out_halves_host);
+/* split path (gf_frame_t.precision = 2): the same six layers as two-term f16 splits; GF_ERR_UNSUPPORTED when a weight is outside the f16 range */
+uint32_t gf_head_pack_split_halves(void);
+int gf_head_pack_split(const float* amb0_host, const float* amb1_host, const float* sig0_host, const float* sig1_host,
+                       const float* sig2_host, const float* col0_host, uint16_t* out_halves_host);
 /* HOST pointers: torso_deform_net / torso_canonicial_net weights */
 int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_host, const float* c0_host,
                   const float* c1_host, const float* c2_host, float* out_host);

@@ -84,10 +84,12 @@ def test_frame_256_vs_oracle(impl):
         total, hi, lo = sum(fs["samples"]), sum(t["n_valid"] for t in trace), sum(t["n_composited"] for t in trace)
         assert lo - max(16, 1e-3 * lo) <= total <= hi + max(16, 1e-3 * hi), (lo, total, hi)
         # what the compositor consumed is the reference's composited count (up to the rays whose transmittance sits within rounding of
-        # T_thresh), and the samples evaluated beyond it -- the rest of a dying ray's slots in its last round -- stay under 5 %
+        # T_thresh).  The samples evaluated beyond it are the rest of a dying ray's slots in its last round: never more than the reference's
+        # own iterations evaluate in vain (here, at 256x256, the pools are a third full and a ray gets 2-3 slots per round: ~10 %; at the
+        # headline 512x512 every pool is full, one slot per ray and round: < 5 %, asserted in test_frame_loop_512_head_torso_vs_oracle)
         comp = sum(fs["composited"])
         assert abs(comp - lo) <= max(16, 1e-3 * lo), (comp, lo)
-        assert total - comp <= 0.05 * total, (total, comp)
+        assert total - comp <= hi - lo, (total, comp, hi, lo)
         assert fs["n_hit"] == trace[1]["n_alive"] or abs(fs["n_hit"] - trace[0]["n_valid"]) == 0
     elif hasattr(model, "last_schedule") and model.last_schedule:
         # the n_step schedule is a discrete function of the alive counts: it must be identical; the counts themselves may
@@ -646,7 +648,7 @@ def test_fast_tier_edge_cases():
     _check_fast(render_gpu(m, hp, fi_r), ref)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("precision", ["fp32", "fast", "split"])
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
 def test_frames_in_flight_do_not_interfere(in_flight, precision):
     """Several frames enqueued on separate streams share the model, the packed weights and the tables but nothing else (one workspace,
@@ -703,7 +705,7 @@ def test_pipeline_depth_follows_the_scene(thin, monkeypatch):
     assert pipe.in_flight == (3 if thin else 4)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("precision", ["fp32", "fast", "split"])
 def test_full_size_frames_are_reproducible(precision):
     """Run-to-run reproducibility where it was once lost: at 512x512 the persistent head grid puts two workgroups on every CU (a 160x160
     frame leaves each CU with one, which is why the test above never saw it).  The fast tier's 2-D grid lookup then dropped one corner of
@@ -752,6 +754,10 @@ def test_frame_loop_512_head_torso_vs_oracle(seed):
     fi = frame_inputs(seq, 1)
     ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
     check(render_gpu(model, hp, fi), ref, True)
+    from geneface_amd.fused import frame_stats
+    fs = frame_stats(model.last_ctrl, 512 * 512, hp["max_steps"])
+    total, comp = sum(fs["samples"]), sum(fs["composited"])
+    assert 0 <= total - comp <= 0.05 * total, (total, comp)     # field evaluations a terminating ray no longer needed: < 5 % at the headline shape
     pipe = FramePipeline(model, hp, seq, DEV, impl="fused")
     frame = pipe.render_frame(1)
     pipe.wait()
@@ -827,3 +833,126 @@ def test_ops_path_and_stand_alone_encoders_are_reproducible():
         r1, r2 = sh(d), fq(d)
         for rep in range(8):
             assert torch.equal(sh(d), r1) and torch.equal(fq(d), r2), rep
+
+
+# ----------------------------------------------------------------------------------------------- round 3: the split tier (precision = 2)
+# fp32 VALUES carried as two-term f16 splits on the f16 matrix pipe (frame_head.hip, field_round_split): not fp32 bit patterns, but
+# fp32-level accuracy -- so it is held to the STRICT bar of BASELINE.md section 4 (check(): max|d rgb| < 1e-4, PSNR > 65 dB, >= 99.9 % of
+# the bytes within 1 LSB, depth < 2e-4, torso maps < 2e-5), on the same frames as the fp32 tier.
+def _split_model(torso, sd=None, hp_over=None):
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd0 = model_fixture(torso)
+    hp = dict(hp, **(hp_over or {}))
+    m = (RADNeRFTorso if torso else RADNeRF)(hp)
+    m.load_state_dict(sd if sd is not None else sd0, strict=True)
+    m.render_impl, m.render_precision = "fused", "split"
+    return hp, (sd if sd is not None else sd0), m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("torso", [False, True])
+@pytest.mark.parametrize("size,idx", [(64, 1), (96, 3)])
+def test_split_tier_golden_frames(torso, size, idx):
+    hp, sd, model = _split_model(torso)
+    fi = frame_inputs(sequence(4, size, size), idx)
+    check(render_gpu(model, hp, fi), np.load(os.path.join(GOLD, f"frame_{'torso' if torso else 'head'}_{size}.npz")), torso)
+
+
+def test_split_tier_256_vs_oracle_and_fp32_tier():
+    """Strict bar against the oracle, the reference's n_step schedule replayed exactly (the schedule is a discrete function of which rays
+    terminated when: the split arithmetic must not move it), and the distance to the fp32 tier of the same library."""
+    from geneface_amd.fused import frame_stats
+    hp, sd, model = _split_model(True)
+    fi = frame_inputs(sequence(4, 256, 256), 0)
+    trace = []
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True, trace=trace)
+    out = render_gpu(model, hp, fi)
+    check(out, ref, True)
+    fs = frame_stats(model.last_ctrl, 256 * 256, hp["max_steps"])
+    assert [n for _, n in fs["schedule"]] == [t["n_step"] for t in trace]
+    assert fs["budget"] == fs["budget_device"] == sum(t["n_step"] for t in trace)
+    for (a, _), t in zip(fs["schedule"], trace):
+        assert abs(a - t["n_alive"]) <= max(3, 1e-3 * t["n_alive"]), (a, t["n_alive"])
+    _, _, m32 = build(True, "fused")
+    o32 = render_gpu(m32, hp, fi)
+    assert (o32["rgb_map"] - out["rgb_map"]).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1000])
+def test_split_tier_512_head_torso_vs_oracle(seed):
+    """configs[2] / configs[4] at the headline shape on the split tier: module API (strict bar) and the pose-mode frame loop (uint8)."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = _identity_model(seed)
+    model.render_precision = "split"
+    seq = sequence(4, 512, 512, seed=5 if seed else 0)
+    fi = frame_inputs(seq, 1)
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+    check(render_gpu(model, hp, fi), ref, True)
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused")
+    frame = pipe.render_frame(1)
+    pipe.wait()
+    ref8 = (ref["rgb_map"] * 255).view(512, 512, 3).to(torch.uint8)
+    d = (frame.int() - ref8.int()).abs()
+    assert int(d.max()) <= 1 and (d == 0).float().mean().item() > 0.999
+    assert psnr(frame.float() / 255, ref8.float() / 255) > 55
+
+
+def test_split_tier_edge_cases_and_grid_variants():
+    """Empty / full occupancy, the three budget regimes (max_steps 4 / 16 / 64), ragged ray counts, thin density (no early termination:
+    every sample of every ray contributes), the other grid index rules -- all at the strict bar."""
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 64, 64), 0)
+    empty = dict(sd, density_bitfield=torch.zeros_like(sd["density_bitfield"]))
+    _, _, m = _split_model(True, empty)
+    out = render_gpu(m, hp, fi)
+    check(out, R.render(empty, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True), True)
+    assert float(out["depth_map"].abs().max()) == 0.0
+    hp_h, sd_h = model_fixture(False)
+    full = dict(sd_h, density_bitfield=torch.full_like(sd_h["density_bitfield"], 255))
+    fi48 = frame_inputs(sequence(4, 48, 48), 2)
+    for ms in (4, 16, 64):
+        hpm, _, m = _split_model(False, full, dict(max_steps=ms))
+        ref = R.render(full, hpm, fi48["rays_o"], fi48["rays_d"], fi48["cond"], fi48["bg_coords"], fi48["pose6"], fi48["bg"], False)
+        check_small(render_gpu(m, hpm, fi48), ref)
+    idx = torch.linspace(0, 64 * 64 - 1, 37 * 5).long()
+    fi_r = dict(fi, rays_o=fi["rays_o"][:, idx].contiguous(), rays_d=fi["rays_d"][:, idx].contiguous(),
+                bg_coords=fi["bg_coords"][:, idx].contiguous(), bg=fi["bg"][:, idx].contiguous())
+    _, _, m = _split_model(True)
+    check(render_gpu(m, hp, fi_r), R.render(sd, hp, fi_r["rays_o"], fi_r["rays_d"], fi_r["cond"], fi_r["bg_coords"], fi_r["pose6"], fi_r["bg"], True), True)
+    from geneface_amd import synthetic as S
+    thin = S.make_state_dict(hp, True, sigma_row_scale=0.02)
+    _, _, m = _split_model(True, thin)
+    fi96 = frame_inputs(sequence(4, 96, 96), 2)
+    check(render_gpu(m, hp, fi96), R.render(thin, hp, fi96["rays_o"], fi96["rays_d"], fi96["cond"], fi96["bg_coords"], fi96["pose6"], fi96["bg"], True), True)
+    for grid_type, interp in (("hashgrid", "linear"), ("hashgrid", "smoothstep"), ("tiledgrid", "smoothstep")):
+        hpg, _, m = _split_model(True, None, dict(grid_type=grid_type, grid_interpolation_type=interp))
+        check(render_gpu(m, hpg, fi96), R.render(sd, hpg, fi96["rays_o"], fi96["rays_d"], fi96["cond"], fi96["bg_coords"], fi96["pose6"], fi96["bg"], True), True)
+
+
+def test_split_tier_survives_tiny_and_large_values():
+    """The two ends of the f16 range.  Grid tables scaled down by 2^-12 (features ~1e-4 and below -- the reference's own table init is
+    U(-1e-4, 1e-4), grid.py:138-140) with the first layers scaled up to compensate: the hi term of such a value is an f16 denormal or zero,
+    the scaled lo' term carries it.  And first-layer weights scaled up / hidden activations in the hundreds.  Strict bar both times."""
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 96, 96), 1)
+    k = 2.0 ** -12
+    tiny = dict(sd)
+    for name in ("position_embedder.embeddings", "ambient_embedder.embeddings"):
+        tiny[name] = sd[name] * k
+    tiny["ambient_net.net.0.weight"] = sd["ambient_net.net.0.weight"].clone()
+    tiny["ambient_net.net.0.weight"][:, :32] /= k
+    tiny["sigma_net.net.0.weight"] = sd["sigma_net.net.0.weight"] / k
+    _, _, m = _split_model(True, tiny)
+    check(render_gpu(m, hp, fi), R.render(tiny, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True), True)
+    big = dict(sd)
+    big["sigma_net.net.0.weight"] = sd["sigma_net.net.0.weight"] * 64.0        # hidden activations x64 ...
+    big["sigma_net.net.1.weight"] = sd["sigma_net.net.1.weight"] / 64.0        # ... undone by the next layer: the same field, other magnitudes inside
+    _, _, m = _split_model(True, big)
+    check(render_gpu(m, hp, fi), R.render(big, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True), True)
+    # a weight beyond the f16 range cannot be split: refused at pack time, loudly
+    bad = dict(sd)
+    bad["color_net.net.0.weight"] = sd["color_net.net.0.weight"].clone()
+    bad["color_net.net.0.weight"][3, 20] = 1e5
+    _, _, m = _split_model(True, bad)
+    with pytest.raises(RuntimeError, match="f16 range"):
+        render_gpu(m, hp, fi)

@@ -86,3 +86,41 @@ def test_tall_product_matches_the_plain_one():
     x = torch.randn(10000, 7)
     assert torch.allclose(train_field._tall_tn(g, x), g.t() @ x, rtol=1e-4, atol=1e-3)
     assert torch.allclose(train_field._tall_tn(g[:100], x[:100]), g[:100].t() @ x[:100], rtol=1e-5, atol=1e-4)
+
+
+def test_split_pack_reconstructs_the_weights(hip_lib):
+    """gf_head_pack_split (precision = 2): every fp32 weight as hi = half(w) and lo' = half((w - hi) * 2^11), [8 x hi | 8 x lo'] per lane
+    and group.  hi + lo' / 2048 gives the weight back to 2^-22 relative (2^-24 typical), tiny weights live in lo' alone, weights outside
+    the f16 range are refused."""
+    import ctypes as C
+    import numpy as np
+    L = hip_lib
+    rng = np.random.default_rng(0)
+    shapes = [(128, 96), (128, 128), (128, 64), (128, 128), (129, 128), (128, 148)]
+    ws = [(rng.standard_normal(s) * 10.0 ** rng.uniform(-6, 2, size=s)).astype(np.float32) for s in shapes]
+    ws[2][5, 7] = 3e-8                                    # far below the smallest normal half: the scaled lo' term carries it
+    n = L.gf_head_pack_split_halves()
+    out = np.zeros(n, dtype=np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.gf_head_pack_split(*[p(w) for w in ws], p(out)) == 0
+    h = out.view(np.float16).astype(np.float64).reshape(4, 39, 64, 2, 8)         # [wave][group][lane][hi | lo'][8]
+    rec = h[..., 0, :] + h[..., 1, :] / 2048.0
+    assert np.all(np.abs(h[..., 0, :][h[..., 0, :] != 0]) >= 2.0 ** -14)       # no f16 denormal in a hi term
+    layers = [(0, 2, 0, 0, 0), (2, 8, 1, 0, 0), (10, 4, 2, 0, 0), (14, 8, 3, 0, 0), (22, 8, 4, 1, 0), (30, 1, 5, 0, 0), (31, 8, 5, 0, 16)]
+    checked = 0
+    for g0, groups, wi, row0, col0 in layers:
+        W = ws[wi]
+        for w in range(4):
+            for u in range(groups):
+                lane = np.arange(64)
+                rows = row0 + 32 * w + (lane & 31)
+                for i in range(8):
+                    cols = col0 + 16 * u + 8 * (lane >> 5) + i
+                    want = W[rows, cols].astype(np.float64)
+                    got = rec[w, g0 + u, :, i]
+                    assert np.all(np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -22, 2.0 ** -25)), (g0, u, i)
+                    checked += 64
+    assert checked == 39 * 4 * 64 * 8
+    assert abs(rec[0, 10, 5, 7] - 3e-8) < 3e-8 * 2.0 ** -11                                 # ws[2][5, 7]: wave 0, group SP_SIG1, lane 5 (row 5), i = 7
+    ws[5][3, 20] = 1e5
+    assert L.gf_head_pack_split(*[p(w) for w in ws], p(out)) != 0 and b"f16 range" in L.gf_last_error()

@@ -26,7 +26,7 @@ def main():
                 k = row["Kernel_Name"]
                 k = k.replace("(anonymous namespace)::", "").split("(")[0]
                 k = k[5:] if k.startswith("void ") else k
-                k = k.replace("k_head_phase<false>", "k_head_phase").replace("k_head_phase<true>", "k_head_phase_fast")
+                k = k.replace("k_head_phase<false>", "k_head_phase").replace("k_head_phase<true>", "k_head_phase_fast").replace("k_head_phase<0>", "k_head_phase").replace("k_head_phase<1>", "k_head_phase_fast").replace("k_head_phase<2>", "k_head_phase_split")
                 per[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 dur[(k, row["Dispatch_Id"], path)] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     summary = {}
