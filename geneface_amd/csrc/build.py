@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = False, trace: bool = False, varia
         results = list(ex.map(lambda s: _compile(s, force, extra, obj_dir), sources()))
     objs = [o for o, _ in results]
     if force or any(ch for _, ch in results) or not os.path.exists(out):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out]
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out, "-lz", "-lpthread"]   # zlib: the PNG frame writer (png_writer.cpp)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

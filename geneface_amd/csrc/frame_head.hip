@@ -894,9 +894,10 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
 // ---------------------------------------------------------------------------------------------------- split path (fp32 values on the f16 matrix pipe)
 // precision = 2.  The fp32 kernel is bound by the f32 matrix rate (64 cycles per 32x32x2 MFMA: 80 K cycles of pipe per wave and round); the
 // f16 instruction moves eight times the k-depth in half the cycles.  Here every fp32 value -- weight or activation -- is carried as
-//   v = hi + lo' * 2^-11,   hi = half(v) (round to nearest, |v| < 2^-14 -> 0),   lo' = half((v - hi) * 2^11)
-// which represents v to 2^-24 relative (the scaled lo' keeps the residual in the f16 NORMAL range down to |v| = 3e-8, so nothing depends on
-// how the matrix pipe treats f16 denormals), products of two halves are exact in the fp32 accumulators, and
+//   v = hi + lo' * 2^-11,   hi = half(v) (round to nearest),   lo' = half((v - hi) * 2^11)
+// which represents v to 2^-24 relative (the scaled lo' keeps the residual of every |v| >= 2^-14 in the f16 normal range; below that hi is an f16
+// denormal with 2^-25 absolute resolution and lo' refines it further -- the matrix pipe and v_cvt_f16_f32 honour f16 denormals on gfx950,
+// tools/mfma_denorm_probe.hip), products of two halves are exact in the fp32 accumulators, and
 //   w * x = hi_w hi_x + (lo'_w hi_x + hi_w lo'_x) 2^-11 + O(2^-22)
 // costs three v_mfma_f32_32x32x16_f16 per 16 input features and tile (acc1 for the first term, acc2 for the two cross terms): 468 MFMAs of 32
 // cycles per wave and round instead of 1 248 of 64.  Errors against the fp32 kernel are of the size of its own rounding (different
@@ -923,42 +924,63 @@ __device__ __forceinline__ void wpipes_refill(WPipeS& wp, const char* __restrict
 template <bool RELU>
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     const float c = __builtin_amdgcn_fmed3f(v, RELU ? 0.0f : -65504.0f, 65504.0f);
-    const float ch = fabsf(c) < 6.103515625e-05f ? 0.0f : c;       // no f16 denormal in the hi term
-    hi = (_Float16)ch;
-    lo = (_Float16)((c - (float)hi) * gf::kSplitScale);
+    hi = (_Float16)c;                                               // may be an f16 denormal: v_cvt_f16_f32 produces them and the MFMA honours them
+    // (c - hi) * 2^11, exactly (the difference has at most 13 significant bits), as ONE fused op on the f16 register: v_fma_mix_f32
+    lo = (_Float16)__builtin_fmaf((float)hi, -gf::kSplitScale, c * gf::kSplitScale);   // (tools/mfma_denorm_probe.hip, profiles/round3/mfma_denorm_probe.txt)
 }
 
 // U groups (K = 16 each) of this wave's output block over nt tiles.  Hb = &H[lane & 31][8 * (lane >> 5)] (hi part; lo' 128 halves on).
-template <int G0, int U, int u>
-__device__ __forceinline__ void obws_step(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
-                                          floatx16 (&a2)[4], int nt) {
-    if constexpr (u < U) {
-        // B operands one tile ahead of the MFMAs that consume them (two tiles' worth of registers, not four: the accumulators of the two
-        // product terms already take 128 of the 256 a lane has at two workgroups per CU)
-        half8 bh = *reinterpret_cast<const half8*>(Hb + 16 * u), bl = *reinterpret_cast<const half8*>(Hb + 16 * u + 128);
-        const half8 wh = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][0]), wl = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][1]);
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (t < nt) {
-                half8 nh = bh, nl = bl;
-                if (t + 1 < nt) {
-                    nh = *reinterpret_cast<const half8*>(Hb + (t + 1) * 32 * kHSS + 16 * u);
-                    nl = *reinterpret_cast<const half8*>(Hb + (t + 1) * 32 * kHSS + 16 * u + 128);
-                }
-                a1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2[t], 0, 0, 0);
-                a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2[t], 0, 0, 0);
-                bh = nh; bl = nl;
-            }
-        wpipes_refill<G0 + u>(wp, Ws, lane32);
-        __builtin_amdgcn_sched_barrier(0);
-        obws_step<G0, U, u + 1>(wp, Ws, lane32, Hb, a1, a2, nt);
+// B operands run ONE tile ahead of the MFMAs that consume them within a group (two tiles' worth of registers, not four: the accumulators of
+// the two product terms already take 128 of the 256 a lane has at two workgroups per CU; carrying the prefetch across group boundaries in
+// two alternating register sets spilled 67 VGPRs).
+__device__ __forceinline__ void bset_load(half8& h, half8& l, const _Float16* p) {
+    h = *reinterpret_cast<const half8*>(p);
+    l = *reinterpret_cast<const half8*>(p + 128);
+}
+// one tile of one group: MFMAs from set (bh, bl); the other set (oh, ol) receives the next tile's operands -- or, behind an odd tile (which
+// reads set 1), set 0 takes tile 0 of the next group.  No register copies: the two sets alternate with the tile index.
+template <int T, int u, int U>
+__device__ __forceinline__ void obws_tile(const half8& wh, const half8& wl, const _Float16* Hb, floatx16& a1, floatx16& a2, int nt, const half8& bh,
+                                          const half8& bl, half8& oh, half8& ol) {
+    if (T < nt) {
+        if (T + 1 < nt) bset_load(oh, ol, Hb + (T + 1) * 32 * kHSS + 16 * u);
+#ifndef GF_SPLIT_NO_XPREFETCH
+        else if ((T & 1) && u + 1 < U) bset_load(oh, ol, Hb + 16 * (u + 1));
+#endif
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2, 0, 0, 0);
     }
 }
-template <int G0, int U>
+template <int G0, int U, int u>
+__device__ __forceinline__ void obws_step(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
+                                          floatx16 (&a2)[4], int nt, half8& b0h, half8& b0l, half8& b1h, half8& b1l) {
+    if constexpr (u < U) {
+        const half8 wh = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][0]), wl = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][1]);
+#ifndef GF_SPLIT_NO_XPREFETCH
+        if (u > 0 && (nt & 1)) bset_load(b0h, b0l, Hb + 16 * u);     // odd tile count (a thin round): set 0 was busy until the end of the last group
+#else
+        if (u > 0) bset_load(b0h, b0l, Hb + 16 * u);
+#endif
+        obws_tile<0, u, U>(wh, wl, Hb, a1[0], a2[0], nt, b0h, b0l, b1h, b1l);
+        obws_tile<1, u, U>(wh, wl, Hb, a1[1], a2[1], nt, b1h, b1l, b0h, b0l);
+        obws_tile<2, u, U>(wh, wl, Hb, a1[2], a2[2], nt, b0h, b0l, b1h, b1l);
+        obws_tile<3, u, U>(wh, wl, Hb, a1[3], a2[3], nt, b1h, b1l, b0h, b0l);
+        wpipes_refill<G0 + u>(wp, Ws, lane32);
+        __builtin_amdgcn_sched_barrier(0);
+        obws_step<G0, U, u + 1>(wp, Ws, lane32, Hb, a1, a2, nt, b0h, b0l, b1h, b1l);
+    }
+}
+template <int G0, int U, bool FIRST, bool BIAS = false>
 __device__ __forceinline__ void obws_mfma(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
                                           floatx16 (&a2)[4], int nt) {
-    obws_step<G0, U, 0>(wp, Ws, lane32, Hb, a1, a2, nt);
+    // FIRST: the layer starts here.  (A literal-zero C operand in the first group's MFMAs would save the 128 register clears, but leaves the
+    // accumulators of the tiles beyond nt undefined, and the allocator then spills 66 VGPRs: measured, not kept.)
+    if (FIRST) { if (!BIAS) obw_zero<4>(a1); obw_zero<4>(a2); }
+    half8 b0h, b0l, b1h, b1l;
+    bset_load(b0h, b0l, Hb);
+    b1h = b0h; b1l = b0l;
+    obws_step<G0, U, 0>(wp, Ws, lane32, Hb, a1, a2, nt, b0h, b0l, b1h, b1l);
 }
 
 // accumulators -> split activations.  Hw = &H[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves, twice.
@@ -1028,11 +1050,6 @@ __device__ __forceinline__ void store16s(_Float16* dst, const float (&f)[16]) {
     }
 }
 
-__device__ __forceinline__ void obws_init(const float* bias16_or_null, floatx16 (&a1)[4], floatx16 (&a2)[4]) {
-    if (bias16_or_null) obw_bias<4>(bias16_or_null, a1); else obw_zero<4>(a1);
-    obw_zero<4>(a2);
-}
-
 __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
@@ -1065,14 +1082,13 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     }
     __syncthreads();
     // ---- ambient L1 (cond_feat folded into the bias)
-    obws_init(s.P + P_AMBBIAS + wave * 32 + half * 16, A1, A2);
-    obws_mfma<gf::SP_AMB1, 2>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obw_bias<4>(s.P + P_AMBBIAS + wave * 32 + half * 16, A1);
+    obws_mfma<gf::SP_AMB1, 2, true, true>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<true>(Hw, A1, A2, nt);
     __syncthreads();
     // ---- ambient L2
-    obws_init(nullptr, A1, A2);
-    obws_mfma<gf::SP_AMB2, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<gf::SP_AMB2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<true>(Hw, A1, A2, nt);
     __syncthreads();
@@ -1089,31 +1105,28 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     }
     __syncthreads();
     // ---- density L1: K = 64
-    obws_init(nullptr, A1, A2);
-    obws_mfma<gf::SP_SIG1, 4>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<gf::SP_SIG1, 4, true>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<true>(Hw, A1, A2, nt);
     __syncthreads();
     // ---- density L2
-    obws_init(nullptr, A1, A2);
-    obws_mfma<gf::SP_SIG2, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<gf::SP_SIG2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<true>(Hw, A1, A2, nt);
     __syncthreads();
     // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
-    float sigma = 0.0f;
     if (tile_on) {
         float h0[1];
         rows_from_lds_split<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
-        sigma = expf(h0[0]);
+        if (valid && half == 0) s.sx[raw] = expf(h0[0]);     // the position slots were consumed before the first barrier of this function
     }
-    obws_init(nullptr, A1, A2);
-    obws_mfma<gf::SP_SIG3, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<gf::SP_SIG3, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<false>(Hw, A1, A2, nt);
     __syncthreads();
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
-    obws_init(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1, A2);
+    obw_bias<4>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1);
+    obw_zero<4>(A2);
     {
         const half8 wh = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][0]), wl = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][1]);
 #pragma unroll
@@ -1143,7 +1156,7 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         wpipes_refill<gf::SP_COL1S>(wp, Ws, lane32);
         __builtin_amdgcn_sched_barrier(0);
     }
-    obws_mfma<gf::SP_COL1G, 8>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<gf::SP_COL1G, 8, false>(wp, Ws, lane32, Hb, A1, A2, nt);
     __syncthreads();
     obws_store<true>(Hw, A1, A2, nt);
     __syncthreads();
@@ -1152,7 +1165,6 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         float c[3];
         rows_from_lds_split<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
         if (valid && half == 0) {
-            s.sx[raw] = sigma;
             s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
             s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
             s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
@@ -1201,6 +1213,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     if (a.pool_cap_override) pool_cap = a.pool_cap_override;
 #endif
     if ((uint32_t)blockIdx.x * pool_cap >= limit) return;  // not even one refill's worth of work for this workgroup
+    // the three loop-invariant scalars live in LDS from here on (s.misc[13..15]): with ~100 SGPRs already parked in VGPR lanes the allocator
+    // put them into scratch instead, and a launch that touches scratch at all pays for it
+    if (tid == 0) { s.misc[13] = budget; s.misc[14] = limit; s.misc[15] = pool_cap; }
 #ifdef GF_DIAG
     if (a.poison) {   // any read of LDS this workgroup has not written itself now returns NaN (fp32 and f16 views alike)
         __syncthreads();
@@ -1224,10 +1239,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
 
     // pooled ray of this lane (owners only): everything the marcher and the compositor carry between rounds
     int ray = -1;
-    float r_ox = 0, r_oy = 0, r_oz = 0, r_dx = 0, r_dy = 0, r_dz = 1, r_t = 0, r_far = 0;
+    // (the direction lives in LDS by pool slot, p_dx/p_dy/p_dz, where the SH evaluation reads it too; the origin is the camera's in pose mode
+    // and is re-read per round otherwise: six registers less across the MFMA segments, where all three kernels sit at the 256-register limit)
+    float r_t = 0, r_far = 0;
     gf::RayAcc acc = {0, 0, 0, 0, 0, 0};
     uint32_t r_done = 0;
-    uint32_t st_samples = 0, st_rounds = 0, st_tiles = 0;  // statistics (thread 0)
+    // statistics: s.misc[10..12] = samples, rounds, tiles of this workgroup (thread 0 adds per round; LDS, not three registers)
+    if (tid == 0) { s.misc[10] = 0; s.misc[11] = 0; s.misc[12] = 0; }
     bool queue_open = true;         // uniform
 #ifdef GF_TRACE
     uint32_t tr_round = 0;
@@ -1250,7 +1268,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
 #endif
         // ------------------------------------------------------------------ refill empty pool slots from the queue
         if (queue_open && wave < 2) {  // wave-uniform branch
-            const bool want = ray < 0 && (uint32_t)tid < pool_cap;
+            const bool want = ray < 0 && (uint32_t)tid < s.misc[15];
             const unsigned long long m = __ballot(want);
             const uint32_t nw = (uint32_t)__popcll(m);
             uint32_t base = 0;
@@ -1258,16 +1276,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             base = __shfl(base, 0);
             if (want) {
                 const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (idx < limit) {
+                if (idx < s.misc[14]) {
                     ray = a.queue[idx];
                     const float* d = a.rays_d + (size_t)ray * 3;
-                    if (a.pose_mode) {
-                        r_ox = a.cam_o[0]; r_oy = a.cam_o[1]; r_oz = a.cam_o[2];
-                    } else {
-                        const float* o = a.rays_o + (size_t)ray * 3;
-                        r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
-                    }
-                    r_dx = d[0]; r_dy = d[1]; r_dz = d[2];
                     r_t = a.rays_t[ray];
                     r_far = a.far_occ[ray];
                     if (a.phase == 0) {
@@ -1277,10 +1288,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                         acc.r = a.image[(size_t)ray * 3]; acc.g = a.image[(size_t)ray * 3 + 1]; acc.b = a.image[(size_t)ray * 3 + 2];
                     }
                     r_done = 0;
-                    s.p_dx[tid] = r_dx; s.p_dy[tid] = r_dy; s.p_dz[tid] = r_dz;
+                    s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
                 }
             }
-            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= limit) ? 1u : 0u;  // this wave saw the end of the queue
+            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
         }
         GF_STAMP(1);
         // ------------------------------------------------------------------ pool census
@@ -1308,10 +1319,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         const uint32_t extra = 0u;
 #endif
         // ------------------------------------------------------------------ A. march
-        uint32_t cnt = 0, req = 0, rank = 0;
+        uint32_t mcnt = 0, req = 0, rank = 0;
         if (alive) {
             rank = (wave ? s.misc[0] : 0u) + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
-            const uint32_t left = budget - r_done;
+            const uint32_t left = s.misc[13] - r_done;
             const uint32_t mine = n + (rank < extra ? 1u : 0u);
             req = mine < left ? mine : left;
             const uint32_t base = rank * n + (rank < extra ? rank : extra);
@@ -1320,7 +1331,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             // would have discovered in the next one -- where it held a pool slot and produced nothing: one empty slot per exiting ray,
             // 10 % of all slots.  If there is one, the ray clock is rewound to its start, where the next round's march begins anyway.
             float t_next = 0.0f;
-            cnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u, r_t,
+            float r_ox = a.cam_o[0], r_oy = a.cam_o[1], r_oz = a.cam_o[2];
+            if (!a.pose_mode) {
+                const float* o = a.rays_o + (size_t)ray * 3;
+                r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
+            }
+            const float r_dx = s.p_dx[tid], r_dy = s.p_dy[tid], r_dz = s.p_dz[tid];
+            mcnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u, r_t,
                                 [&](uint32_t q, float x, float y, float z, float dt, float t_after, float t_at) {
                                     if (q >= req) { t_next = t_at; return; }
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
@@ -1337,10 +1354,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                                     s.dkey[base + q] = key;
 #endif
                                 }, req + 1u + kMarchSlack);
-            if (cnt > req) { cnt = req; r_t = t_next; }
+            if (mcnt > req) { mcnt = req; r_t = t_next; }
         }
         GF_STAMP(3);
-        if (owner) s.rcnt[tid] = (uint8_t)cnt;
+        if (owner) s.rcnt[tid] = (uint8_t)mcnt;
         __syncthreads();
         GF_STAMP(4);
         if (wave == 0) {  // exclusive scan of 128 counts, two per lane
@@ -1361,9 +1378,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         if (alive) {
             const uint32_t b = s.rbase[tid];
             const uint32_t base = rank * n + (rank < extra ? rank : extra);
-            for (uint32_t q = 0; q < cnt; q++) { s.d2r[b + q] = (uint8_t)(base + q); s.rrank[b + q] = (uint8_t)tid; }
+            for (uint32_t q = 0; q < mcnt; q++) { s.d2r[b + q] = (uint8_t)(base + q); s.rrank[b + q] = (uint8_t)tid; }
         }
-        if (tid == 0) { st_samples += Mv; st_rounds++; st_tiles += (Mv + 31) / 32; }
+        if (tid == 0) { s.misc[10] += Mv; s.misc[11] += 1u; s.misc[12] += (Mv + 31) / 32; }
         GF_STAMP(5);
 
         // ------------------------------------------------------------------ B. field
@@ -1386,7 +1403,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         // ------------------------------------------------------------------ C. composite, retire
         bool survivor = false;
         if (alive) {
-            const uint32_t base = rank * n + (rank < extra ? rank : extra);
+            // this ray's sample count and first raw slot come back from LDS (the scan left them there): two registers less across the field
+            const uint32_t cnt = s.rcnt[tid];
+            const uint32_t base = cnt ? (uint32_t)s.d2r[s.rbase[tid]] : 0u;
             bool died = false;
             uint32_t d = 0;
             for (uint32_t q = 0; q < cnt; q++) {
@@ -1410,7 +1429,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 died = true;
                 d = r_done + 1;
             }
-            const bool finished = !died && r_done == budget;
+            const bool finished = !died && r_done == s.misc[13];
             if (died || finished) {
                 atomicAdd(&s.misc[9], r_done);   // statistics: what this ray's compositor consumed in this phase
                 a.weights_sum[ray] = acc.weight_sum;
@@ -1444,22 +1463,25 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     }
 
     __syncthreads();
-    if (a.phase == 0 && tid >= 1 && tid <= (int)a.max_steps) {
-        const uint32_t v = s.hist[tid];
-        if (v) atomicAdd(&a.ctrl[gf::kCtrlHist + tid], v);
+    {   // the lane index is re-derived here (mbcnt) rather than kept: the allocator had parked `4 * tid` in scratch from the first line to this one
+        const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (a.phase == 0 && tid_e >= 1 && tid_e <= (int)a.max_steps) {
+            const uint32_t v = s.hist[tid_e];
+            if (v) atomicAdd(&a.ctrl[gf::kCtrlHist + tid_e], v);
+        }
     }
 #ifdef GF_TRACE
     if (tid == 0 && a.spans) {   // per-workgroup lifetime (s_memtime offsets differ between CUs: only differences are meaningful)
         unsigned long long* sp = a.spans + ((size_t)a.phase * 512 + blockIdx.x) * 8;
-        sp[0] = span_t0; sp[1] = span_t1; sp[2] = (unsigned long long)st_rounds | ((unsigned long long)st_samples << 32);
+        sp[0] = span_t0; sp[1] = span_t1; sp[2] = (unsigned long long)s.misc[11] | ((unsigned long long)s.misc[10] << 32);
         sp[3] = __builtin_amdgcn_s_getreg(63508 /* HW_REG_XCC_ID */); sp[4] = span_r0; sp[5] = span_r1;
         sp[6] = __builtin_amdgcn_s_memtime(); sp[7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     if (tid == 0) {
-        atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], st_samples);
-        atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], st_rounds);
-        atomicAdd(&a.ctrl[gf::kCtrlTiles + a.phase], st_tiles);
+        atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], s.misc[10]);
+        atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], s.misc[11]);
+        atomicAdd(&a.ctrl[gf::kCtrlTiles + a.phase], s.misc[12]);
         atomicAdd(&a.ctrl[gf::kCtrlComposited + a.phase], s.misc[9]);
     }
 }

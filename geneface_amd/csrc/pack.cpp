@@ -115,8 +115,7 @@ GF_EXPORT int gf_head_pack_split(const float* amb0, const float* amb1, const flo
                     for (uint32_t i = 0; i < 8; i++) {
                         const float v = W[(size_t)(row0 + 32 * w + (l & 31u)) * ld + col0 + 16 * u + 8 * (l >> 5) + i];
                         if (!(v >= -65504.0f && v <= 65504.0f)) ok = false;
-                        _Float16 hi = (_Float16)v;
-                        if (v > -6.103515625e-05f && v < 6.103515625e-05f) hi = (_Float16)0.0f;      // no f16 denormals in the hi term (see split_f16, frame_head.hip)
+                        const _Float16 hi = (_Float16)v;       // round to nearest; may be an f16 denormal (honoured by the matrix pipe: split_f16, frame_head.hip)
                         const _Float16 lo = (_Float16)((v - (float)hi) * kSplitScale);
                         uint16_t* dst = out_halves + (((size_t)w * SP_TOTAL + g0 + u) * 64 + l) * 16;
                         memcpy(dst + i, &hi, sizeof(uint16_t));

@@ -34,7 +34,7 @@ def header_prototypes(path: str = HEADER_PATH):
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     protos = []
-    for m in re.finditer(r"\b(int|uint32_t|uint64_t|const char\*)\s+(gf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int|uint32_t|uint64_t|const char\*|void\*)\s+(gf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         parsed = []
         if args and args != "void":
@@ -50,7 +50,7 @@ def header_prototypes(path: str = HEADER_PATH):
 def _bind(lib):
     for ret, name, args in header_prototypes():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
-        fn.restype = {"int": C.c_int, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64}.get(ret, C.c_char_p)
+        fn.restype = {"int": C.c_int, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "void*": C.c_void_p}.get(ret, C.c_char_p)
         argtypes = []
         for typ, _ in args:
             if typ in _CTYPE:

@@ -1,7 +1,7 @@
 """Minimal PNG (8-bit RGB) writer / reader on zlib -- the frame output contract of the reference's loop
 (inference/nerfs/base_nerf_infer.py:97-101: `cv2.imwrite(f"{tmp_imgs_dir}/{idx:05d}.png", rgb->bgr)`, i.e. a PNG file holding the
-RGB picture) without cv2, which this image does not ship.  Encoding runs on a small thread pool so it never sits on the render
-thread (the reference encodes synchronously between frames)."""
+RGB picture) without cv2, which this image does not ship.  The frame loop's writer (FrameWriter) runs on native threads of the library
+(csrc/png_writer.cpp); encode_rgb8 / decode_rgb8 are the pure-Python pair the tests and the background-image loader use."""
 import os
 import struct
 import zlib
@@ -49,28 +49,50 @@ def decode_rgb8(data: bytes) -> np.ndarray:
 
 
 class FrameWriter:
-    """Writes frames as `<dir>/<idx:05d>.png` on worker threads; `close()` waits for all of them."""
+    """Writes frames as `<dir>/<idx:05d>.png` on NATIVE worker threads (gf_png_writer_* of libgeneface_hip.so: deflate + CRC + file write with
+    no interpreter lock anywhere on the path); `close()` waits for all of them.  Round 2 ran zlib.compress on a Python thread pool: the
+    workers need the interpreter lock between their zlib calls while the render thread holds it for most of a frame -- 0.75-0.84 of the
+    render rate.  strategy: zlib's (0 default, 3 = Z_RLE: half the deflate time, ~1.3x the bytes)."""
 
-    def __init__(self, out_dir: str, workers: int = 4, level: int = 1, max_pending: int = None):
+    def __init__(self, out_dir: str, workers: int = 4, level: int = 1, max_pending: int = None, strategy: int = 0):
         os.makedirs(out_dir, exist_ok=True)
-        self.out_dir, self.level = out_dir, level
-        self._pool = ThreadPoolExecutor(max_workers=workers)
-        self._futures = []
+        self.out_dir, self.level, self.workers, self.strategy = out_dir, level, workers, strategy
         self._max_pending = max_pending or 4 * workers   # frames copied but not yet encoded: bounds host memory
-
-    def _write(self, idx: int, img: np.ndarray):
-        with open(os.path.join(self.out_dir, f"{idx:05d}.png"), "wb") as fh:
-            fh.write(encode_rgb8(img, self.level))
+        self._h, self._shape, self._stats = None, None, None
 
     def submit(self, idx: int, img: np.ndarray):
         """Takes a private copy of `img` (callers hand in views of reused pinned buffers: FramePipeline.stream) and queues the encode.
         Blocks while `max_pending` frames are waiting, so a renderer faster than the encoders cannot grow the queue without bound."""
-        while len(self._futures) >= self._max_pending:
-            self._futures.pop(0).result()
-        self._futures.append(self._pool.submit(self._write, idx, np.array(img, dtype=np.uint8, order="C", copy=True)))
+        from .lib import check, lib
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("FrameWriter.submit expects uint8 [H, W, 3]")
+        if not img.flags["C_CONTIGUOUS"]:
+            img = np.ascontiguousarray(img)
+        if self._h is None:
+            self._shape = img.shape
+            self._h = lib().gf_png_writer_create(os.fsencode(self.out_dir), img.shape[0], img.shape[1], self.workers, self.level, self.strategy, self._max_pending)
+            if not self._h:
+                raise RuntimeError(lib().gf_last_error().decode())
+        elif img.shape != self._shape:
+            raise ValueError(f"FrameWriter: frame {img.shape} after frames of {self._shape}")
+        check(lib().gf_png_writer_submit(self._h, int(idx), img.ctypes.data))
 
     def close(self):
-        for f in self._futures:
-            f.result()
-        self._pool.shutdown()
-        self._futures = []
+        if self._h is not None:
+            import ctypes as C
+            from .lib import lib
+            st = (C.c_double * 6)()
+            h, self._h = self._h, None
+            rc = lib().gf_png_writer_close(h, C.cast(st, C.c_void_p))
+            self._stats = list(st)
+            if rc != 0:
+                raise RuntimeError(lib().gf_last_error().decode())
+
+    def stage_seconds(self):
+        """After close(): where the host time went -- seconds copying frames in and waiting for queue room (submit side), deflating and
+        writing (summed over the workers), frames and bytes written."""
+        if self._stats is None:
+            return None
+        k = ("copy_in", "wait_for_room", "deflate_sum_over_workers", "write_sum_over_workers", "frames", "bytes")
+        return dict(zip(k, self._stats))

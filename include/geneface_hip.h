@@ -324,6 +324,17 @@ int gf_render_torso(const gf_frame_t* frame, void* stream);
  * launches (k_head_phase), [2] k_frame_init (ray generation + the march through empty space); *n_phases_host = 3 */
 int gf_render_head_timed(const gf_frame_t* frame, void* stream, float* phase_ms_host, uint32_t* n_phases_host);
 
+/* ------------------------------------------------------------------------------------------------
+ * Frame files.  inference/nerfs/base_nerf_infer.py:97-101 writes every frame as <tmp_imgs_dir>/<idx:05d>.png (cv2.imwrite) between two
+ * frames; here native worker threads deflate and write while the GPU renders on.  HOST pointers only; 8-bit RGB PNG, filter type 0.
+ * level 0..9 and strategy 0..4 are zlib's (Z_DEFAULT_STRATEGY 0, Z_FILTERED 1, Z_HUFFMAN_ONLY 2, Z_RLE 3, Z_FIXED 4).
+ * ---------------------------------------------------------------------------------------------- */
+void* gf_png_writer_create(const char* dir, uint32_t H, uint32_t W, uint32_t workers, int level, int strategy, uint32_t max_pending);
+int gf_png_writer_submit(void* handle, uint32_t idx, const uint8_t* rgb_host);   /* copies the frame; blocks while max_pending frames wait */
+int gf_png_writer_close(void* handle, double* stats_out_host);                   /* drains, joins, frees; stats [6] or NULL (see png_writer.cpp) */
+int gf_png_encode_rgb8(const uint8_t* rgb_host, uint32_t H, uint32_t W, int level, int strategy, uint8_t* out_host, uint64_t cap_bytes,
+                       uint64_t* n_bytes_host);
+
 #ifdef __cplusplus
 }
 #endif

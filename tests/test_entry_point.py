@@ -96,9 +96,8 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         ref = R.render(sd, hp, ro, rd, torch.from_numpy(samples[i]["cond_wins"]), bgc, R.convert_poses(pose), bg, torso=True)
         ref8 = (ref["rgb_map"] * 255).view(64, 64, 3).to(torch.uint8)
         got = torch.from_numpy(frames[i])
-        d = (got.int() - ref8.int()).abs()
-        assert int(d.max()) <= 1 and (d == 0).float().mean().item() > 0.999
-        assert psnr(got.float() / 255, ref8.float() / 255) > 55
+        from test_gpu_render import check_u8
+        check_u8(got, ref8)          # >= 99.9 % of the bytes identical, <= 1 LSB, PSNR >= 55 dB, up to 4 grazing-ray pixels excepted
 
 
 def _save_reference_checkpoint(path, model_sd, step, extra_children=True):
@@ -207,11 +206,31 @@ def test_png_writer_roundtrip(tmp_path):
     buf = np.zeros((64, 64, 3), dtype=np.uint8)
     for i in range(12):
         buf[...] = i
-        w.submit(i, buf)
-        assert len(w._futures) <= 3                                        # the queue is bounded
+        w.submit(i, buf)                                                   # blocks while 3 frames wait: the queue is bounded
     w.close()
+    st = w.stage_seconds()
+    assert st["frames"] == 12 and st["bytes"] > 0 and st["deflate_sum_over_workers"] > 0
     for i in range(12):
         assert (decode_rgb8(open(tmp_path / "reused" / f"{i:05d}.png", "rb").read()) == i).all()
+    # the native encoder and the pure-Python one agree on the pixels, and a stock reader (Pillow, where installed) reads the files
+    import ctypes as C
+    from geneface_amd.lib import lib
+    img = rng.integers(0, 256, size=(33, 17, 3), dtype=np.uint8)
+    out, n = np.empty(1 << 16, dtype=np.uint8), C.c_uint64(0)
+    for strategy in (0, 2, 3):
+        assert lib().gf_png_encode_rgb8(img.ctypes.data, 33, 17, 1, strategy, out.ctypes.data, out.size, C.cast(C.byref(n), C.c_void_p)) == 0
+        np.testing.assert_array_equal(decode_rgb8(out[:n.value].tobytes()), img)
+    try:
+        from PIL import Image
+        np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "imgs" / "00003.png")), frames[3])
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError):                                      # a directory that cannot be written: the error surfaces, loudly
+        bad = FrameWriter(str(tmp_path / "imgs2"), workers=1)
+        os.rmdir(tmp_path / "imgs2")
+        (tmp_path / "imgs2").write_bytes(b"")                               # a FILE where the directory was
+        bad.submit(0, buf)
+        bad.close()
     with pytest.raises(ValueError):
         encode_rgb8(np.zeros((4, 4), dtype=np.uint8))
 

@@ -105,7 +105,6 @@ def test_split_pack_reconstructs_the_weights(hip_lib):
     assert L.gf_head_pack_split(*[p(w) for w in ws], p(out)) == 0
     h = out.view(np.float16).astype(np.float64).reshape(4, 39, 64, 2, 8)         # [wave][group][lane][hi | lo'][8]
     rec = h[..., 0, :] + h[..., 1, :] / 2048.0
-    assert np.all(np.abs(h[..., 0, :][h[..., 0, :] != 0]) >= 2.0 ** -14)       # no f16 denormal in a hi term
     layers = [(0, 2, 0, 0, 0), (2, 8, 1, 0, 0), (10, 4, 2, 0, 0), (14, 8, 3, 0, 0), (22, 8, 4, 1, 0), (30, 1, 5, 0, 0), (31, 8, 5, 0, 16)]
     checked = 0
     for g0, groups, wi, row0, col0 in layers:
@@ -118,9 +117,9 @@ def test_split_pack_reconstructs_the_weights(hip_lib):
                     cols = col0 + 16 * u + 8 * (lane >> 5) + i
                     want = W[rows, cols].astype(np.float64)
                     got = rec[w, g0 + u, :, i]
-                    assert np.all(np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -22, 2.0 ** -25)), (g0, u, i)
+                    assert np.all(np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -22, 2.0 ** -35)), (g0, u, i)
                     checked += 64
     assert checked == 39 * 4 * 64 * 8
-    assert abs(rec[0, 10, 5, 7] - 3e-8) < 3e-8 * 2.0 ** -11                                 # ws[2][5, 7]: wave 0, group SP_SIG1, lane 5 (row 5), i = 7
+    assert abs(rec[0, 10, 5, 7] - 3e-8) < 2.0 ** -35                                 # ws[2][5, 7]: wave 0, group SP_SIG1, lane 5 (row 5), i = 7
     ws[5][3, 20] = 1e5
     assert L.gf_head_pack_split(*[p(w) for w in ws], p(out)) != 0 and b"f16 range" in L.gf_last_error()
