@@ -176,7 +176,10 @@ constexpr uint32_t kGbThreads = 1024;
 constexpr uint32_t kGbLdsEntries = 16384;   // int64 accumulators: 128 KiB, one workgroup per CU
 constexpr uint32_t kGbMaxParts = 8;
 constexpr float kGbFixedOne = 1099511627776.0f;   // 2^40: one quantum = 9e-13 of the level's largest gradient; 2^23 contributions of full size fit an int64
-constexpr float kGbSmall = 16384.0f;              // contributions below 2^14 quanta (1.5e-8 of the largest gradient) would lose more than 2^-15 of their
+#ifndef GF_GB_SMALL
+#define GF_GB_SMALL 16384.0f
+#endif
+constexpr float kGbSmall = GF_GB_SMALL;              // contributions below 2^14 quanta (1.5e-8 of the largest gradient) would lose more than 2^-15 of their
                                                   // value to the rounding: they take a float atomic into the table instead (rare; keeps every entry's
                                                   // RELATIVE accuracy, which is what Adam with eps = 1e-15 -- tasks/radnerfs/radnerf.py:63 -- steps by)
 

@@ -87,7 +87,7 @@ class FramePipeline:
             # The fourth frame only pays when the frames are light on phase 1: a thin-density scene (37 % of the hit rays survive their
             # first max_steps samples, 1.2 M samples per frame) loses 4.5 % with it (536 -> 512 fps), the saturating fixture (6 %) gains
             # 2 %.  So: start with three, look at the first finished frame's survivor count, then decide once.
-            if getattr(model, "render_precision", "fp32") == "fp32" and queues >= 8 and overlap and pinned_outputs is None \
+            if getattr(model, "render_precision", "fp32") in ("fp32", "split") and queues >= 8 and overlap and pinned_outputs is None \
                     and (impl or model.render_impl) == "fused" and self.device.type == "cuda":
                 self._grow_to = 4
         self.in_flight = max(1, int(in_flight)) if overlap else 1

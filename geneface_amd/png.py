@@ -52,9 +52,12 @@ class FrameWriter:
     """Writes frames as `<dir>/<idx:05d>.png` on NATIVE worker threads (gf_png_writer_* of libgeneface_hip.so: deflate + CRC + file write with
     no interpreter lock anywhere on the path); `close()` waits for all of them.  Round 2 ran zlib.compress on a Python thread pool: the
     workers need the interpreter lock between their zlib calls while the render thread holds it for most of a frame -- 0.75-0.84 of the
-    render rate.  strategy: zlib's (0 default, 3 = Z_RLE: half the deflate time, ~1.3x the bytes)."""
+    render rate.  strategy: zlib's.  Default 3 = Z_RLE at level 1: measured on rendered 512x512 frames (tools/png_bench.py,
+    profiles/round3/png_bench.json) 4.8 ms of deflate per frame and 0.66 MB files against 9.3 ms and 0.40 MB for the default strategy -- 32
+    workers encode 3 750 frames/s instead of 1 550, above what one GPU renders on any tier; the files are an intermediate the reference
+    deletes after the ffmpeg mux (base_nerf_infer.py:307-317).  strategy=0 gives the smaller files."""
 
-    def __init__(self, out_dir: str, workers: int = 4, level: int = 1, max_pending: int = None, strategy: int = 0):
+    def __init__(self, out_dir: str, workers: int = 4, level: int = 1, max_pending: int = None, strategy: int = 3):
         os.makedirs(out_dir, exist_ok=True)
         self.out_dir, self.level, self.workers, self.strategy = out_dir, level, workers, strategy
         self._max_pending = max_pending or 4 * workers   # frames copied but not yet encoded: bounds host memory
