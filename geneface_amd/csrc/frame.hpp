@@ -123,5 +123,16 @@ constexpr uint32_t TP_C3 = TP_D3 + 2 * 64;           // VALU rows [4][32]
 constexpr uint32_t TP_TOTAL = TP_C3 + 4 * 32;
 // per-frame torso bias vector: [64 deform L1 | 32 canonical L1], accumulator-layout order
 constexpr uint32_t TB_TOTAL = 96;
+// torso_head_aware extension (radnerf_torso.py:36-46): the 16 encoder outputs are 8 more steps of both first layers (lane half h supplies
+// encoder output 8h + t), as two extra streams in the layout above, followed by head_color_weights_encoder itself in nn.Linear layout
+constexpr uint32_t TH_D1E = 0;                       // deform L1, encoder columns 104..119: NOB=2, 8 steps
+constexpr uint32_t TH_C1E = TH_D1E + 2 * 8 * 64;     // canonical L1, encoder columns 136..151: NOB=1, 8 steps
+constexpr uint32_t TH_W0 = TH_C1E + 1 * 8 * 64;      // [16][4]
+constexpr uint32_t TH_B0 = TH_W0 + 64;               // [16]
+constexpr uint32_t TH_W1 = TH_B0 + 16;               // [32][16]
+constexpr uint32_t TH_B1 = TH_W1 + 512;              // [32]
+constexpr uint32_t TH_W2 = TH_B1 + 32;               // [16][32]
+constexpr uint32_t TH_B2 = TH_W2 + 512;              // [16]
+constexpr uint32_t TH_TOTAL = TH_B2 + 16;
 
 }  // namespace gf

@@ -1896,6 +1896,7 @@ struct InitArgs {
     float pose[12]; float fx, fy, cx, cy; uint32_t img_w;
     const float* aabb; float min_near;
     float occ[6]; uint32_t has_occ;
+    const float* noise;   // [N] or NULL: first-iteration jitter of perturb=True (renderer.py:338-342, raymarching.cu:851)
     float *rays_o, *rays_d, *nears, *fars, *far_occ, *rays_t, *weights_sum, *depth, *image;
     int* hit_list; uint32_t* ctrl; uint32_t N;
 };
@@ -1939,7 +1940,7 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
         }
         // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there
         float t = near, t_first = near;
-        const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far_m, 0.0f, 1u, t,
+        const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far_m, a.noise ? a.noise[n] : 0.0f, 1u, t,
                                            [&](uint32_t, float, float, float, float, float, float t_at) { t_first = t_at; });
         hit = got > 0;
         miss = !hit;
@@ -2011,6 +2012,7 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ia.img_w = f->img_w ? f->img_w : 1;
     ia.aabb = f->aabb; ia.min_near = f->min_near;
     ia.has_occ = f->has_occ_aabb;
+    ia.noise = f->perturb_noise;
     // pad the box by a hundredth of a cell: the slab test and the marcher's o + t*d round differently
     const float pad = 0.01f * 2.0f * f->bound / (float)f->grid_size;
     for (int i = 0; i < 3; i++) {

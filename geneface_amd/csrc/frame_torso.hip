@@ -25,7 +25,54 @@ struct TorsoArgs {
     const float *pack, *bias, *table; const int* offsets;
     gf::GridLevels lv;
     float *out_rgb, *out_depth, *out_alpha, *out_torso_rgb, *out_deform; uint8_t* out_rgb8;
+    const float* ha;       // head-aware extension pack (frame.hpp TH_*), HA launches only
+    const float* ha_enc;   // [N,16] encoder outputs (k_head_aware_encode), HA launches only
 };
+
+__device__ __forceinline__ float leaky02(float x) { return x > 0.0f ? x : 0.02f * x; }
+
+// head_color_weights_encoder (radnerf_torso.py:38-44: Linear(4,16) LeakyReLU(0.02) Linear(16,32) LeakyReLU Linear(32,16)) of every pixel's
+// accumulated head colour + opacity (radnerf_torso.py:68-74), one lane per pixel, into enc16 [N,16].  A launch of its own in front of
+// k_torso_finish<true>: inside that kernel its ~50 temporaries pushed 170 registers into scratch.  Weights are read as wave-uniform LDS
+// broadcasts.  1 088 FMAs per pixel; only head-aware models (base.yaml:90 default: off) ever launch it.
+__global__ void __launch_bounds__(kThreads) k_head_aware_encode(uint32_t N, const float* __restrict__ image, const float* __restrict__ weights_sum,
+                                                                const float* __restrict__ ha_pack, float* __restrict__ enc16) {
+    __shared__ float w[gf::TH_TOTAL - gf::TH_W0];
+    for (int i = threadIdx.x; i < (int)(gf::TH_TOTAL - gf::TH_W0); i += kThreads) w[i] = ha_pack[gf::TH_W0 + i];
+    __syncthreads();
+    const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= N) return;
+    const float* W0 = w; const float* B0 = w + (gf::TH_B0 - gf::TH_W0); const float* W1 = w + (gf::TH_W1 - gf::TH_W0);
+    const float* B1 = w + (gf::TH_B1 - gf::TH_W0); const float* W2 = w + (gf::TH_W2 - gf::TH_W0); const float* B2 = w + (gf::TH_B2 - gf::TH_W0);
+    const float in4[4] = {image[(size_t)n * 3], image[(size_t)n * 3 + 1], image[(size_t)n * 3 + 2], weights_sum[n]};
+    float h0[16], h1[32];
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+        float v = B0[o];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v = __builtin_fmaf(W0[o * 4 + k], in4[k], v);
+        h0[o] = leaky02(v);
+    }
+#pragma unroll
+    for (int o = 0; o < 32; o++) {
+        float v = B1[o];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v = __builtin_fmaf(W1[o * 16 + k], h0[k], v);
+        h1[o] = leaky02(v);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float e[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = B2[4 * q + i];
+#pragma unroll
+            for (int k = 0; k < 32; k++) v = __builtin_fmaf(W2[(4 * q + i) * 32 + k], h1[k], v);
+            e[i] = v;
+        }
+        reinterpret_cast<float4*>(enc16 + (size_t)n * 16)[q] = float4{e[0], e[1], e[2], e[3]};
+    }
+}
 
 // F.grid_sample(input[1,1,G,G], grid[..., (x,y)], bilinear, zeros padding, align_corners=True) at one location:
 // x indexes the last axis, y the one before it.
@@ -51,9 +98,11 @@ __device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
     return sinf(scalbnf(d ? x1 : x0, freq) + phase);
 }
 
+template <bool HA>
 __global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* pack = reinterpret_cast<float*>(smem_raw);   // [TP_TOTAL]
+    float* ha = reinterpret_cast<float*>(smem_raw);     // [TH_W0]: the two extra weight streams (HA launches only)
+    float* pack = ha + (HA ? gf::TH_W0 : 0);            // [TP_TOTAL]
     float* bias = pack + gf::TP_TOTAL;                  // [TB_TOTAL]
     float* meta = bias + gf::TB_TOTAL;                  // [64]
     float* o_a = meta + 64;                             // [256] per local pixel: alpha, r, g, b, dx0, dx1
@@ -85,6 +134,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a)
     if (Mt > 0) {  // workgroup-uniform
         for (int i = tid; i < (int)gf::TP_TOTAL / 4; i += kThreads) reinterpret_cast<float4*>(pack)[i] = reinterpret_cast<const float4*>(a.pack)[i];
         if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
+        if constexpr (HA) {
+            for (int i = tid; i < (int)gf::TH_W0 / 4; i += kThreads) reinterpret_cast<float4*>(ha)[i] = reinterpret_cast<const float4*>(a.ha)[i];
+        }
         if (tid < 16) {
             meta[tid * 4 + 0] = a.lv.scale[tid];
             meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
@@ -101,13 +153,24 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a)
             const uint32_t pix = blockIdx.x * kThreads + p;
             const float x0 = a.bg_coords[(size_t)pix * 2] * a.shrink, x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
 
+            float e8[8];
+            if constexpr (HA) {   // encoder output 8 * half + t of this pixel (k_head_aware_encode): the B operand of the 8 extra steps of both first layers
+                const float4* e4 = reinterpret_cast<const float4*>(a.ha_enc + (size_t)pix * 16 + 8 * half);
+                const float4 u = e4[0], v = e4[1];
+                e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
+            }
             float enc[24];
 #pragma unroll
             for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
 
             floatx16 h2[2];
             float act2[32];
-            gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+            if constexpr (HA) {
+                gf::mfma_layer<2, 24, false, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+                gf::mfma_part<2, 0, 2, 8, true, true>(ha + gf::TH_D1E, lane, e8, nullptr, h2);
+            } else {
+                gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+            }
             gf::unpack<2>(h2, act2);
             gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
             gf::unpack<2>(h2, act2);
@@ -126,7 +189,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a)
             }
             floatx16 h1[1];
             float act1[16];
-            gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+            if constexpr (HA) {
+                gf::mfma_layer<1, 40, false, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+                gf::mfma_part<1, 0, 1, 8, true, true>(ha + gf::TH_C1E, lane, e8, nullptr, h1);
+            } else {
+                gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+            }
             gf::unpack<1>(h1, act1);
             gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
             gf::unpack<1>(h1, act1);
@@ -184,8 +252,21 @@ GF_EXPORT int gf_render_torso(const gf_frame_t* f, void* stream) {
     if (gf::fill_grid_levels(a.lv, 16, f->torso_S, f->base_res)) return gf_set_error(GF_ERR_INVALID, "torso: bad grid levels");
     a.out_rgb = f->out_rgb; a.out_depth = f->out_depth; a.out_alpha = f->out_torso_alpha; a.out_torso_rgb = f->out_torso_rgb;
     a.out_deform = f->out_deform; a.out_rgb8 = f->out_rgb8;
-    static GfLdsAttr lds;
-    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_torso_finish), (int)kTorsoSmem, "torso")) return e;
-    hipLaunchKernelGGL(k_torso_finish, dim3(gf_div_up(f->n_rays, (uint32_t)kThreads)), dim3(kThreads), kTorsoSmem, gf_stream(stream), a);
+    const bool ha = f->torso_ha_pack && f->torso_ha_branch;
+    a.ha = ha ? f->torso_ha_pack : nullptr;
+    a.ha_enc = nullptr;
+    if (ha) {
+        if (!f->torso_ha_ws) return gf_set_error(GF_ERR_INVALID, "torso: torso_ha_branch = 1 needs torso_ha_ws ([n_rays, 16] floats)");
+        hipLaunchKernelGGL(k_head_aware_encode, dim3(gf_div_up(f->n_rays, (uint32_t)kThreads)), dim3(kThreads), 0, gf_stream(stream), f->n_rays, w.image,
+                           w.weights_sum, f->torso_ha_pack, f->torso_ha_ws);
+        a.ha_enc = f->torso_ha_ws;
+    }
+    static GfLdsAttr lds[2];
+    const size_t smem = kTorsoSmem + (ha ? gf::TH_W0 * sizeof(float) : 0);
+    const void* fn = ha ? reinterpret_cast<const void*>(k_torso_finish<true>) : reinterpret_cast<const void*>(k_torso_finish<false>);
+    if (const int e = gf_raise_lds_limit(lds[ha], fn, (int)smem, "torso")) return e;
+    const dim3 grid(gf_div_up(f->n_rays, (uint32_t)kThreads));
+    if (ha) hipLaunchKernelGGL(k_torso_finish<true>, grid, dim3(kThreads), smem, gf_stream(stream), a);
+    else hipLaunchKernelGGL(k_torso_finish<false>, grid, dim3(kThreads), smem, gf_stream(stream), a);
     return gf_check_launch("render_torso");
 }

@@ -163,8 +163,8 @@ GF_EXPORT int gf_occupancy_aabb(const uint8_t* bitfield_host, uint32_t cascade, 
 //   d0 [64,104] d1 [64,64] d2 [2,64] | c0 [32,136] c1 [32,32] c2 [4,32].  out [gf_torso_pack_floats()]
 // d0 columns: [enc(x) 0..41 | enc(pose) 42..95 | code 96..103]; c0 columns: [grid 0..31 | enc(x) 32..73 | enc(pose)+code 74..135].
 // The pose/code columns are per-frame constants: the host folds them into torso_bias.
-GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, const float* c0, const float* c1, const float* c2,
-                            float* out) {
+static int torso_pack_impl(const float* d0, uint32_t ld_d0, const float* d1, const float* d2, const float* c0, uint32_t ld_c0, const float* c1,
+                           const float* c2, float* out) {
     using namespace gf;
     if (!d0 || !d1 || !d2 || !c0 || !c1 || !c2 || !out) return gf_set_error(GF_ERR_INVALID, "torso_pack: null pointer");
     memset(out, 0, sizeof(float) * TP_TOTAL);
@@ -177,9 +177,9 @@ GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, c
                 }
     };
     auto enc_col = [](uint32_t t, uint32_t h) { const uint32_t e = 24 * h + t; return e < 42 ? (int)e : -1; };
-    stream(out + TP_D1, d0, 104, 2, 24, enc_col);
+    stream(out + TP_D1, d0, ld_d0, 2, 24, enc_col);
     stream(out + TP_D2, d1, 64, 2, 32, [](uint32_t t, uint32_t h) { return (int)hidden_col(t, h); });
-    stream(out + TP_C1, c0, 136, 1, 40, [&](uint32_t t, uint32_t h) {
+    stream(out + TP_C1, c0, ld_c0, 1, 40, [&](uint32_t t, uint32_t h) {
         if (t < 16) return (int)(16 * h + t);            // 2-D grid features: levels 8h..8h+7
         const int e = enc_col(t - 16, h);
         return e < 0 ? -1 : 32 + e;
@@ -192,5 +192,33 @@ GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, c
     for (uint32_t c = 0; c < 4; c++)
         for (uint32_t h = 0; h < 2; h++)
             for (uint32_t r = 0; r < 16; r++) out[TP_C3 + c * 32 + h * 16 + r] = c2[(size_t)c * 32 + c_row(r, h)];
+    return GF_OK;
+}
+
+GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, const float* c0, const float* c1, const float* c2, float* out) {
+    return torso_pack_impl(d0, 104, d1, d2, c0, 136, c1, c2, out);
+}
+
+// torso_head_aware models (radnerf_torso.py:36-46): d0 [64,120], c0 [32,152]; out_ha layout: frame.hpp TH_*.
+GF_EXPORT uint32_t gf_torso_ha_pack_floats(void) { return gf::TH_TOTAL; }
+
+GF_EXPORT int gf_torso_pack_ha(const float* d0, const float* d1, const float* d2, const float* c0, const float* c1, const float* c2, const float* e0w,
+                               const float* e0b, const float* e1w, const float* e1b, const float* e2w, const float* e2b, float* out_main, float* out_ha) {
+    using namespace gf;
+    if (!e0w || !e0b || !e1w || !e1b || !e2w || !e2b || !out_ha) return gf_set_error(GF_ERR_INVALID, "torso_pack_ha: null pointer");
+    const int rc = torso_pack_impl(d0, 120, d1, d2, c0, 152, c1, c2, out_main);
+    if (rc) return rc;
+    memset(out_ha, 0, sizeof(float) * TH_TOTAL);
+    auto ext = [&](float* dst, const float* W, uint32_t ld, uint32_t nob, uint32_t col0) {
+        for (uint32_t ob = 0; ob < nob; ob++)
+            for (uint32_t t = 0; t < 8; t++)
+                for (uint32_t l = 0; l < 64; l++)
+                    dst[((ob * 2 + t / 4) * 64 + l) * 4 + (t & 3u)] = W[(size_t)(ob * 32 + (l & 31u)) * ld + col0 + 8 * (l >> 5) + t];
+    };
+    ext(out_ha + TH_D1E, d0, 120, 2, 104);
+    ext(out_ha + TH_C1E, c0, 152, 1, 136);
+    memcpy(out_ha + TH_W0, e0w, 64 * sizeof(float)); memcpy(out_ha + TH_B0, e0b, 16 * sizeof(float));
+    memcpy(out_ha + TH_W1, e1w, 512 * sizeof(float)); memcpy(out_ha + TH_B1, e1b, 32 * sizeof(float));
+    memcpy(out_ha + TH_W2, e2w, 512 * sizeof(float)); memcpy(out_ha + TH_B2, e2b, 16 * sizeof(float));
     return GF_OK;
 }

@@ -8,6 +8,7 @@ stream with no host synchronisation (the reference's loop, renderer.py:316-351, 
 Per-model state (packed weights, fold matrices, workspace) is built once and cached on the module.
 """
 import ctypes as C
+import random
 
 import numpy as np
 import torch
@@ -36,6 +37,7 @@ class GfFrame(C.Structure):
         ("bg_color", _vp), ("out_rgb", _vp), ("out_depth", _vp), ("out_rgb8", _vp), ("out_torso_alpha", _vp),
         ("out_torso_rgb", _vp), ("out_deform", _vp),
         ("workspace", _vp),
+        ("perturb_noise", _vp), ("torso_ha_pack", _vp), ("torso_ha_ws", _vp), ("torso_ha_branch", _u32), ("_pad4", _u32),
     ]
 
 
@@ -124,11 +126,17 @@ class FusedState:
         check(L.gf_occupancy_aabb(_hp(bits), int(model.cascade), int(model.grid_size), float(model.bound), _hp(box)))
         self.occ_aabb = [float(v) for v in box]
 
+        self.head_aware = bool(getattr(model, "torso_head_aware", False)) and self.has_torso
         if self.has_torso:
             d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
             tpack = np.empty(L.gf_torso_pack_floats(), dtype=np.float32)
-            check(L.gf_torso_pack(_hp(_np(d[0].weight)), _hp(_np(d[1].weight)), _hp(_np(d[2].weight)), _hp(_np(cn[0].weight)),
-                                  _hp(_np(cn[1].weight)), _hp(_np(cn[2].weight)), _hp(tpack)))
+            if self.head_aware:   # radnerf_torso.py:36-46: 16 encoder columns appended to both first layers
+                hpack = np.empty(L.gf_torso_ha_pack_floats(), dtype=np.float32)
+                check(L.gf_torso_pack_ha(*[_hp(_np(w)) for w in self._torso_weights(model)], _hp(tpack), _hp(hpack)))
+                self.torso_ha_pack = torch.from_numpy(hpack).to(dev)
+            else:
+                check(L.gf_torso_pack(_hp(_np(d[0].weight)), _hp(_np(d[1].weight)), _hp(_np(d[2].weight)), _hp(_np(cn[0].weight)),
+                                      _hp(_np(cn[1].weight)), _hp(_np(cn[2].weight)), _hp(tpack)))
             self.torso_pack = torch.from_numpy(tpack).to(dev)
             p64, p32 = self.perm[:64].to(dev), self.perm[:32].to(dev)
             # per-frame constants [enc(pose) 54 | code 8] fold into the first-layer biases
@@ -150,7 +158,22 @@ class FusedState:
     @staticmethod
     def _torso_weights(model):
         d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
-        return [d[0].weight, d[1].weight, d[2].weight, cn[0].weight, cn[1].weight, cn[2].weight]
+        ws = [d[0].weight, d[1].weight, d[2].weight, cn[0].weight, cn[1].weight, cn[2].weight]
+        if getattr(model, "torso_head_aware", False):
+            e = model.head_color_weights_encoder
+            ws += [e[0].weight, e[0].bias, e[2].weight, e[2].bias, e[4].weight, e[4].bias]
+        return ws
+
+    def _torso_codes(self, model):
+        """The per-frame constant vector the cond kernel folds into torso_bias behind enc(pose): the identity code and, for head-aware
+        models, the encoder's 16 outputs -- for the coin's 'no head' outcome the encoding of a black, transparent head (a constant,
+        radnerf_torso.py:69-71), for the other outcome zeros (the per-pixel encoding enters through the extra MFMA steps instead)."""
+        code = model.torso_individual_codes[0].detach().float() if model.torso_individual_embedding_dim > 0 else torch.zeros(0, device=self.device)
+        if not self.head_aware:
+            return (code.contiguous() if code.numel() else None), None
+        with torch.no_grad():
+            e0 = model.head_color_weights_encoder(torch.zeros(1, 4, device=self.device)).reshape(-1).float()
+        return torch.cat([code, e0]).contiguous(), torch.cat([code, torch.zeros_like(e0)]).contiguous()
 
     def refresh_weights(self, model):
         """The packed copies follow the model's current weights: per pack one cat + one gather on the device."""
@@ -172,21 +195,28 @@ class FusedState:
             self.head_pack[self._colbias_off:self._colbias_off + 128] = torch.mv(self.W_ind, model.individual_embeddings[0].detach().float())
         self._head_pack16 = self._head_pack_split = None
         if self.has_torso:
+            n_main = L.gf_torso_pack_floats()
             if self._torso_idx is None:
                 ws = self._torso_weights(model)
-                self._torso_idx = _pack_index(lambda arr, out: check(L.gf_torso_pack(*[_hp(a) for a in arr], _hp(out))),
-                                              [tuple(w.shape) for w in ws], L.gf_torso_pack_floats()).to(dev)
+                if self.head_aware:
+                    packer = lambda arr, out: check(L.gf_torso_pack_ha(*[_hp(a) for a in arr], _hp(out[:n_main]), _hp(out[n_main:])))
+                    n_out = n_main + L.gf_torso_ha_pack_floats()
+                else:
+                    packer, n_out = (lambda arr, out: check(L.gf_torso_pack(*[_hp(a) for a in arr], _hp(out)))), n_main
+                self._torso_idx = _pack_index(packer, [tuple(w.shape) for w in ws], n_out).to(dev)
             flat = torch.cat([zero] + [w.detach().reshape(-1).float() for w in self._torso_weights(model)])
-            self.torso_pack = flat[self._torso_idx]
+            both = flat[self._torso_idx]
+            self.torso_pack = both[:n_main].contiguous()
+            if self.head_aware:
+                self.torso_ha_pack = both[n_main:].contiguous()
             d, cn = model.torso_deform_net.net, model.torso_canonicial_net.net
             self.W_tconst = torch.cat([d[0].weight.detach()[perm[:64], 42:], cn[0].weight.detach()[perm[:32], 74:]], dim=0).contiguous()
-            if self.cond is not None and model.torso_individual_embedding_dim > 0:
-                self._torso_code = model.torso_individual_codes[0].detach().contiguous()
+            self._torso_code, self._torso_code_ha = self._torso_codes(model)
         if self.cond is not None:          # the cached gf_cond_t points at W_cond / W_tconst / the torso code
             self.cond.W_cond = ptr(self.W_cond)
             if self.has_torso:
                 self.cond.W_tconst = ptr(self.W_tconst)
-                self.cond.torso_code = ptr(self._torso_code) if getattr(self, "_torso_code", None) is not None else None
+                self.cond.torso_code = ptr(self._torso_code) if self._torso_code is not None else None
 
     def refresh_occupancy(self, model):
         bits = np.ascontiguousarray(model.density_bitfield.detach().cpu().numpy().astype(np.uint8))
@@ -244,8 +274,8 @@ class FusedState:
         c.W_cond = ptr(self.W_cond)
         if self.has_torso:
             c.W_tconst = ptr(self.W_tconst)
-            c.code_dim = int(model.torso_individual_embedding_dim)
-            self._torso_code = model.torso_individual_codes[0].detach().contiguous() if c.code_dim > 0 else None
+            self._torso_code, self._torso_code_ha = self._torso_codes(model)
+            c.code_dim = int(self._torso_code.numel()) if self._torso_code is not None else 0
             c.torso_code = ptr(self._torso_code) if self._torso_code is not None else None
         if L.gf_cond_check(C.byref(c)) != 0:
             return None   # window / encoder outside the kernel's limits: the torch modules serve it
@@ -270,8 +300,9 @@ class FusedState:
         if model.position_embedder.num_levels != 16 or model.ambient_embedder.num_levels != 16:
             raise NotImplementedError("fused path: grids must have 16 levels")
         if hasattr(model, "torso_deform_net"):
-            tshapes = {"torso_deform_net.net.0.weight": (64, 104), "torso_deform_net.net.1.weight": (64, 64), "torso_deform_net.net.2.weight": (2, 64),
-                       "torso_canonicial_net.net.0.weight": (32, 136), "torso_canonicial_net.net.1.weight": (32, 32),
+            ha = 16 if getattr(model, "torso_head_aware", False) else 0     # radnerf_torso.py:36-46: the head-colour encoding widens both first layers
+            tshapes = {"torso_deform_net.net.0.weight": (64, 104 + ha), "torso_deform_net.net.1.weight": (64, 64), "torso_deform_net.net.2.weight": (2, 64),
+                       "torso_canonicial_net.net.0.weight": (32, 136 + ha), "torso_canonicial_net.net.1.weight": (32, 32),
                        "torso_canonicial_net.net.2.weight": (4, 32)}
             for k, shp in tshapes.items():
                 if tuple(sd[k].shape) != shp:
@@ -380,8 +411,20 @@ def _fill_common(f: GfFrame, model, st: FusedState, N, dt_gamma, max_steps, T_th
     f.workspace = st.workspace(N, slot)[0].data_ptr()
 
 
-def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_alpha, out_trgb, out_deform):
+def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_alpha, out_trgb, out_deform, ha_branch=False, slot=0):
     te = model.torso_embedder
+    if st.head_aware and ha_branch:     # the torso sees the rendered head (radnerf_torso.py:175-177): encoder outputs per pixel, 8 extra MFMA steps
+        N = int(f.n_rays)
+        if not hasattr(st, "_ha_ws"):
+            st._ha_ws = {}
+        key = (N, slot)
+        if key not in st._ha_ws:
+            if len(st._ha_ws) >= 8:
+                st._ha_ws.pop(next(iter(st._ha_ws)))
+            st._ha_ws[key] = torch.empty(N, 16, dtype=torch.float32, device=st.device)
+        f.torso_ha_pack, f.torso_ha_ws, f.torso_ha_branch = ptr(st.torso_ha_pack), st._ha_ws[key].data_ptr(), 1
+    else:
+        f.torso_ha_pack, f.torso_ha_ws, f.torso_ha_branch = None, None, 0
     f.torso_pack, f.torso_bias = ptr(st.torso_pack), ptr(torso_bias, torch.float32)
     f.torso_table, f.torso_offsets = ptr(te.embeddings, torch.float32), ptr(te.offsets, torch.int32)
     f.torso_occ, f.bg_coords = ptr(model.density_grid_torso, torch.float32), ptr(bg_coords, torch.float32)
@@ -393,7 +436,13 @@ def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_al
     f.out_deform = ptr(out_deform) if out_deform is not None else None
 
 
-def cond_encode_batch(model, st, cond_wins, poses6=None):
+def head_aware_coin(model) -> bool:
+    """radnerf_torso.py:175-179: with torso_head_aware the reference flips a coin PER FRAME, at inference too -- heads: the torso field sees
+    the head's colour and opacity at each pixel; tails: zeros.  Same draw (random.random() < 0.5) so a seeded run decides alike."""
+    return bool(getattr(model, "torso_head_aware", False)) and random.random() < 0.5
+
+
+def cond_encode_batch(model, st, cond_wins, poses6=None, ha_branch=False):
     """gf_cond_encode_batch: the condition encoder + both bias folds for n frames in ONE launch on the current stream.
     cond_wins [n, S, T, C] fp32 contiguous, poses6 [n, 6] or None -> (cond_feat [n, A], amb_bias [n, 128], torso_bias [n, 96] or None);
     row k is bit-identical to the single-frame launch on frame k.  None when the encoder is not the AudioNet + AudioAttNet pair the kernel
@@ -411,17 +460,19 @@ def cond_encode_batch(model, st, cond_wins, poses6=None):
     if poses6 is not None:
         p6 = poses6.reshape(n, 6).float().contiguous()
         call.pose6, call.torso_bias = ptr(p6), ptr(torso_bias)
+        if st.head_aware:     # which constant rides behind the identity code: enc(black, transparent head), or zeros (per-pixel encoding elsewhere)
+            call.torso_code = ptr(st._torso_code_ha if ha_branch else st._torso_code)
     else:
         call.torso_bias = None
     check(lib().gf_cond_encode_batch(C.byref(call), n, current_stream(dev)))
     return cond_feat, amb_bias, torso_bias
 
 
-def _per_frame_vectors(model, st, cond, poses6=None):
+def _per_frame_vectors(model, st, cond, poses6=None, ha_branch=False):
     """cond encoder + the per-frame bias folds: one HIP launch (gf_cond_encode) on the current stream; the torch modules only
     when the encoder is not the AudioNet + AudioAttNet pair (or the window shape is outside the kernel's limits)."""
     if cond.dim() == 3:
-        r = cond_encode_batch(model, st, cond[None], poses6)
+        r = cond_encode_batch(model, st, cond[None], poses6, ha_branch)
         if r is not None:
             return r[0][0], r[1][0], (r[2][0] if r[2] is not None else None)
     cond_feat = model.cal_cond_feat(cond).reshape(-1).float()
@@ -431,18 +482,31 @@ def _per_frame_vectors(model, st, cond, poses6=None):
         v = [model.torso_pose_embedder(poses6.reshape(1, 6).float()).reshape(-1)]
         if model.torso_individual_embedding_dim > 0:
             v.append(model.torso_individual_codes[0].detach())
+        if st.head_aware:
+            e0 = model.head_color_weights_encoder(torch.zeros(1, 4, device=st.device)).reshape(-1).float()
+            v.append(torch.zeros_like(e0) if ha_branch else e0)
         torso_bias = torch.mv(st.W_tconst, torch.cat(v))
     return cond_feat, amb_bias, torso_bias
 
 
 def _check_args(perturb, max_steps):
-    if perturb:
-        raise NotImplementedError("fused render path: perturb=True (training / GUI jitter) is only available with render_impl='ops'")
     if max_steps > 64:
         raise NotImplementedError("fused render path: max_steps > 64 is only available with render_impl='ops'")
 
 
-def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh):
+def _perturb_noise(perturb, perturb_noise, N, dev):
+    """perturb=True at inference (renderer.py:338-342): U[0,1) per ray for the first march iteration -- the caller's draws, or fresh ones."""
+    if not perturb:
+        return None
+    if perturb_noise is None:
+        return torch.rand(N, dtype=torch.float32, device=dev)
+    noise = perturb_noise.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    if noise.numel() != N:
+        raise ValueError(f"perturb_noise: {noise.numel()} draws for {N} rays")
+    return noise
+
+
+def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh, perturb_noise=None):
     """NeRFRenderer.render (renderer.py:263-367, inference) on the fused path."""
     _check_args(perturb, max_steps)
     with torch.no_grad():
@@ -458,13 +522,15 @@ def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, b
         f = GfFrame()
         _fill_common(f, model, st, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth)
         f.rays_o, f.rays_d = ptr(rays_o), ptr(rays_d)
+        noise = _perturb_noise(perturb, perturb_noise, N, dev)
+        f.perturb_noise = ptr(noise) if noise is not None else None
         check(lib().gf_render_head(C.byref(f), current_stream(dev)))
         model.last_ctrl = st.workspace(N)[1]
         return {"depth_map": out_depth.view(*prefix), "rgb_map": out_rgb.view(*prefix, 3)}
 
 
 def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh,
-                       return_deform=True):
+                       return_deform=True, perturb_noise=None):
     """RADNeRFTorso.render (radnerf_torso.py:86-198, inference) on the fused path."""
     _check_args(perturb, max_steps)
     with torch.no_grad():
@@ -474,7 +540,8 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
         rays_d = rays_d.contiguous().view(-1, 3).float()
         bg_coords = bg_coords.contiguous().view(-1, 2).float()
         N, dev = rays_o.shape[0], rays_o.device
-        _, amb_bias, torso_bias = _per_frame_vectors(model, st, cond, poses)
+        ha_branch = head_aware_coin(model)
+        _, amb_bias, torso_bias = _per_frame_vectors(model, st, cond, poses, ha_branch)
         bg = _bg_tensor(bg_color, N, dev)
         out_rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         out_depth = torch.empty(N, dtype=torch.float32, device=dev)
@@ -484,7 +551,9 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
         f = GfFrame()
         _fill_common(f, model, st, N, dt_gamma, max_steps, T_thresh, amb_bias, bg, out_rgb, out_depth)
         f.rays_o, f.rays_d = ptr(rays_o), ptr(rays_d)
-        _fill_torso(f, model, st, bg_coords, torso_bias, out_alpha, out_trgb, out_deform)
+        noise = _perturb_noise(perturb, perturb_noise, N, dev)
+        f.perturb_noise = ptr(noise) if noise is not None else None
+        _fill_torso(f, model, st, bg_coords, torso_bias, out_alpha, out_trgb, out_deform, ha_branch)
         s = current_stream(dev)
         check(lib().gf_render_head(C.byref(f), s))
         check(lib().gf_render_torso(C.byref(f), s))
@@ -574,11 +643,12 @@ def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
         bufs = pipe._fused_bufs = _PipeBuffers(pipe)
     N = pipe.H * pipe.W
     torso = st.has_torso
-    pre = pipe.prepared(i) if hasattr(pipe, "prepared") else None
+    ha_branch = head_aware_coin(model) if torso else False
+    pre = pipe.prepared(i) if (hasattr(pipe, "prepared") and not st.head_aware) else None
     if pre is not None:          # the pass's batched launch (FramePipeline.prepare) already holds this frame's vectors
         amb_bias, torso_bias = pre
     else:
-        _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None)
+        _, amb_bias, torso_bias = _per_frame_vectors(model, st, pipe.cond_wins[i], pipe.pose6[i:i + 1] if torso else None, ha_branch)
     _fill_common(f, model, st, N, hp["dt_gamma"], hp["max_steps"], hp.get("T_thresh", 1e-4), amb_bias, bufs.bg, bufs.rgb[slot], bufs.depth[slot],
                  rgb8, slot)   # the reference forwards **hparams to render(): a T_thresh key overrides the 1e-4 default (renderer.py:263)
     f.img_h, f.img_w = pipe.H, pipe.W
@@ -590,7 +660,7 @@ def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
     for k in range(4):
         f.intrinsics[k] = float(pipe.intrinsics[k])
     if torso:
-        _fill_torso(f, model, st, bufs.bg_coords, torso_bias, None, None, None)
+        _fill_torso(f, model, st, bufs.bg_coords, torso_bias, None, None, None, ha_branch, slot)
     return st, bufs, (amb_bias, torso_bias)
 
 

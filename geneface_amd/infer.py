@@ -119,8 +119,8 @@ class FramePipeline:
         encoder launch (70 us alone, 0.6 ms beside four persistent head grids, and on the critical path of the frame's stream).  Same
         bytes either way (tests/test_gpu_render.py::test_prepared_pass_is_bit_identical).  No-op for the op-by-op path."""
         self._pre = None
-        if self.impl != "fused" or self.device.type != "cuda" or stop <= first:
-            return
+        if self.impl != "fused" or self.device.type != "cuda" or stop <= first or getattr(self.model, "torso_head_aware", False):
+            return      # (head-aware torso models flip a coin per frame that decides what is folded into torso_bias: they encode per frame)
         from .fused import cond_encode_batch, get_state
         st = get_state(self.model)
         if getattr(self, "_prep_stream", None) is None:

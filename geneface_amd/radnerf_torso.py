@@ -120,7 +120,8 @@ class RADNeRFTorso(RADNeRF):
         impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_torso_fused
-            return render_torso_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh)
+            return render_torso_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh,
+                                      perturb_noise=kwargs.get("perturb_noise"))
         with torch.no_grad():
             prefix = rays_o.shape[:-1]
             rays_o = rays_o.contiguous().view(-1, 3)
@@ -130,7 +131,7 @@ class RADNeRFTorso(RADNeRF):
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
             cond_feat = self.cal_cond_feat(cond)
             weights_sum, depth, image = self._march_head_ops(rays_o, rays_d, nears, fars, cond_feat, self._ind_code(),
-                                                             dt_gamma, perturb, max_steps, T_thresh)
+                                                             dt_gamma, perturb, max_steps, T_thresh, kwargs.get("perturb_noise"))
             if bg_color is None:
                 bg_color = 1
             results = {}

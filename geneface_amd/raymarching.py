@@ -63,7 +63,7 @@ def morton3D_dilation(grid):
 
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1,
-               perturb=False, dt_gamma=0, max_steps=1024):
+               perturb=False, dt_gamma=0, max_steps=1024, noises=None):
     rays_o = _f32(rays_o).contiguous().view(-1, 3)
     rays_d = _f32(rays_d).contiguous().view(-1, 3)
     M = n_alive * n_step
@@ -73,7 +73,10 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, densi
     xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
     deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
-    noises = torch.rand(n_alive, dtype=torch.float32, device=dev) if perturb else torch.zeros(n_alive, dtype=torch.float32, device=dev)
+    if noises is not None and perturb:      # caller-supplied draws (extension; the reference always draws here, raymarching.py:395-398)
+        noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        noises = torch.rand(n_alive, dtype=torch.float32, device=dev) if perturb else torch.zeros(n_alive, dtype=torch.float32, device=dev)
     _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                         density_bitfield, near, far, xyzs, dirs, deltas, noises)
     return xyzs, dirs, deltas

@@ -43,7 +43,7 @@ def _mark_written(*tensors):
 
 class NeRFRenderer(nn.Module):
     #: execution strategy of render(): "fused", "ops", or "auto" = fused whenever the call is inside what the fused
-    #: kernels cover (no perturbation, max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
+    #: kernels cover (max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
     #: the GPU through libgeneface_hip.so; neither has a CPU fallback.
     render_impl = "auto"
     #: arithmetic of the fused head field: "fp32" (strict parity: everything in fp32, the offline inference path of the reference) or
@@ -216,7 +216,7 @@ class NeRFRenderer(nn.Module):
     def _pick_impl(self, impl, perturb, max_steps):
         if impl != "auto":
             return impl
-        if perturb or max_steps > 64:
+        if max_steps > 64:
             return "ops"
         ok = getattr(self, "_fused_arch_ok", None)
         if ok is None:
@@ -233,7 +233,7 @@ class NeRFRenderer(nn.Module):
     def _ind_code(self):
         return self.individual_embeddings[0] if self.individual_embedding_dim > 0 else None
 
-    def _march_head_ops(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb, max_steps, T_thresh):
+    def _march_head_ops(self, rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb, max_steps, T_thresh, perturb_noise=None):
         """renderer.py:316-351: wavefront loop with a host-visible alive list."""
         N, device = rays_o.shape[0], rays_o.device
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
@@ -251,7 +251,8 @@ class NeRFRenderer(nn.Module):
             self.last_schedule.append((n_alive, n_step))
             xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
                                                         self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
-                                                        perturb if step == 0 else False, dt_gamma, max_steps)
+                                                        perturb if step == 0 else False, dt_gamma, max_steps,
+                                                        noises=perturb_noise if step == 0 else None)
             sigmas, rgbs, _ = self(xyzs, dirs, cond_feat, ind_code)
             sigmas = self.density_scale * sigmas
             raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
@@ -298,7 +299,8 @@ class NeRFRenderer(nn.Module):
         impl = self._pick_impl(kwargs.get("render_impl", self.render_impl), perturb, max_steps)
         if impl == "fused":
             from .fused import render_head_fused
-            return render_head_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh)
+            return render_head_fused(self, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh,
+                                     perturb_noise=kwargs.get("perturb_noise"))
         with torch.no_grad():
             prefix = rays_o.shape[:-1]
             rays_o = rays_o.contiguous().view(-1, 3)
@@ -306,7 +308,7 @@ class NeRFRenderer(nn.Module):
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
             cond_feat = self.cal_cond_feat(cond)
             weights_sum, depth, image = self._march_head_ops(rays_o, rays_d, nears, fars, cond_feat, self._ind_code(),
-                                                             dt_gamma, perturb, max_steps, T_thresh)
+                                                             dt_gamma, perturb, max_steps, T_thresh, kwargs.get("perturb_noise"))
             if bg_color is None:
                 bg_color = 1
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color

@@ -180,6 +180,16 @@ typedef struct gf_frame_t {
     float* out_torso_rgb;       /* [N,3] or NULL: torso_rgb_map */
     float* out_deform;          /* [N,2] or NULL: dx of the masked pixels (others untouched) */
     void* workspace;            /* gf_frame_workspace_bytes(n_rays) bytes, 256-byte aligned */
+    /* perturb=True at inference (renderer.py:338-342: `perturb if step == 0 else False`): the FIRST march iteration starts every ray at
+     * t = near + clamp(near * dt_gamma, dt_min, dt_max) * noise (raymarching.cu:851).  [N] U[0,1) draws in ray order, or NULL = no jitter. */
+    const float* perturb_noise;
+    /* torso_head_aware (radnerf_torso.py:36-46,68-74,175-179): device copy of gf_torso_pack_ha()'s second output, or NULL.  With
+     * torso_ha_branch = 1 the torso field of a masked pixel also sees the head's accumulated colour and opacity at that pixel through
+     * head_color_weights_encoder; the other outcome of the reference's per-frame coin (zeros in) is a per-frame constant the host folds
+     * into torso_bias, so it needs nothing here. */
+    const float* torso_ha_pack;
+    float* torso_ha_ws;         /* [N,16] scratch for the encoder's outputs; needed when torso_ha_branch = 1 */
+    uint32_t torso_ha_branch, _pad4;
 } gf_frame_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -316,6 +326,13 @@ int gf_head_pack_split(const float* amb0_host, const float* amb1_host, const flo
 /* HOST pointers: torso_deform_net / torso_canonicial_net weights */
 int gf_torso_pack(const float* d0_host, const float* d1_host, const float* d2_host, const float* c0_host,
                   const float* c1_host, const float* c2_host, float* out_host);
+/* torso_head_aware models: d0 [64,120], c0 [32,152] (16 encoder columns appended to both first layers), the encoder's three Linear layers
+ * e0 [16,4]+[16], e1 [32,16]+[32], e2 [16,32]+[16].  out_main_host [gf_torso_pack_floats()] as gf_torso_pack; out_ha_host
+ * [gf_torso_ha_pack_floats()] = the encoder columns as two extra A-operand streams + the encoder itself. */
+uint32_t gf_torso_ha_pack_floats(void);
+int gf_torso_pack_ha(const float* d0_host, const float* d1_host, const float* d2_host, const float* c0_host, const float* c1_host,
+                     const float* c2_host, const float* e0w_host, const float* e0b_host, const float* e1w_host, const float* e1b_host,
+                     const float* e2w_host, const float* e2b_host, float* out_main_host, float* out_ha_host);
 /* head pass; with torso_pack == NULL also the head-only tail (renderer.py:354-364) so outputs are final */
 int gf_render_head(const gf_frame_t* frame, void* stream);
 /* torso pass + final blend (radnerf_torso.py:156-198); gf_render_head must precede it on the same stream */

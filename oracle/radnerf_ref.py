@@ -49,13 +49,14 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
     return nears, fars
 
 
-def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfield, C, H, nears, fars, align, dt_gamma, max_steps):
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, bitfield, C, H, nears, fars, align, dt_gamma, max_steps, noises=None):
     M = n_alive * n_step
     if align > 0:
         M += align - (M % align)
     dev = rays_o.device
     xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
-    noises = torch.zeros(n_alive, device=dev)  # perturb=False at inference
+    if noises is None:
+        noises = torch.zeros(n_alive, device=dev)  # perturb=False; with perturb=True the reference draws torch.rand(n_alive) here (raymarching.py:395-398)
     RM.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bitfield, nears, fars,
                   xyzs, dirs, deltas, noises)
     return xyzs, dirs, deltas
@@ -262,7 +263,9 @@ def _count_composited(n_alive, n_step, T_thresh, ws0, sigmas, deltas):
     return cnt
 
 
-def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace=None):
+def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace=None, perturb_noise=None):
+    """renderer.py:316-351.  perturb_noise [N]: the U[0,1) draws of perturb=True, used by the FIRST iteration only (renderer.py:338-342:
+    `perturb if step == 0 else False`; all N rays are alive then, so draw n belongs to ray n)."""
     N = rays_o.shape[0]
     cascade = 1 + math.ceil(math.log2(hp["bound"]))
     nears, fars = near_far_from_aabb(rays_o, rays_d, sd["aabb_infer"], hp["min_near"])
@@ -278,7 +281,8 @@ def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh,
             break
         n_step = max(min(N // n_alive, 8), 1)
         xyzs, dirs, deltas = march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, float(hp["bound"]), sd["density_bitfield"],
-                                        cascade, hp["grid_size"], nears, fars, 128, dt_gamma, max_steps)
+                                        cascade, hp["grid_size"], nears, fars, 128, dt_gamma, max_steps,
+                                        noises=perturb_noise.contiguous().float() if (perturb_noise is not None and step == 0) else None)
         sigmas, rgbs, _ = head_field(sd, hp, xyzs, dirs, cond_feat, ind_code)
         if trace is not None:
             trace.append({"n_alive": n_alive, "n_step": n_step, "n_valid": int((deltas[:, 0] > 0).sum()),
@@ -291,7 +295,7 @@ def march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh,
 
 
 def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_gamma=None, max_steps=None, T_thresh=1e-4, trace=None,
-           head_aware_branch=False):
+           head_aware_branch=False, perturb_noise=None):
     """One frame: the dict `NeRFRenderer.render` / `RADNeRFTorso.render` return at inference.  `head_aware_branch` fixes the coin the
     reference flips per frame when torso_head_aware is set (radnerf_torso.py:175-179): True = the torso sees the rendered head."""
     dt_gamma = hp["dt_gamma"] if dt_gamma is None else dt_gamma
@@ -302,7 +306,7 @@ def render(sd, hp, rays_o, rays_d, cond, bg_coords, poses6, bg_color, torso, dt_
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N = rays_o.shape[0]
         cond_feat = cal_cond_feat(sd, hp, cond)
-        weights_sum, depth, image, nears, fars = march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace)
+        weights_sum, depth, image, nears, fars = march_head(sd, hp, rays_o, rays_d, cond_feat, dt_gamma, max_steps, T_thresh, trace, perturb_noise)
         if bg_color is None:
             bg_color = 1
         out = {}

@@ -545,11 +545,13 @@ def test_second_identity_256_vs_oracle(impl):
     check(render_gpu(m, hp, fi), ref, True)
 
 
+@pytest.mark.parametrize("impl", ["ops", "fused"])
 @pytest.mark.parametrize("branch", [False, True])
-def test_torso_head_aware_vs_oracle(branch, monkeypatch):
+def test_torso_head_aware_vs_oracle(branch, impl, monkeypatch):
     """`torso_head_aware: true` (radnerf_torso.py:36-46, :68-74, :175-179): the head-colour encoder widens both torso MLPs; the reference
-    flips a coin per frame between showing the torso the rendered head and zeros.  Both outcomes against the oracle; render_impl='auto'
-    must route this architecture to the op-by-op path (the fused torso kernel is built for the default layer shapes)."""
+    flips a coin per frame between showing the torso the rendered head and zeros.  Both outcomes against the oracle, on the op-by-op path
+    and (round 3) on the fused one: 'zeros' is a per-frame constant folded into the torso bias, 'head' a per-pixel encoder launch plus 8
+    extra MFMA steps in both first layers of k_torso_finish<true>.  The frame loop flips the same coin."""
     import random
     from geneface_amd import synthetic as S
     from geneface_amd.radnerf_torso import RADNeRFTorso
@@ -558,7 +560,8 @@ def test_torso_head_aware_vs_oracle(branch, monkeypatch):
     m = RADNeRFTorso(hp)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
-    assert m._pick_impl("auto", False, hp["max_steps"]) == "ops"
+    assert m._pick_impl("auto", False, hp["max_steps"]) == "fused"
+    m.render_impl = impl
     monkeypatch.setattr(random, "random", lambda: 0.25 if branch else 0.75)
     fi = frame_inputs(sequence(4, 96, 96), 2)
     out = render_gpu(m, hp, fi)
@@ -566,6 +569,20 @@ def test_torso_head_aware_vs_oracle(branch, monkeypatch):
     check(out, ref, True)
     other = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True, head_aware_branch=not branch)
     assert (other["torso_alpha_map"] - ref["torso_alpha_map"]).abs().max() > 1e-3     # the two branches really differ
+    if impl == "fused":
+        from geneface_amd.infer import FramePipeline
+        seq = sequence(4, 96, 96)
+        pipe = FramePipeline(m, hp, seq, DEV, impl="fused")
+        frame = pipe.render_frame(2)
+        pipe.wait()
+        check_u8(frame, (ref["rgb_map"] * 255).view(96, 96, 3).to(torch.uint8))
+        # a weight update reaches the head-aware packs as well (index-map refresh, no host round trip)
+        with torch.no_grad():
+            m.head_color_weights_encoder[4].weight.mul_(0.5)
+            m.torso_deform_net.net[0].weight[:, 104:].mul_(2.0)
+        sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref2 = R.render(sd2, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], True, head_aware_branch=branch)
+        check(render_gpu(m, hp, fi), ref2, True)
 
 
 def test_fused_state_follows_the_weights():
@@ -966,3 +983,30 @@ def test_split_tier_survives_tiny_and_large_values():
     _, _, m = _split_model(True, bad)
     with pytest.raises(RuntimeError, match="f16 range"):
         render_gpu(m, hp, fi)
+
+
+@pytest.mark.parametrize("torso", [False, True])
+def test_perturb_first_iteration_jitter_vs_oracle(torso):
+    """perturb=True at inference (the GUI's and validation's jitter, renderer.py:338-342): the FIRST march iteration starts every ray at
+    near + clamp(near * dt_gamma, dt_min, dt_max) * noise.  With the caller's draws (`perturb_noise`, an extension of the signature: the
+    reference always draws inside the wrapper) both paths must reproduce the oracle at the strict bar; round 3 moved this into the fused
+    path (k_frame_init), which used to refuse it."""
+    hp, sd, model = build(torso, "fused")
+    hp = dict(hp, dt_gamma=1.0 / 64)         # a distance-proportional step: the jitter then scales with the ray's near distance
+    fi = frame_inputs(sequence(4, 96, 96), 1)
+    noise = torch.rand(96 * 96, generator=torch.Generator().manual_seed(4))
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso, perturb_noise=noise)
+    plain = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
+    assert (ref["rgb_map"] - plain["rgb_map"]).abs().max() > 1e-3         # the jitter is visible
+    to = lambda t: t.to(DEV)
+    for impl in ("ops", "fused"):
+        model.render_impl = impl
+        out = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), index=0, staged=False,
+                           bg_color=to(fi["bg"]), perturb=True, force_all_rays=True, perturb_noise=to(noise), **hp)
+        check(out, ref, torso)
+    # without caller-supplied draws: fresh noise per call (two renders differ from each other and from the unperturbed frame)
+    kw = dict(index=0, staged=False, bg_color=to(fi["bg"]), perturb=True, force_all_rays=True)
+    a = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), **kw, **hp)["rgb_map"]
+    b = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), **kw, **hp)["rgb_map"]
+    assert not torch.equal(a, b) and (a.cpu() - plain["rgb_map"].view_as(a.cpu())).abs().max() > 1e-3
+    assert model._pick_impl("auto", True, hp["max_steps"]) == "fused"
