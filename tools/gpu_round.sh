@@ -15,6 +15,13 @@ for s in $STEPS; do
     bench) timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
     benchfast) timeout 600 python bench.py --fast --no-cpu-baseline > $OUT/bench_fast.json 2> $OUT/bench_fast.err; cat $OUT/bench_fast.json
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_fast -o k --output-format csv -- python $REPO/bench.py --fast --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --no-overlap > $OUT/prof_fast.log 2>&1); head -6 $OUT/prof_fast/k_kernel_stats.csv | cut -c1-160 ;;
+    benchsplit) timeout 600 python bench.py --precision split > $OUT/bench_split.json 2> $OUT/bench_split.err; cut -c1-300 $OUT/bench_split.json
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_split -o k --output-format csv -- python $REPO/bench.py --precision split --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --no-overlap > $OUT/prof_split.log 2>&1); head -6 $OUT/prof_split/k_kernel_stats.csv | cut -c1-160
+           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_split_overlap -o k --output-format csv -- python $REPO/bench.py --precision split --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline > $OUT/prof_split_overlap.log 2>&1); head -4 $OUT/prof_split_overlap/k_kernel_stats.csv | cut -c1-160 ;;
+    pmcsplit) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F32 -d $OUT/pmcs_sq -o sq --output-format csv -- python $REPO/bench.py --precision split --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmcs_sq.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmcs_fetch -o f --output-format csv -- python $REPO/bench.py --precision split --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmcs_fetch.log 2>&1)
+           (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmcs_write -o w --output-format csv -- python $REPO/bench.py --precision split --steps 3 --warmup 1 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --profile-frames 0 --no-overlap > $OUT/pmcs_write.log 2>&1)
+           python tools/pmc_summary.py $OUT pmcs > $OUT/pmc_split_summary.txt 2>&1; tail -5 $OUT/pmc_split_summary.txt ;;
     ab:*)  # A/B of an experiment library against the product one, interleaved, short benches: ab:<variant>
            V=${s#ab:}
            for rep in 1 2 3; do

@@ -18,9 +18,10 @@ import sys
 
 def main():
     out = sys.argv[1]
+    prefix = sys.argv[2] if len(sys.argv) > 2 else "pmc"      # directory prefix of the passes: pmc_* (fp32 line) or pmcs_* (split tier)
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for path in glob.glob(os.path.join(out, prefix + "_*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"]
@@ -55,7 +56,7 @@ def main():
         print(f"== {k}")
         for n, v in sorted(d.items()):
             print(f"   {n:36s} {v:18.4f}")
-    with open(os.path.join(out, "pmc_summary.json"), "w") as fh:
+    with open(os.path.join(out, "pmc_summary.json" if prefix == "pmc" else f"{prefix}_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
 
 
