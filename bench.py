@@ -35,6 +35,7 @@ BYTES_PER_TORSO_PIXEL = 512
 BYTES_PER_RAY = 56
 INIT_BYTES_PER_RAY, INIT_BYTES_PER_HIT = 28, 24   # k_frame_init: near, far, zeroed accumulators per ray; direction, clock, far bound, list entry per hit ray
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense MFMA peak for f32 inputs
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16 / FP16 MFMA peak (32x32x16); the split tier spends three f16 MFMAs per fp32 product term set
 PEAK_HBM_GBS = 8000.0
 
 
@@ -516,6 +517,13 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
                       "traffic": None, "note": "f16-operand tier: gather bound; algorithmic table bytes per second, no peak claimed"})
             for k in ("frac_composited", "mfma_executed_frac"):
                 r.pop(k, None)
+            if precision == "split":
+                # the matrix pipe's own yardstick for this tier: fp32-equivalent algorithmic FLOPs against a third of the f16 peak
+                # (hi*hi + lo*hi + hi*lo: three v_mfma_f32_32x32x16_f16 per 16 input features and tile)
+                pk = PEAK_F16_MFMA_TFLOPS / 3.0
+                r["mfma"] = {"achieved_f32_equivalent": r["mfma_tflops_f32_equivalent"], "peak": pk, "unit": "TFLOP/s", "frac": r["mfma_tflops_f32_equivalent"] / pk,
+                             "note": "fp32-equivalent algorithmic FLOPs / (f16 dense peak / 3): the matrix pipe is a quarter busy; the round is gathers, "
+                                     "f32 <-> split conversions, march / composite and barriers (profiles/round3/r3i_head_timeline_split.txt)"}
             return r
         r["traffic"], r["traffic_source"] = pmc_traffic()
         return r

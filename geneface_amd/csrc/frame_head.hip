@@ -1080,18 +1080,28 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16s(Hrow + 16 * half, pf);
     }
+    GF_STAMP(7);
     __syncthreads();
+    GF_STAMP(8);
     // ---- ambient L1 (cond_feat folded into the bias)
     obw_bias<4>(s.P + P_AMBBIAS + wave * 32 + half * 16, A1);
     obws_mfma<gf::SP_AMB1, 2, true, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(9);
     __syncthreads();
+    GF_STAMP(10);
     obws_store<true>(Hw, A1, A2, nt);
+    GF_STAMP(11);
     __syncthreads();
+    GF_STAMP(12);
     // ---- ambient L2
     obws_mfma<gf::SP_AMB2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(13);
     __syncthreads();
+    GF_STAMP(14);
     obws_store<true>(Hw, A1, A2, nt);
+    GF_STAMP(15);
     __syncthreads();
+    GF_STAMP(16);
     // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 32:64]; the kept 3-D features -> H[:, 0:32]
     if (tile_on) {
         float ambient[2];
@@ -1103,17 +1113,27 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         store16s(Hrow + 16 * half, pf);
         store16s(Hrow + 32 + 16 * half, af);
     }
+    GF_STAMP(17);
     __syncthreads();
+    GF_STAMP(18);
     // ---- density L1: K = 64
     obws_mfma<gf::SP_SIG1, 4, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(19);
     __syncthreads();
+    GF_STAMP(20);
     obws_store<true>(Hw, A1, A2, nt);
+    GF_STAMP(21);
     __syncthreads();
+    GF_STAMP(22);
     // ---- density L2
     obws_mfma<gf::SP_SIG2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(23);
     __syncthreads();
+    GF_STAMP(24);
     obws_store<true>(Hw, A1, A2, nt);
+    GF_STAMP(25);
     __syncthreads();
+    GF_STAMP(26);
     // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
     if (tile_on) {
         float h0[1];
@@ -1121,9 +1141,13 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         if (valid && half == 0) s.sx[raw] = expf(h0[0]);     // the position slots were consumed before the first barrier of this function
     }
     obws_mfma<gf::SP_SIG3, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(27);
     __syncthreads();
+    GF_STAMP(28);
     obws_store<false>(Hw, A1, A2, nt);
+    GF_STAMP(29);
     __syncthreads();
+    GF_STAMP(30);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
     obw_bias<4>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1);
     obw_zero<4>(A2);
@@ -1157,9 +1181,13 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         __builtin_amdgcn_sched_barrier(0);
     }
     obws_mfma<gf::SP_COL1G, 8, false>(wp, Ws, lane32, Hb, A1, A2, nt);
+    GF_STAMP(31);
     __syncthreads();
+    GF_STAMP(32);
     obws_store<true>(Hw, A1, A2, nt);
+    GF_STAMP(33);
     __syncthreads();
+    GF_STAMP(34);
     // ---- colour L2 + sigmoid
     if (tile_on) {
         float c[3];
@@ -1170,7 +1198,9 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
             s.ob[raw] = 1.0f / (1.0f + __expf(-c[2]));
         }
     }
+    GF_STAMP(35);
     __syncthreads();
+    GF_STAMP(36);
 }
 
 // MODE: 0 = fp32 (strict, bit-reproducible fp32 arithmetic), 1 = fast (f16 operands), 2 = split (fp32 values as two-term f16 splits)

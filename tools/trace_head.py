@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="print every traced round of the first N workgroups (start, duration, gap to the previous round, samples, pool)")
     ap.add_argument("--spans", default=None, help="save the per-workgroup [start tick, end tick, rounds | samples << 32, XCC, start / end realtime] array (.npy)")
     ap.add_argument("--fast", action="store_true", help="trace the f16 fast-tier kernel (render_precision='fast')")
+    ap.add_argument("--split", action="store_true", help="trace the split-tier kernel (render_precision='split'; density L1 is one K=64 layer there: slots 8-9 = "
+                                                         "ambient L1 alone, 18-19 = density L1)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -61,6 +63,8 @@ def main():
     model = model.to(dev).eval()
     if args.fast:
         model.render_precision = "fast"
+    if args.split:
+        model.render_precision = "split"
     pipe = FramePipeline(model, hp, seq, dev, impl="fused")
     L = lib()
     L.gf_trace_dims.restype = C.c_uint32
