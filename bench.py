@@ -261,8 +261,11 @@ def timed_pass(job, pipe, first, K, prepare=True):
     t0 = time.perf_counter()
     if prepare:
         pipe.prepare(first, first + K)
+    free = max(1, min(int(getattr(pipe, "in_flight", 1)), K))     # the first `in_flight` frames find free slots: their calls never wait for the GPU
     for i in range(first, first + K):
         pipe.render_frame(i)
+        if i - first + 1 == free:
+            timed_pass.enqueue_s = (time.perf_counter() - t0) / free     # host time to describe + enqueue ONE frame (incl. its share of prepare())
     job.barrier()
     return job.reduce(time.perf_counter() - t0, "max")
 
@@ -271,10 +274,12 @@ def timed_loop(job, pipe, first, K, args):
     """The K-step pass repeated until --min-seconds of it have been measured (the driver's --steps 20 is 30 ms of GPU work: mostly
     pipeline fill and drain, and invisible to a utilisation sampler); every rank derives the same repeat count from the reduced time
     of the first pass.  Reports the median pass."""
-    dts = [timed_pass(job, pipe, first, K, not args.no_prepare)]
+    dts, enq = [timed_pass(job, pipe, first, K, not args.no_prepare)], []
     reps = args.repeats or int(min(400, max(1, -(-args.min_seconds // dts[0]))))
     while len(dts) < reps:
         dts.append(timed_pass(job, pipe, first, K, not args.no_prepare))
+        enq.append(timed_pass.enqueue_s)
+    timed_loop.host_enqueue_ms_per_step = (sorted(enq)[len(enq) // 2] * 1e3) if enq else None     # if this approaches ms_per_step the host is the limiter
     return sorted(dts)[len(dts) // 2], dts
 
 
@@ -330,7 +335,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
     ranks_seen = int(round(job.reduce(1.0, "sum")))
 
     # CPU baseline FIRST (rank 0, N = 1): the GPU legs then run back to back at the end of the process, where a utilisation sampler sees them
-    cpu, parity, parity_idx = None, None, []
+    cpu, parity, parity_idx, oframes = None, None, [], None
     if real and rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_par = max(args.cpu_frames, min(args.parity_frames, per_rank))
         parity_idx = sorted({int(round(1 + k * (per_rank - 2) / max(n_par - 1, 1))) for k in range(n_par)})
@@ -341,6 +346,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
         for i in range(Wm):
             pipe.render_frame(i)
         dt, dts = timed_loop(job, pipe, Wm, K, args)
+        host_ms = getattr(timed_loop, "host_enqueue_ms_per_step", None)
         roofline = None
         if real and rank == 0:
             roofline = measure_roofline(pipe, args.impl, Wm, min(args.profile_frames, K), PEAK_F32_MFMA_TFLOPS, precision=args.precision)
@@ -352,6 +358,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             "metric": "rendered 512x512 fps (head+torso)" if torso else "rendered 512x512 fps (head only)", "value": world * K / dt, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "repeats": len(dts), "timed_region_s": sum(dts), "ms_per_step_min_max": [min(dts) / K * 1e3, max(dts) / K * 1e3],
+            "host_enqueue_ms_per_step": host_ms,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic" if real else "selftest: no rendering (launch-path check only)",
             "config": {"workload": (f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
                                     f"(BASELINE.json configs[2])" if torso else
@@ -385,6 +392,8 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
                                                     radius=HEAVY_RADIUS)
                 if torso:
                     line["head_only"] = head_only_leg(args, job)
+                if args.precision == "fp32":
+                    line["split_tier"] = split_tier_leg(args, job, hp, torso, seq, sd, oframes if parity else None)
         line["cpu_baseline"] = cpu
         if emit is not None:
             emit(line)
@@ -420,6 +429,27 @@ def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_idx, what, radius=None)
             "samples_composited_per_frame": r.get("samples_composited_per_frame"),
             "roofline_frac": r.get("frac"), "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "tile_fill": r.get("tile_fill"),
             "example_frame": r.get("example_frame"), "parity": parity, "fixture": what}
+
+
+def split_tier_leg(args, job, hp, torso, seq, sd, oracle_frames_or_none):
+    """Beside the headline (which stays exact fp32): the same workload on the split tier -- fp32 VALUES as two-term f16 splits on the f16
+    matrix pipe, held to the same strict tolerance.  `python bench.py --precision split` prints its full line."""
+    import torch
+    n = args.steps + args.warmup
+    pipe = build_pipe(args, job, hp, torso, seq, sd, (0, n), precision="split")
+    parity = None
+    if oracle_frames_or_none:
+        parity = parity_vs_oracle(pipe, dict(list(sorted(oracle_frames_or_none.items()))[:4]))
+    with torch.no_grad():
+        for i in range(args.warmup):
+            pipe.render_frame(i)
+        dt, dts = timed_loop(job, pipe, args.warmup, args.steps, args)
+        r = measure_roofline(pipe, args.impl, args.warmup, min(4, args.steps), precision="split")
+    return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "repeats": len(dts), "frames_in_flight": pipe.in_flight,
+            "host_enqueue_ms_per_step": getattr(timed_loop, "host_enqueue_ms_per_step", None),
+            "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "mfma": r.get("mfma"), "parity": parity,
+            "dtype": "f32 values as two-term f16 splits (hi + lo' * 2^-11), three v_mfma_f32_32x32x16_f16 per product term set, f32 accumulate",
+            "note": "opt-in (model.render_precision = 'split'): strict tolerance, not fp32 bit patterns; the headline `value` is the exact-fp32 tier"}
 
 
 def head_only_leg(args, job):
