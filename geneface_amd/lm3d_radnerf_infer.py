@@ -282,10 +282,15 @@ class LM3d_RADNeRFInfer:
     def infer_once(self, inp: dict):
         self.inp = inp
         samples = self.get_pose_from_ds(self.get_cond_from_input(inp))
-        frames = self.forward_system(samples)
+        # inp["return_frames"] = False: the PNG files are the output (what the reference's loop produces, base_nerf_infer.py:97-101) and the
+        # stacked uint8 result -- 2.4 GB of first-touch host memory for a 3000-frame sequence -- is not assembled
+        collect = bool(inp.get("return_frames", True)) or not inp.get("tmp_imgs_dir")
+        frames = self.forward_system(samples, collect=collect)
         if self.proc_rank != 0:          # base_nerf_infer.py:267: only rank 0 post-processes
             return frames
         name = inp.get("out_video_name", "")
+        if name.endswith(".npy") and not isinstance(frames, np.ndarray):
+            raise ValueError("out_video_name ends in .npy but return_frames is False: there is no frame stack to store")
         if name.endswith(".npy"):
             os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
             np.save(name, frames)

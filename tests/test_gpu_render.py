@@ -1010,3 +1010,52 @@ def test_perturb_first_iteration_jitter_vs_oracle(torso):
     b = model.render(to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]), **kw, **hp)["rgb_map"]
     assert not torch.equal(a, b) and (a.cpu() - plain["rgb_map"].view_as(a.cpu())).abs().max() > 1e-3
     assert model._pick_impl("auto", True, hp["max_steps"]) == "fused"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_full_size_properties_512(precision):
+    """Size-independent properties at BASELINE.json's full frame size (the oracle needs ~6 s per 512x512 frame; these need none):
+    * rays are independent: a permuted ray batch gives the permuted frame, bit for bit (the pools regroup every ray, the per-frame sample
+      budget is a function of the whole batch's terminal-index histogram, which a permutation leaves alone);
+    * the background enters affinely: rgb(bg = 1) - rgb(bg = 0) = 1 - weights_sum on all three channels, depth does not move;
+    * a camera that looks away from the head sees the (torso-blended) background exactly, depth 0, and no field evaluation at all."""
+    from geneface_amd.fused import frame_stats
+    hp, sd, model = build(True, "fused")
+    model.render_precision = precision
+    seq = sequence(4, 512, 512)
+    fi = frame_inputs(seq, 3)
+    N = 512 * 512
+    to = lambda t: t.to(DEV)
+    base = render_gpu(model, hp, fi)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(9))
+    fi_p = dict(fi, rays_o=fi["rays_o"][:, perm].contiguous(), rays_d=fi["rays_d"][:, perm].contiguous(),
+                bg_coords=fi["bg_coords"][:, perm].contiguous(), bg=fi["bg"][:, perm].contiguous())
+    out_p = render_gpu(model, hp, fi_p)
+    pd = perm.to(DEV)
+    for k in ("rgb_map", "depth_map", "torso_alpha_map", "torso_rgb_map"):
+        a, b = base[k].reshape(N, -1), out_p[k].reshape(N, -1)
+        assert torch.equal(b, a[pd]), (precision, k)
+    # head-only model for the background property (the torso pass blends its own colour under the head)
+    hp_h, sd_h, head = build(False, "fused")
+    head.render_precision = precision
+    kw = dict(index=0, staged=False, perturb=False, force_all_rays=True)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    r0 = head.render(*args, bg_color=torch.zeros(1, N, 3, device=DEV), **kw, **hp_h)
+    r1 = head.render(*args, bg_color=torch.ones(1, N, 3, device=DEV), **kw, **hp_h)
+    assert torch.equal(r0["depth_map"], r1["depth_map"])
+    d = (r1["rgb_map"] - r0["rgb_map"]).reshape(N, 3)                      # = 1 - weights_sum wherever nothing clamps
+    unclamped = (r1["rgb_map"].reshape(N, 3) < 1).all(dim=1)
+    assert int(unclamped.sum()) > 0.6 * N
+    du = d[unclamped]
+    assert float((du - du[:, :1]).abs().max()) < 2e-6 and float(du.min()) > -2e-6 and float(du.max()) <= 1.0 + 2e-6
+    assert float(du.max()) == 1.0 and float(du.min()) < 0.01                 # rays that miss the head entirely, rays that saturate
+    # looking away: ngp pose rotated by 180 degrees about the image-up axis
+    away = fi["pose44"].clone()
+    away[0, :3, 0] *= -1
+    away[0, :3, 2] *= -1
+    ro, rd = R.get_rays(away, seq["intrinsics"], 512, 512)
+    out_a = model.render(to(ro), to(rd), to(fi["cond"]), to(fi["bg_coords"]), to(R.convert_poses(away)), bg_color=to(fi["bg"]), **kw, **hp)
+    fs = frame_stats(model.last_ctrl, N, hp["max_steps"])
+    assert fs["n_hit"] == 0 and sum(fs["samples"]) == 0
+    assert float(out_a["depth_map"].abs().max()) == 0.0
+    assert torch.equal(out_a["rgb_map"].reshape(N, 3), out_a["torso_rgb_map"].reshape(N, 3).clamp(0, 1))

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-png", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "split", "fast"])
+    ap.add_argument("--files-only", action="store_true", help="inp['return_frames'] = False: the PNG files are the output, no stacked result (the reference's contract)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -41,6 +43,7 @@ def main():
     hp = HP.may_hparams(True)
     model = RADNeRFTorso(hp)
     model.load_state_dict(S.make_state_dict(hp, True), strict=True)
+    model.render_precision = args.precision
     dd, _ = S.make_dataset_dict(T=args.frames, H=args.size, W=args.size)
     inf = LM3d_RADNeRFInfer(hp, model=model, dataset=RADNeRFPoseSource(dd, hp), device="cuda:0")
     work = tempfile.mkdtemp(prefix="gf_shard_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -48,10 +51,11 @@ def main():
         cond = os.path.join(work, "pred_lm3d.npy")
         np.save(cond, S.make_landmarks(args.frames).astype(np.float32)[None])      # [1, T, 204] as PostNet writes it
         imgs = None if args.no_png else os.path.join(work, "imgs")
-        inp = {"cond_name": cond, "out_video_name": "", "audio_source_name": "", "tmp_imgs_dir": imgs, "shard": (args.rank, args.ranks)}
+        inp = {"cond_name": cond, "out_video_name": "", "audio_source_name": "", "tmp_imgs_dir": imgs, "shard": (args.rank, args.ranks),
+               "return_frames": not args.files_only}
         lo, hi = shard_range(args.frames, args.rank, args.ranks)
         # one small warm-up block (library load, packing, first-launch costs), then the measured shard
-        inf.infer_once(dict(inp, tmp_imgs_dir=None, shard=(0, args.frames // 8)))
+        inf.infer_once(dict(inp, tmp_imgs_dir=None, shard=(0, max(args.ranks, args.frames // 8))))
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
@@ -59,8 +63,9 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         free, total = torch.cuda.mem_get_info()
-        assert frames.shape == (hi - lo, args.size, args.size, 3)
-        res = {"workload": f"frames [{lo}, {hi}) of a {args.frames}-frame sequence = rank {args.rank} of {args.ranks} (BASELINE.json configs[3]), "
+        assert args.files_only or frames.shape == (hi - lo, args.size, args.size, 3)
+        res = {"render_precision": args.precision,
+               "workload": f"frames [{lo}, {hi}) of a {args.frames}-frame sequence = rank {args.rank} of {args.ranks} (BASELINE.json configs[3]), "
                            f"May head+torso {args.size}x{args.size}, through LM3d_RADNeRFInfer.infer_once" + ("" if args.no_png else " with one PNG per frame"),
                "frames": hi - lo, "seconds": dt, "fps": (hi - lo) / dt, "includes": "landmark normalisation + windows, pose lookup, H2D of the shard's inputs, one batched "
                "cond-encoder launch, render, D2H, PNG encode + write (tmpfs), the stacked uint8 result",
@@ -70,8 +75,10 @@ def main():
             names = sorted(os.listdir(imgs))
             assert names == [f"{i:05d}.png" for i in range(lo, hi)], (names[:3], lo, hi)
             res["png_MB_per_frame"] = sum(os.path.getsize(os.path.join(imgs, n)) for n in names) / len(names) / 1e6
-            for k in (0, len(names) // 2, len(names) - 1):      # the files decode to the returned frames
-                assert np.array_equal(decode_rgb8(open(os.path.join(imgs, names[k]), "rb").read()), frames[k])
+            for k in (0, len(names) // 2, len(names) - 1):      # the files decode, and to the returned frames
+                img = decode_rgb8(open(os.path.join(imgs, names[k]), "rb").read())
+                assert img.shape == (args.size, args.size, 3) and (args.files_only or np.array_equal(img, frames[k]))
+            res["returns"] = "image directory only" if args.files_only else "stacked uint8 frames + image directory"
         print(json.dumps(res))
         if args.json:
             os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
