@@ -1277,6 +1277,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     // statistics: s.misc[10..12] = samples, rounds, tiles of this workgroup (thread 0 adds per round; LDS, not three registers)
     if (tid == 0) { s.misc[10] = 0; s.misc[11] = 0; s.misc[12] = 0; }
     bool queue_open = true;         // uniform
+    // The first refill of every workgroup is a STATIC block of the queue (workgroup b takes entries [b, b + 1) * pool_cap), the dynamic queue
+    // serves what lies beyond gridDim.x * pool_cap: at launch all 1 024 owner waves used to hit one queue-head word at once, and L2 retires
+    // same-address atomics at ~10 ns each (the same chain that was k_frame_init's whole duration, profiles/round3/r3l_init_ab.txt).
+    bool first_fill = true;         // uniform
+    const uint32_t q_off = gridDim.x * pool_cap;
 #ifdef GF_TRACE
     uint32_t tr_round = 0;
     unsigned long long span_t1 = span_t0, span_r1 = span_r0;   // end of the last round
@@ -1302,10 +1307,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             const unsigned long long m = __ballot(want);
             const uint32_t nw = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (lane == 0 && nw) base = atomicAdd(&a.ctrl[qhead], nw);
-            base = __shfl(base, 0);
+            if (!first_fill) {
+                if (lane == 0 && nw) base = atomicAdd(&a.ctrl[qhead], nw);
+                base = q_off + __shfl(base, 0);
+            }
             if (want) {
-                const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                // first fill: every lane below pool_cap wants a ray, lane tid takes entry blockIdx.x * pool_cap + tid
+                const uint32_t idx = first_fill ? (uint32_t)blockIdx.x * s.misc[15] + (uint32_t)tid
+                                                : base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (idx < s.misc[14]) {
                     ray = a.queue[idx];
                     const float* d = a.rays_d + (size_t)ray * 3;
@@ -1321,8 +1330,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
                 }
             }
-            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
+            if (lane == 0) s.misc[4 + wave] = (!first_fill && nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
         }
+        first_fill = false;
         GF_STAMP(1);
         // ------------------------------------------------------------------ pool census
         const bool alive = ray >= 0;
@@ -1931,8 +1941,16 @@ struct InitArgs {
     int* hit_list; uint32_t* ctrl; uint32_t N;
 };
 
-__global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
-    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+// 1024-lane workgroups, ONE pair of control-block atomics per workgroup.  With one pair per wave (8 192 atomics on two addresses per frame)
+// the launch took 45 us whatever else it did -- 52 us with the walk AND the stores compiled out (profiles/round3/r3l_init_ab.txt): L2
+// retires same-address atomics at about one per 10 ns, and that serial chain was the kernel.
+#ifndef GF_INIT_THREADS
+#define GF_INIT_THREADS 1024
+#endif
+constexpr int kInitThreads = GF_INIT_THREADS;
+__global__ void __launch_bounds__(kInitThreads) k_frame_init(const InitArgs a) {
+    __shared__ uint32_t wave_hits[kInitThreads / 64], wave_miss[kInitThreads / 64], wg_base;
+    const uint32_t n = blockIdx.x * kInitThreads + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool hit = false, miss = false;
     if (n < a.N) {
@@ -1968,7 +1986,10 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
             if (of == FLT_MAX) far_m = near;              // misses the occupied region: no sample on this ray
             else far_m = fminf(far, of);
         }
-        // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there
+        // march through empty space to the first occupied sample; the field kernel restarts the marcher exactly there.  (Round 3 tried taking
+        // the occupancy-bit loads off the dependency chain -- 4 or 8 visits computed ahead assuming "empty", their bytes loaded together,
+        // answers checked in order: same result bit for bit, but 36-38 us against 33-34: the kernel is bound by instruction issue, and the
+        // visits computed beyond the hit are pure cost.  profiles/round3/r3l_init_ab.txt.)
         float t = near, t_first = near;
         const uint32_t got = gf::march_ray(a.mp, ox, oy, oz, dx, dy, dz, far_m, a.noise ? a.noise[n] : 0.0f, 1u, t,
                                            [&](uint32_t, float, float, float, float, float, float t_at) { t_first = t_at; });
@@ -1983,14 +2004,22 @@ __global__ void __launch_bounds__(256) k_frame_init(const InitArgs a) {
     }
     // rays with a sample -> hit list (order is irrelevant: rays are independent); rays without one terminate at index 1
     const unsigned long long hm = __ballot(hit), mm = __ballot(miss);
-    const uint32_t nh = (uint32_t)__popcll(hm), nm = (uint32_t)__popcll(mm);
-    uint32_t base = 0;
-    if (lane == 0) {
-        if (nh) base = atomicAdd(&a.ctrl[gf::kCtrlNHit], nh);
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) { wave_hits[wave] = (uint32_t)__popcll(hm); wave_miss[wave] = (uint32_t)__popcll(mm); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t nh = 0, nm = 0;
+#pragma unroll
+        for (int w = 0; w < kInitThreads / 64; w++) { nh += wave_hits[w]; nm += wave_miss[w]; }
+        wg_base = nh ? atomicAdd(&a.ctrl[gf::kCtrlNHit], nh) : 0u;
         if (nm) atomicAdd(&a.ctrl[gf::kCtrlHist + 1], nm);
     }
-    base = __shfl(base, 0);
-    if (hit) a.hit_list[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (int)n;
+    __syncthreads();
+    if (hit) {
+        uint32_t base = wg_base;
+        for (int w = 0; w < wave; w++) base += wave_hits[w];
+        a.hit_list[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = (int)n;
+    }
 }
 
 // head-only tail of NeRFRenderer.render (renderer.py:354-364): background blend, clamp, depth normalisation
@@ -2055,7 +2084,7 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
     ia.rays_o = w.rays_o; ia.rays_d = w.rays_d; ia.nears = w.nears; ia.fars = w.fars; ia.far_occ = w.far_occ; ia.rays_t = w.rays_t;
     ia.weights_sum = w.weights_sum; ia.depth = w.depth; ia.image = w.image; ia.hit_list = w.alive_b; ia.ctrl = w.ctrl; ia.N = N;
     if (ev) (void)hipEventRecord(ev[4], s);
-    hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, 256u)), dim3(256), 0, s, ia);
+    hipLaunchKernelGGL(k_frame_init, dim3(gf_div_up(N, (uint32_t)kInitThreads)), dim3(kInitThreads), 0, s, ia);
     if (ev) (void)hipEventRecord(ev[5], s);
 
     HeadArgs ha;
