@@ -16,19 +16,22 @@ struct FrameWs {
     size_t bytes;
 };
 constexpr uint32_t kMaxSteps = 64;  // largest max_steps the fused path accepts
-// Control block (uint32 words), zeroed by a memset node at the head of every frame:
-constexpr uint32_t kCtrlQHead0 = 0;    // phase 0: next unclaimed entry of the hit list
+// Control block (uint32 words), zeroed by a memset node at the head of every frame.  Three groups on separate 128-byte lines (round 3): L2
+// retires atomics on one line at ~10 ns each, and the queue heads -- on the critical path of every pool refill -- used to share a line with
+// the statistics and the histogram that every retiring workgroup adds to.
+// line 0: work distribution
+constexpr uint32_t kCtrlQHead0 = 0;    // phase 0: next unclaimed entry of the hit list BEYOND the static blocks (frame_head.hip, first_fill)
 constexpr uint32_t kCtrlNHit = 1;      // rays with >= 1 sample (length of the hit list, alive_b)
 constexpr uint32_t kCtrlNSurv = 2;     // rays still alive after max_steps samples (length of the survivor list, alive_a)
-constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list
-constexpr uint32_t kCtrlSamples = 4;   // [2] field evaluations per phase
-constexpr uint32_t kCtrlRounds = 6;    // [2] workgroup rounds per phase
-constexpr uint32_t kCtrlTiles = 8;     // [2] 32-sample MFMA tiles executed per phase
+constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list beyond the static blocks
 constexpr uint32_t kCtrlBudget = 10;   // total per-ray sample budget B the reference's n_step schedule arrives at
-constexpr uint32_t kCtrlComposited = 12;   // [2] samples the compositor consumed per phase (<= kCtrlSamples: a ray that terminates inside a round
-                                          //     leaves the rest of its slots of that round evaluated but unused)
-constexpr uint32_t kCtrlHist = 16;     // [kMaxSteps + 2] rays that terminate at cumulative sample index d (d = 1 .. max_steps)
-constexpr uint32_t kCtrlWords = 128;
+// line 1: statistics (two 64-bit adds per workgroup and phase: [samples | tiles << 32], [rounds | composited << 32])
+constexpr uint32_t kCtrlStatA = 32;    // [2 phases] uint64: field evaluations (low word) | 32-sample MFMA tiles executed (high word)
+constexpr uint32_t kCtrlStatB = 36;    // [2 phases] uint64: workgroup rounds (low) | samples the compositor consumed (high; <= evaluations: a ray
+                                       //     that terminates inside a round leaves the rest of its slots of that round evaluated but unused)
+// lines 2..4: terminal-index histogram
+constexpr uint32_t kCtrlHist = 64;     // [kMaxSteps + 2] rays that terminate at cumulative sample index d (d = 1 .. max_steps)
+constexpr uint32_t kCtrlWords = 160;
 
 inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
     FrameWs w;

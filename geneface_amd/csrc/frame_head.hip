@@ -1519,10 +1519,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     }
 #endif
     if (tid == 0) {
-        atomicAdd(&a.ctrl[gf::kCtrlSamples + a.phase], s.misc[10]);
-        atomicAdd(&a.ctrl[gf::kCtrlRounds + a.phase], s.misc[11]);
-        atomicAdd(&a.ctrl[gf::kCtrlTiles + a.phase], s.misc[12]);
-        atomicAdd(&a.ctrl[gf::kCtrlComposited + a.phase], s.misc[9]);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(a.ctrl);
+        atomicAdd(&st[gf::kCtrlStatA / 2 + a.phase], (unsigned long long)s.misc[10] | ((unsigned long long)s.misc[12] << 32));
+        atomicAdd(&st[gf::kCtrlStatB / 2 + a.phase], (unsigned long long)s.misc[11] | ((unsigned long long)s.misc[9] << 32));
     }
 }
 

@@ -604,7 +604,7 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
     (n_alive, n_step) list (renderer.py:330-351) replayed from the terminal-index histogram, `budget` the total number of
     samples a never-terminating ray receives; `budget_device` is the same number as the phase-1 kernel computed it."""
     c = ctrl.cpu().numpy().astype(np.int64)
-    hist = c[16:16 + max_steps + 2]
+    hist = c[64:64 + max_steps + 2]          # control-block layout: geneface_amd/csrc/frame.hpp (kCtrl*)
     sched, cum, dead, d = [], 0, 0, 0
     while cum < max_steps:
         while d < cum:
@@ -617,8 +617,8 @@ def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:
         sched.append((n_alive, n_step))
         cum += n_step
     return {"schedule": sched, "budget": cum, "budget_device": int(c[10]), "n_hit": int(c[1]), "n_survivors": int(c[2]),
-            "samples": (int(c[4]), int(c[5])), "rounds": (int(c[6]), int(c[7])), "tiles": (int(c[8]), int(c[9])),
-            "composited": (int(c[12]), int(c[13]))}
+            "samples": (int(c[32]), int(c[34])), "tiles": (int(c[33]), int(c[35])), "rounds": (int(c[36]), int(c[38])),
+            "composited": (int(c[37]), int(c[39]))}
 
 
 # --------------------------------------------------------------------------------------------- frame-loop step
