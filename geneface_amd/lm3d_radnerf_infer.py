@@ -295,16 +295,54 @@ class LM3d_RADNeRFInfer:
             os.makedirs(os.path.dirname(name) or ".", exist_ok=True)
             np.save(name, frames)
         elif name:
-            import shutil
-            import subprocess
-            if shutil.which("ffmpeg") and inp.get("tmp_imgs_dir"):   # base_nerf_infer.py:307 (video only; the wav is muxed when given)
-                wav = inp.get("audio_source_name") or None
-                cmd = ["ffmpeg", "-y", "-loglevel", "error", "-r", "25", "-i", os.path.join(inp["tmp_imgs_dir"], "%05d.png")]
-                cmd += (["-i", wav] if wav and os.path.exists(wav) else []) + ["-c:v", "libx264", "-pix_fmt", "yuv420p", "-r", "25", name]
-                subprocess.run(cmd, check=True)
-            else:
-                print(f"| {name}: no ffmpeg binary (or no tmp_imgs_dir): the frames are returned / written as PNG only")
+            out = self.postprocess_output(frames)
+            if out:
+                print(f"The synthesized video is saved at {out}")
         return frames
+
+    # ------------------------------------------------------------------ IO (base_nerf_infer.py:255-259, 303-317)
+    def save_wav16k(self, inp: dict):
+        """base_nerf_infer.py:309-317: the audio source resampled to a 16 kHz wav beside it (ffmpeg), remembered as `self.wav16k_name`.
+        Returns the name, or None when there is no audio source or no ffmpeg binary (this image ships none; the frames are still rendered)."""
+        import shutil
+        import subprocess
+        source_name = inp.get("audio_source_name") or ""
+        self.wav16k_name = None
+        if not source_name:
+            return None
+        supported_types = (".wav", ".mp3", ".mp4", ".avi")
+        assert source_name.endswith(supported_types), f"Now we only support {','.join(supported_types)} as audio source!"
+        if not shutil.which("ffmpeg") or not os.path.exists(source_name):
+            return None
+        wav16k_name = source_name[:-4] + "_16k.wav"
+        subprocess.run(["ffmpeg", "-i", source_name, "-v", "quiet", "-f", "wav", "-ar", "16000", wav16k_name, "-y"], check=True)
+        print(f"Saved 16khz wav file to {wav16k_name}.")
+        self.wav16k_name = wav16k_name
+        return wav16k_name
+
+    @classmethod
+    def save_mp4(cls, img_dir: str, wav_name, out_name: str):
+        """base_nerf_infer.py:305-306, the same ffmpeg invocation (25 fps, libx264, yuv420p, 2000k, -shortest against the audio track)."""
+        import subprocess
+        cmd = ["ffmpeg", "-i", os.path.join(img_dir, "%5d.png")]
+        if wav_name:
+            cmd += ["-i", wav_name, "-shortest"]
+        cmd += ["-v", "quiet", "-c:v", "libx264", "-pix_fmt", "yuv420p", "-b:v", "2000k", "-r", "25", "-strict", "-2", "-y", out_name]
+        os.makedirs(os.path.dirname(out_name) or ".", exist_ok=True)
+        subprocess.run(cmd, check=True)
+
+    def postprocess_output(self, output):
+        """base_nerf_infer.py:255-259: mux `<tmp_imgs_dir>/%5d.png` (+ the 16 kHz audio) into `out_video_name`.  Without an ffmpeg binary, or
+        without an image directory, the PNG frames / the returned stack are the output and None is returned."""
+        import shutil
+        tmp_imgs_dir, name = self.inp.get("tmp_imgs_dir"), self.inp.get("out_video_name", "")
+        if not tmp_imgs_dir or not shutil.which("ffmpeg"):
+            print(f"| {name}: no ffmpeg binary (or no tmp_imgs_dir): the frames are returned / written as PNG only")
+            return None
+        if getattr(self, "wav16k_name", None) is None:
+            self.save_wav16k(self.inp)
+        self.save_mp4(tmp_imgs_dir, self.wav16k_name, name)
+        return name
 
     @classmethod
     def example_run(cls, inp: dict, hparams: dict = None, config: str = None, hparams_str: str = "", config_root: str = None, **kw):
@@ -314,4 +352,11 @@ class LM3d_RADNeRFInfer:
         from .hparams import load_config, may_hparams
         if hparams is None:
             hparams = load_config(config, hparams_str, root=config_root) if config else may_hparams(True)
+        inp = dict(inp)
+        for key in ("cond_name", "audio_source_name", "out_video_name"):          # base_nerf_infer.py:284-291: hparams override the inputs
+            if hparams.get("infer_" + key, "") != "":
+                inp[key] = hparams["infer_" + key]
+        name = inp.get("out_video_name", "")
+        if name and not name.endswith(".npy") and not inp.get("tmp_imgs_dir"):    # :292-298: <out_dir>/tmp_imgs/<video name>
+            inp["tmp_imgs_dir"] = os.path.join(os.path.dirname(name), "tmp_imgs", os.path.basename(name)[:-4])
         return cls(hparams, **kw).infer_once(inp)

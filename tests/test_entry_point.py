@@ -283,3 +283,42 @@ def test_infer_once_shard_is_the_ranks_block_of_the_whole_run(tmp_path):
     assert seen == list(range(T))
     with pytest.raises(ValueError):
         inf.infer_once({"cond_name": cond_path, "out_video_name": "", "audio_source_name": "", "shard": (3, 3)})
+
+
+def test_postprocess_runs_the_references_ffmpeg_commands(tmp_path, monkeypatch):
+    """base_nerf_infer.py:255-259, 303-317: after the frames, rank 0 resamples the audio source to a 16 kHz wav and muxes
+    `<tmp_imgs_dir>/%5d.png` + that wav into out_video_name.  No ffmpeg binary exists in this image, so a recording stand-in on PATH checks
+    the two command lines (the reference's, argument for argument); without any ffmpeg the entry point says so and returns the frames."""
+    import json
+    import stat
+    log = tmp_path / "ffmpeg_calls.jsonl"
+    fake = tmp_path / "bin" / "ffmpeg"
+    fake.parent.mkdir()
+    fake.write_text(f"#!{os.sys.executable}\nimport json, sys\nopen({str(log)!r}, 'a').write(json.dumps(sys.argv[1:]) + '\\n')\n"
+                    "out = [a for a in sys.argv[1:] if a.endswith(('.wav', '.mp4')) and not a.startswith('-')][-1]\nopen(out, 'wb').write(b'x')\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    hp = HP.may_hparams(True)
+    dd, _ = _ds_dict(T=6, H=16, W=16)
+    inf = LM3d_RADNeRFInfer.__new__(LM3d_RADNeRFInfer)      # host logic only
+    inf.hparams, inf.dataset, inf.proc_rank = hp, RADNeRFPoseSource(dd, hp), 0
+    frames = np.zeros((4, 16, 16, 3), dtype=np.uint8)
+    inf.forward_system = lambda samples, collect=True: frames
+    cond = tmp_path / "lm.npy"
+    np.save(cond, S.make_landmarks(4).astype(np.float32)[None])
+    wav = tmp_path / "zozo.wav"
+    wav.write_bytes(b"RIFF")
+    inp = {"cond_name": str(cond), "audio_source_name": str(wav), "out_video_name": str(tmp_path / "out" / "zozo.mp4"), "tmp_imgs_dir": str(tmp_path / "imgs")}
+    # no ffmpeg anywhere: frames come back, nothing is muxed
+    monkeypatch.setenv("PATH", str(tmp_path / "empty"))
+    assert inf.infer_once(dict(inp)) is frames and not log.exists()
+    # with the stand-in on PATH
+    monkeypatch.setenv("PATH", str(fake.parent))
+    assert inf.infer_once(dict(inp)) is frames
+    calls = [json.loads(ln) for ln in log.read_text().splitlines()]
+    wav16k = str(wav)[:-4] + "_16k.wav"
+    assert calls[0] == ["-i", str(wav), "-v", "quiet", "-f", "wav", "-ar", "16000", wav16k, "-y"]
+    assert calls[1] == ["-i", os.path.join(str(tmp_path / "imgs"), "%5d.png"), "-i", wav16k, "-shortest", "-v", "quiet", "-c:v", "libx264", "-pix_fmt",
+                        "yuv420p", "-b:v", "2000k", "-r", "25", "-strict", "-2", "-y", inp["out_video_name"]]
+    assert os.path.exists(inp["out_video_name"]) and inf.wav16k_name == wav16k
+    with pytest.raises(AssertionError):
+        inf.save_wav16k({"audio_source_name": str(tmp_path / "zozo.flac")})
