@@ -241,6 +241,16 @@ __device__ __forceinline__ void obw_mfma(WP& wp, const char* __restrict__ Ws, ui
 }
 
 template <int NT>
+__device__ __forceinline__ void obw_bias_n(const float* bias16, floatx16 (&acc)[NT]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 b = reinterpret_cast<const float4*>(bias16)[q];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w; }
+    }
+}
+
+template <int NT>
 __device__ __forceinline__ void obw_zero(floatx16 (&acc)[4]) {
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -929,79 +939,80 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)__builtin_fmaf((float)hi, -gf::kSplitScale, c * gf::kSplitScale);   // (tools/mfma_denorm_probe.hip, profiles/round3/mfma_denorm_probe.txt)
 }
 
-// U groups (K = 16 each) of this wave's output block over nt tiles.  Hb = &H[lane & 31][8 * (lane >> 5)] (hi part; lo' 128 halves on).
-// B operands run ONE tile ahead of the MFMAs that consume them within a group (two tiles' worth of registers, not four: the accumulators of
-// the two product terms already take 128 of the 256 a lane has at two workgroups per CU; carrying the prefetch across group boundaries in
-// two alternating register sets spilled 67 VGPRs).
+// U groups (K = 16 each) of this wave's output block over NT tiles -- NT is a COMPILE-TIME count (4, or 2 for the thin rounds of phase 1): with
+// a run-time tile count every tile's MFMAs and loads sat behind their own branch, the LDS reads were serialised by waits and a K = 128
+// layer took 5 000 cycles of a wave where its 96 MFMAs need 3 072 (profiles/round3/r3r_*).  A round with 3 (or 1) tiles runs the 4- (2-)
+// tile code: the surplus tile multiplies whatever the activation rows beyond the round's samples hold, and nothing reads its results
+// (columns of an MFMA are independent) -- 2.7 % of all tiles.  Hb = &H[lane & 31][8 * (lane >> 5)] (hi part; lo' 128 halves on).
+// B operands run ONE tile ahead of the MFMAs that consume them, across group boundaries, in two register sets that alternate with the tile
+// index (the accumulators of the two product terms already take 128 of the 256 registers a lane has at two workgroups per CU).
 __device__ __forceinline__ void bset_load(half8& h, half8& l, const _Float16* p) {
     h = *reinterpret_cast<const half8*>(p);
     l = *reinterpret_cast<const half8*>(p + 128);
 }
-// one tile of one group: MFMAs from set (bh, bl); the other set (oh, ol) receives the next tile's operands -- or, behind an odd tile (which
-// reads set 1), set 0 takes tile 0 of the next group.  No register copies: the two sets alternate with the tile index.
-template <int T, int u, int U>
-__device__ __forceinline__ void obws_tile(const half8& wh, const half8& wl, const _Float16* Hb, floatx16& a1, floatx16& a2, int nt, const half8& bh,
+// one tile of one group: MFMAs from set (bh, bl) while the other set (oh, ol) receives the next tile's operands (behind the last tile of a
+// group -- NT is even, so that tile reads set 1 -- set 0 takes tile 0 of the next group).  ZC1 / ZC2: first group of a layer, the accumulator
+// holds nothing yet: a literal zero as C operand instead of a register clear.
+template <int NT, int T, int u, int U, bool ZC1, bool ZC2>
+__device__ __forceinline__ void obws_tile(const half8& wh, const half8& wl, const _Float16* Hb, floatx16& a1, floatx16& a2, const half8& bh,
                                           const half8& bl, half8& oh, half8& ol) {
-    if (T < nt) {
-        if (T + 1 < nt) bset_load(oh, ol, Hb + (T + 1) * 32 * kHSS + 16 * u);
-#ifndef GF_SPLIT_NO_XPREFETCH
-        else if ((T & 1) && u + 1 < U) bset_load(oh, ol, Hb + 16 * (u + 1));
-#endif
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2, 0, 0, 0);
-    }
+    if constexpr (T + 1 < NT) bset_load(oh, ol, Hb + (T + 1) * 32 * kHSS + 16 * u);
+    else if constexpr (u + 1 < U) bset_load(oh, ol, Hb + 16 * (u + 1));
+    __builtin_amdgcn_sched_barrier(0);     // the next tile's two LDS reads stay IN FRONT of this tile's three MFMAs (96 cycles of issue to land in);
+                                           // left alone the scheduler sinks them to just before their use and every tile waits for LDS
+    const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // acc2's two MFMAs are separated by acc1's: no MFMA waits for the result of the one issued just before it
+    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, ZC2 ? zero : a2, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, ZC1 ? zero : a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
-template <int G0, int U, int u>
-__device__ __forceinline__ void obws_step(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
-                                          floatx16 (&a2)[4], int nt, half8& b0h, half8& b0l, half8& b1h, half8& b1l) {
+template <int NT, int G0, int U, int u, bool FIRST, bool BIAS>
+__device__ __forceinline__ void obws_step(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[NT],
+                                          floatx16 (&a2)[NT], half8& b0h, half8& b0l, half8& b1h, half8& b1l) {
+    static_assert(NT == 2 || NT == 4, "an even tile count: the two B-operand sets alternate with the tile index");
     if constexpr (u < U) {
         const half8 wh = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][0]), wl = __builtin_bit_cast(half8, wp.q[(G0 + u) % 2][1]);
-#ifndef GF_SPLIT_NO_XPREFETCH
-        if (u > 0 && (nt & 1)) bset_load(b0h, b0l, Hb + 16 * u);     // odd tile count (a thin round): set 0 was busy until the end of the last group
-#else
-        if (u > 0) bset_load(b0h, b0l, Hb + 16 * u);
-#endif
-        obws_tile<0, u, U>(wh, wl, Hb, a1[0], a2[0], nt, b0h, b0l, b1h, b1l);
-        obws_tile<1, u, U>(wh, wl, Hb, a1[1], a2[1], nt, b1h, b1l, b0h, b0l);
-        obws_tile<2, u, U>(wh, wl, Hb, a1[2], a2[2], nt, b0h, b0l, b1h, b1l);
-        obws_tile<3, u, U>(wh, wl, Hb, a1[3], a2[3], nt, b1h, b1l, b0h, b0l);
+        constexpr bool Z1 = FIRST && u == 0 && !BIAS, Z2 = FIRST && u == 0;
+        obws_tile<NT, 0, u, U, Z1, Z2>(wh, wl, Hb, a1[0], a2[0], b0h, b0l, b1h, b1l);
+        obws_tile<NT, 1, u, U, Z1, Z2>(wh, wl, Hb, a1[1], a2[1], b1h, b1l, b0h, b0l);
+        if constexpr (NT == 4) {
+            obws_tile<NT, 2, u, U, Z1, Z2>(wh, wl, Hb, a1[2], a2[2], b0h, b0l, b1h, b1l);
+            obws_tile<NT, 3, u, U, Z1, Z2>(wh, wl, Hb, a1[3], a2[3], b1h, b1l, b0h, b0l);
+        }
         wpipes_refill<G0 + u>(wp, Ws, lane32);
         __builtin_amdgcn_sched_barrier(0);
-        obws_step<G0, U, u + 1>(wp, Ws, lane32, Hb, a1, a2, nt, b0h, b0l, b1h, b1l);
+        obws_step<NT, G0, U, u + 1, FIRST, BIAS>(wp, Ws, lane32, Hb, a1, a2, b0h, b0l, b1h, b1l);
     }
 }
-template <int G0, int U, bool FIRST, bool BIAS = false>
-__device__ __forceinline__ void obws_mfma(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[4],
-                                          floatx16 (&a2)[4], int nt) {
-    // FIRST: the layer starts here.  (A literal-zero C operand in the first group's MFMAs would save the 128 register clears, but leaves the
-    // accumulators of the tiles beyond nt undefined, and the allocator then spills 66 VGPRs: measured, not kept.)
-    if (FIRST) { if (!BIAS) obw_zero<4>(a1); obw_zero<4>(a2); }
+// FIRST: the layer starts with this call (acc2 from zero; acc1 from zero, or from the bias the caller loaded when BIAS)
+template <int NT, int G0, int U, bool FIRST, bool BIAS = false>
+__device__ __forceinline__ void obws_mfma(WPipeS& wp, const char* __restrict__ Ws, uint32_t lane32, const _Float16* Hb, floatx16 (&a1)[NT],
+                                          floatx16 (&a2)[NT]) {
     half8 b0h, b0l, b1h, b1l;
     bset_load(b0h, b0l, Hb);
     b1h = b0h; b1l = b0l;
-    obws_step<G0, U, 0>(wp, Ws, lane32, Hb, a1, a2, nt, b0h, b0l, b1h, b1l);
+    obws_step<NT, G0, U, 0, FIRST, BIAS>(wp, Ws, lane32, Hb, a1, a2, b0h, b0l, b1h, b1l);
 }
 
 // accumulators -> split activations.  Hw = &H[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves, twice.
-template <bool RELU>
-__device__ __forceinline__ void obws_store(_Float16* Hw, const floatx16 (&a1)[4], const floatx16 (&a2)[4], int nt) {
+template <int NT, bool RELU>
+__device__ __forceinline__ void obws_store(_Float16* Hw, const floatx16 (&a1)[NT], const floatx16 (&a2)[NT]) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-        if (t < nt) {
+    for (int t = 0; t < NT; t++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                half4 h, l;
+        for (int q = 0; q < 4; q++) {
+            half4 h, l;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    _Float16 hh, ll;
-                    split_f16<RELU>(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]), hh, ll);
-                    h[i] = hh; l[i] = ll;
-                }
-                *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q) = h;
-                *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q + 128) = l;
+            for (int i = 0; i < 4; i++) {
+                _Float16 hh, ll;
+                split_f16<RELU>(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]), hh, ll);
+                h[i] = hh; l[i] = ll;
             }
+            *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q) = h;
+            *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q + 128) = l;
         }
+    }
 }
 
 template <int NOUT>
@@ -1050,6 +1061,8 @@ __device__ __forceinline__ void store16s(_Float16* dst, const float (&f)[16]) {
     }
 }
 
+// NT: compile-time MFMA tile count of the round (4, or 2 when the round holds <= 64 samples); nt = ceil(Mv / 32) <= NT gates the per-sample work.
+template <int NT>
 __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
@@ -1065,7 +1078,7 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     uint32_t lane32 = (uint32_t)lane * 32u;
     asm volatile("" : "+v"(lane32));
     const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
-    floatx16 A1[4], A2[4];
+    floatx16 A1[NT], A2[NT];
     WPipeS wp;
     load_group_s(wp.q[0], Ws, 0, lane32);
     load_group_s(wp.q[1], Ws, 1, lane32);
@@ -1084,21 +1097,21 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     __syncthreads();
     GF_STAMP(8);
     // ---- ambient L1 (cond_feat folded into the bias)
-    obw_bias<4>(s.P + P_AMBBIAS + wave * 32 + half * 16, A1);
-    obws_mfma<gf::SP_AMB1, 2, true, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obw_bias_n<NT>(s.P + P_AMBBIAS + wave * 32 + half * 16, A1);
+    obws_mfma<NT, gf::SP_AMB1, 2, true, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(9);
     __syncthreads();
     GF_STAMP(10);
-    obws_store<true>(Hw, A1, A2, nt);
+    obws_store<NT, true>(Hw, A1, A2);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
     // ---- ambient L2
-    obws_mfma<gf::SP_AMB2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<NT, gf::SP_AMB2, 8, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(13);
     __syncthreads();
     GF_STAMP(14);
-    obws_store<true>(Hw, A1, A2, nt);
+    obws_store<NT, true>(Hw, A1, A2);
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
@@ -1117,20 +1130,20 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     __syncthreads();
     GF_STAMP(18);
     // ---- density L1: K = 64
-    obws_mfma<gf::SP_SIG1, 4, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<NT, gf::SP_SIG1, 4, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(19);
     __syncthreads();
     GF_STAMP(20);
-    obws_store<true>(Hw, A1, A2, nt);
+    obws_store<NT, true>(Hw, A1, A2);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
     // ---- density L2
-    obws_mfma<gf::SP_SIG2, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<NT, gf::SP_SIG2, 8, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(23);
     __syncthreads();
     GF_STAMP(24);
-    obws_store<true>(Hw, A1, A2, nt);
+    obws_store<NT, true>(Hw, A1, A2);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -1140,51 +1153,50 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
         rows_from_lds_split<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
         if (valid && half == 0) s.sx[raw] = expf(h0[0]);     // the position slots were consumed before the first barrier of this function
     }
-    obws_mfma<gf::SP_SIG3, 8, true>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<NT, gf::SP_SIG3, 8, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(27);
     __syncthreads();
     GF_STAMP(28);
-    obws_store<false>(Hw, A1, A2, nt);
+    obws_store<NT, false>(Hw, A1, A2);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
-    obw_bias<4>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1);
-    obw_zero<4>(A2);
+    obw_bias_n<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A1);
     {
         const half8 wh = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][0]), wl = __builtin_bit_cast(half8, wp.q[gf::SP_COL1S % 2][1]);
+        const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            if (t < nt) {
-                uint32_t d = (uint32_t)(t * 32 + j);
-                d = d < Mv ? d : Mv - 1u;
-                const uint32_t slot = s.rrank[d];
-                float sh[16];
-                gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
-                half8 sh_h, sh_l;
+        for (int t = 0; t < NT; t++) {
+            uint32_t d = (uint32_t)(t * 32 + j);
+            d = d < Mv ? d : Mv - 1u;
+            const uint32_t slot = s.rrank[d];
+            float sh[16];
+            gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
+            half8 sh_h, sh_l;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    // both candidates pass through an opaque move first: otherwise the select of two array elements becomes ONE element at a
-                    // lane-dependent index, and the 16-entry array moves to scratch
-                    float v0 = sh[i], v1 = sh[8 + i];
-                    asm("" : "+v"(v0));
-                    asm("" : "+v"(v1));
-                    _Float16 hh, ll;
-                    split_f16<false>(half ? v1 : v0, hh, ll);
-                    sh_h[i] = hh; sh_l[i] = ll;
-                }
-                A1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_h, A1[t], 0, 0, 0);
-                A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, sh_h, A2[t], 0, 0, 0);
-                A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_l, A2[t], 0, 0, 0);
+            for (int i = 0; i < 8; i++) {
+                // both candidates pass through an opaque move first: otherwise the select of two array elements becomes ONE element at a
+                // lane-dependent index, and the 16-entry array moves to scratch
+                float v0 = sh[i], v1 = sh[8 + i];
+                asm("" : "+v"(v0));
+                asm("" : "+v"(v1));
+                _Float16 hh, ll;
+                split_f16<false>(half ? v1 : v0, hh, ll);
+                sh_h[i] = hh; sh_l[i] = ll;
             }
+            A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, sh_h, zero, 0, 0, 0);
+            A1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_h, A1[t], 0, 0, 0);
+            A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_l, A2[t], 0, 0, 0);
+        }
         wpipes_refill<gf::SP_COL1S>(wp, Ws, lane32);
         __builtin_amdgcn_sched_barrier(0);
     }
-    obws_mfma<gf::SP_COL1G, 8, false>(wp, Ws, lane32, Hb, A1, A2, nt);
+    obws_mfma<NT, gf::SP_COL1G, 8, false>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(31);
     __syncthreads();
     GF_STAMP(32);
-    obws_store<true>(Hw, A1, A2, nt);
+    obws_store<NT, true>(Hw, A1, A2);
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
@@ -1431,7 +1443,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             if constexpr (MODE == 1) {
                 field_round16(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
             } else if constexpr (MODE == 2) {
-                field_round_split(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
+                // two instantiations, ONE arithmetic: every floating-point operation of the round is an explicit builtin (MFMA, fmaf, med3,
+                // round-to-nearest conversions), so which of them evaluates a sample cannot change its value (the fast tier once differed
+                // between instantiations through its conversions' instruction selection; test_full_size_frames_are_reproducible[split])
+                if (nt <= 2) field_round_split<2>(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
+                else field_round_split<4>(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
             } else {
                 if (nt == 4) field_round<4>(a, s, Mv, wave, lane);
                 else if (nt == 3) field_round<3>(a, s, Mv, wave, lane);
