@@ -20,10 +20,10 @@ constexpr uint32_t kMaxSteps = 64;  // largest max_steps the fused path accepts
 // retires atomics on one line at ~10 ns each, and the queue heads -- on the critical path of every pool refill -- used to share a line with
 // the statistics and the histogram that every retiring workgroup adds to.
 // line 0: work distribution
-constexpr uint32_t kCtrlQHead0 = 0;    // phase 0: next unclaimed entry of the hit list BEYOND the static blocks (frame_head.hip, first_fill)
+constexpr uint32_t kCtrlQHead0 = 0;    // phase 0: next unclaimed entry of the hit list
 constexpr uint32_t kCtrlNHit = 1;      // rays with >= 1 sample (length of the hit list, alive_b)
 constexpr uint32_t kCtrlNSurv = 2;     // rays still alive after max_steps samples (length of the survivor list, alive_a)
-constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list beyond the static blocks
+constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list
 constexpr uint32_t kCtrlBudget = 10;   // total per-ray sample budget B the reference's n_step schedule arrives at
 // line 1: statistics (two 64-bit adds per workgroup and phase: [samples | tiles << 32], [rounds | composited << 32])
 constexpr uint32_t kCtrlStatA = 32;    // [2 phases] uint64: field evaluations (low word) | 32-sample MFMA tiles executed (high word)

@@ -1289,11 +1289,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     // statistics: s.misc[10..12] = samples, rounds, tiles of this workgroup (thread 0 adds per round; LDS, not three registers)
     if (tid == 0) { s.misc[10] = 0; s.misc[11] = 0; s.misc[12] = 0; }
     bool queue_open = true;         // uniform
-    // The first refill of every workgroup is a STATIC block of the queue (workgroup b takes entries [b, b + 1) * pool_cap), the dynamic queue
-    // serves what lies beyond gridDim.x * pool_cap: at launch all 1 024 owner waves used to hit one queue-head word at once, and L2 retires
-    // same-address atomics at ~10 ns each (the same chain that was k_frame_init's whole duration, profiles/round3/r3l_init_ab.txt).
-    bool first_fill = true;         // uniform
-    const uint32_t q_off = gridDim.x * pool_cap;
+    // (Round 3 tried a STATIC block of the queue as every workgroup's first refill -- at launch all 1 024 owner waves hit one queue-head word,
+    // and L2 retires same-address atomics at ~10 ns each.  Alone on the GPU the launch got 1-2 % shorter; with four frames in flight the
+    // frame rate DROPPED 1 % (fp32: 727 vs 734 fps, profiles/round3/r3w_static_fill_ab.txt): a workgroup that is scheduled late -- its CU
+    // still busy with another frame -- then sits on 128 rays nobody else can take.  The dynamic queue stays.)
 #ifdef GF_TRACE
     uint32_t tr_round = 0;
     unsigned long long span_t1 = span_t0, span_r1 = span_r0;   // end of the last round
@@ -1319,14 +1318,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             const unsigned long long m = __ballot(want);
             const uint32_t nw = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (!first_fill) {
-                if (lane == 0 && nw) base = atomicAdd(&a.ctrl[qhead], nw);
-                base = q_off + __shfl(base, 0);
-            }
+            if (lane == 0 && nw) base = atomicAdd(&a.ctrl[qhead], nw);
+            base = __shfl(base, 0);
             if (want) {
-                // first fill: every lane below pool_cap wants a ray, lane tid takes entry blockIdx.x * pool_cap + tid
-                const uint32_t idx = first_fill ? (uint32_t)blockIdx.x * s.misc[15] + (uint32_t)tid
-                                                : base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (idx < s.misc[14]) {
                     ray = a.queue[idx];
                     const float* d = a.rays_d + (size_t)ray * 3;
@@ -1342,9 +1337,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
                 }
             }
-            if (lane == 0) s.misc[4 + wave] = (!first_fill && nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
+            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
         }
-        first_fill = false;
         GF_STAMP(1);
         // ------------------------------------------------------------------ pool census
         const bool alive = ray >= 0;
