@@ -553,7 +553,7 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
                 pk = PEAK_F16_MFMA_TFLOPS / 3.0
                 r["mfma"] = {"achieved_f32_equivalent": r["mfma_tflops_f32_equivalent"], "peak": pk, "unit": "TFLOP/s", "frac": r["mfma_tflops_f32_equivalent"] / pk,
                              "note": "fp32-equivalent algorithmic FLOPs / (f16 dense peak / 3): the matrix pipe is a quarter busy; the round is gathers, "
-                                     "f32 <-> split conversions, march / composite and barriers (profiles/round3/r3i_head_timeline_split.txt)"}
+                                     "f32 <-> split conversions, march / composite and barriers (profiles/round3/r3s_head_timeline_split.txt)"}
             return r
         r["traffic"], r["traffic_source"] = pmc_traffic()
         return r
