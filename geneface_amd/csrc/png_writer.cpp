@@ -82,8 +82,17 @@ struct Writer {
     std::mutex mu;
     std::condition_variable cv_job, cv_room;
     bool closing = false;
-    std::atomic<int> failed{0};
+    std::atomic<int> failed{0};   // set AFTER err is complete (release), read with acquire: a reader that sees 1 sees the whole message
     char err[256] = "";
+    std::mutex err_mu;
+
+    void fail(const char* what, const char* path, uint32_t idx) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (failed.load(std::memory_order_relaxed)) return;   // keep the first error
+        if (path) snprintf(err, sizeof(err), "png_writer: %s %s", what, path);
+        else snprintf(err, sizeof(err), "png_writer: %s %u", what, idx);
+        failed.store(1, std::memory_order_release);
+    }
     // per-stage seconds summed over the workers (and the submit side's copy), for the bench line
     std::mutex st_mu;
     double t_copy = 0, t_deflate = 0, t_write = 0, t_wait_room = 0;
@@ -112,9 +121,9 @@ struct Writer {
                 FILE* fh = fopen(path.c_str(), "wb");
                 ok = fh && fwrite(out.data(), 1, out.size(), fh) == out.size();
                 if (fh) ok = (fclose(fh) == 0) && ok;
-                if (!ok && !failed.exchange(1)) snprintf(err, sizeof(err), "png_writer: cannot write %s", path.c_str());
-            } else if (!failed.exchange(1)) {
-                snprintf(err, sizeof(err), "png_writer: deflate failed on frame %u", job.idx);
+                if (!ok) fail("cannot write", path.c_str(), job.idx);
+            } else {
+                fail("deflate failed on frame", nullptr, job.idx);
             }
             const auto t2 = clk::now();
             std::lock_guard<std::mutex> g(st_mu);
@@ -157,7 +166,7 @@ GF_EXPORT int gf_png_writer_submit(void* handle, uint32_t idx, const uint8_t* rg
         std::lock_guard<std::mutex> g(w->st_mu);
         w->t_copy += secs(t0, t1); w->t_wait_room += secs(t1, t2);
     }
-    return w->failed.load() ? gf_set_error(GF_ERR_INVALID, "%s", w->err) : GF_OK;
+    return w->failed.load(std::memory_order_acquire) ? gf_set_error(GF_ERR_INVALID, "%s", w->err) : GF_OK;
 }
 
 // Waits for every queued frame, joins the workers, frees the writer.  stats_out_host (or NULL) [6]: seconds spent copying frames in (submit
@@ -175,7 +184,7 @@ GF_EXPORT int gf_png_writer_close(void* handle, double* stats_out_host) {
         stats_out_host[0] = w->t_copy; stats_out_host[1] = w->t_wait_room; stats_out_host[2] = w->t_deflate; stats_out_host[3] = w->t_write;
         stats_out_host[4] = (double)w->n_done; stats_out_host[5] = (double)w->bytes_out;
     }
-    const int failed = w->failed.load();
+    const int failed = w->failed.load(std::memory_order_acquire);
     int rc = GF_OK;
     if (failed) rc = gf_set_error(GF_ERR_INVALID, "%s", w->err);
     delete w;
