@@ -605,6 +605,7 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
 // tasks/radnerfs/radnerf.py:359, inference/nerfs/radnerf_gui.py:604-605); BASELINE.md section 4 sets its parity bar (PSNR >= 40 dB).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 constexpr int kHS16 = 136;            // halves per activation row
 constexpr int kFS16 = 72;             // halves per row of the 3-D feature buffer (32 used; 144 B: rows 16 B apart in bank space)
 static_assert((kPass * kHS16 + kPass * kFS16 + kPool * 16) * 2 <= kPass * kHS * 4, "f16 activations + 3-D features + SH table fit the fp32 activation buffer");
@@ -938,6 +939,22 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     // (c - hi) * 2^11, exactly (the difference has at most 13 significant bits), as ONE fused op on the f16 register: v_fma_mix_f32
     lo = (_Float16)__builtin_fmaf((float)hi, -gf::kSplitScale, c * gf::kSplitScale);   // (tools/mfma_denorm_probe.hip, profiles/round3/mfma_denorm_probe.txt)
 }
+// Two values at once, the same arithmetic: ONE v_cvt_pk_f16_f32 makes both hi halves, and the two fused ops read them out of that packed
+// register (op_sel).  Written value by value, the compiler converts every hi twice -- once alone for the fused op, once more inside the
+// packing conversion: 5.5 instead of 4.5 VALU ops per written value, in segments that are nothing but these ops (the opaque move between
+// the conversion and its uses is what keeps the packed register the only copy).
+template <bool RELU>
+__device__ __forceinline__ void split_f16x2(float v0, float v1, half2v& hi, half2v& lo) {
+    const float c0 = __builtin_amdgcn_fmed3f(v0, RELU ? 0.0f : -65504.0f, 65504.0f);
+    const float c1 = __builtin_amdgcn_fmed3f(v1, RELU ? 0.0f : -65504.0f, 65504.0f);
+    half2v hp = {(_Float16)c0, (_Float16)c1};
+    uint32_t bits = __builtin_bit_cast(uint32_t, hp);
+    asm("" : "+v"(bits));
+    hp = __builtin_bit_cast(half2v, bits);
+    hi = hp;
+    lo[0] = (_Float16)__builtin_fmaf((float)hp[0], -gf::kSplitScale, c0 * gf::kSplitScale);
+    lo[1] = (_Float16)__builtin_fmaf((float)hp[1], -gf::kSplitScale, c1 * gf::kSplitScale);
+}
 
 // U groups (K = 16 each) of this wave's output block over NT tiles -- NT is a COMPILE-TIME count (4, or 2 for the thin rounds of phase 1): with
 // a run-time tile count every tile's MFMAs and loads sat behind their own branch, the LDS reads were serialised by waits and a K = 128
@@ -1004,10 +1021,11 @@ __device__ __forceinline__ void obws_store(_Float16* Hw, const floatx16 (&a1)[NT
         for (int q = 0; q < 4; q++) {
             half4 h, l;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                _Float16 hh, ll;
-                split_f16<RELU>(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]), hh, ll);
-                h[i] = hh; l[i] = ll;
+            for (int i = 0; i < 4; i += 2) {
+                half2v hh, ll;
+                split_f16x2<RELU>(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]),
+                                  __builtin_fmaf(a2[t][4 * q + i + 1], gf::kSplitInv, a1[t][4 * q + i + 1]), hh, ll);
+                h[i] = hh[0]; h[i + 1] = hh[1]; l[i] = ll[0]; l[i + 1] = ll[1];
             }
             *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q) = h;
             *reinterpret_cast<half4*>(Hw + t * 32 * kHSS + 8 * q + 128) = l;
@@ -1051,10 +1069,10 @@ __device__ __forceinline__ void store16s(_Float16* dst, const float (&f)[16]) {
     for (int q = 0; q < 2; q++) {
         half8 h, l;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            _Float16 hh, ll;
-            split_f16<false>(f[8 * q + i], hh, ll);
-            h[i] = hh; l[i] = ll;
+        for (int i = 0; i < 8; i += 2) {
+            half2v hh, ll;
+            split_f16x2<false>(f[8 * q + i], f[8 * q + i + 1], hh, ll);
+            h[i] = hh[0]; h[i + 1] = hh[1]; l[i] = ll[0]; l[i + 1] = ll[1];
         }
         reinterpret_cast<half8*>(dst)[q] = h;
         reinterpret_cast<half8*>(dst + 128)[q] = l;
@@ -1175,15 +1193,17 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
             gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
             half8 sh_h, sh_l;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 8; i += 2) {
                 // both candidates pass through an opaque move first: otherwise the select of two array elements becomes ONE element at a
                 // lane-dependent index, and the 16-entry array moves to scratch
-                float v0 = sh[i], v1 = sh[8 + i];
+                float v0 = sh[i], v1 = sh[8 + i], u0 = sh[i + 1], u1 = sh[9 + i];
                 asm("" : "+v"(v0));
                 asm("" : "+v"(v1));
-                _Float16 hh, ll;
-                split_f16<false>(half ? v1 : v0, hh, ll);
-                sh_h[i] = hh; sh_l[i] = ll;
+                asm("" : "+v"(u0));
+                asm("" : "+v"(u1));
+                half2v hh, ll;
+                split_f16x2<false>(half ? v1 : v0, half ? u1 : u0, hh, ll);
+                sh_h[i] = hh[0]; sh_h[i + 1] = hh[1]; sh_l[i] = ll[0]; sh_l[i + 1] = ll[1];
             }
             A2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, sh_h, zero, 0, 0, 0);
             A1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, sh_h, A1[t], 0, 0, 0);
