@@ -197,71 +197,89 @@ __device__ __forceinline__ LevelMeta make_level_meta(float scale, uint32_t resol
     return m;
 }
 
-// Eight consecutive levels at one point x (already mapped to [0,1]) -> f[16] = [level][channel].  All 8 * 2^D table reads
-// are independent straight-line loads, so they are in flight together.
+// Eight consecutive levels at one point x (already mapped to [0,1]) -> f[16] = [level][channel].
+// Two explicit steps per batch of levels (four 3-D levels = 32 reads, all eight 2-D levels = 32 reads): every table read of the batch is
+// ISSUED, then a scheduling barrier, then the interpolation consumes them in the reference's corner order.  Left to itself the scheduler
+// either hoists all reads (what it did until the index arithmetic changed) or -- same source shape, other heuristics outcome -- puts a
+// full wait behind every single read; the barrier takes the choice away.
 template <uint32_t D>
 __device__ __forceinline__ void encode8(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t gridtype,
                                         uint32_t interp, const float (&x)[D], float (&f)[16]) {
     static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
+    constexpr int LB = D == 3 ? 4 : 8, NC = 1 << D;
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
     const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
+    (void)gridtype;
 #pragma unroll
-    for (int l = 0; l < 8; l++) {
-        const uint4 m0 = reinterpret_cast<const uint4*>(meta8)[2 * l];
-        const uint2 m1 = reinterpret_cast<const uint2*>(meta8)[4 * l + 2];
-        const float scale = __uint_as_float(m0.x);
-        const uint32_t s1 = m0.y, s2 = m0.z, mask = m0.w, row_off = m1.x, use_hash = m1.y;
-        float w1[D], w0[D];
-        uint32_t g[D];
+    for (int b = 0; b < 8 / LB; b++) {
+        float2 v[LB][NC];
+        float pw[LB][D];
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
-            const float fl = floorf(p);
-            g[d] = (uint32_t)fl;
-            p -= fl;
-            if (interp == 1) p = p * p * (3.0f - 2.0f * p);
-            w1[d] = p;
-            w0[d] = 1 - p;
-        }
-        uint32_t ix[2], iy[2], iz[2] = {0u, 0u};
-        if (gridtype == 0) {  // kernel-uniform
-            // hashed levels xor prime multiples, dense levels of a hash grid still use the strided index
-            ix[0] = g[0]; ix[1] = g[0] + 1u;
-            const uint32_t y0h = g[1] * P1, y0t = g[1] * s1;
-            iy[0] = use_hash ? y0h : y0t; iy[1] = use_hash ? y0h + P1 : y0t + s1;
-            if constexpr (D == 3) {
-                const uint32_t z0h = g[2] * P2, z0t = g[2] * s2;
-                iz[0] = use_hash ? z0h : z0t; iz[1] = use_hash ? z0h + P2 : z0t + s2;
+        for (int k = 0; k < LB; k++) {
+            const int l = b * LB + k;
+            const uint4 m0 = reinterpret_cast<const uint4*>(meta8)[2 * l];
+            const uint2 m1 = reinterpret_cast<const uint2*>(meta8)[4 * l + 2];
+            const float scale = __uint_as_float(m0.x);
+            const uint32_t s1 = m0.y, s2 = m0.z, mask = m0.w, row_off = m1.x, use_hash = m1.y;
+            uint32_t g[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
+                const float fl = floorf(p);
+                g[d] = (uint32_t)fl;
+                p -= fl;
+                if (interp == 1) p = p * p * (3.0f - 2.0f * p);
+                pw[k][d] = p;
             }
-        } else {
-            ix[0] = g[0]; ix[1] = g[0] + 1u;
-            iy[0] = g[1] * s1; iy[1] = iy[0] + s1;
-            if constexpr (D == 3) { iz[0] = g[2] * s2; iz[1] = iz[0] + s2; }
-        }
-        float o0 = 0.0f, o1 = 0.0f;
-#pragma unroll
-        for (uint32_t c = 0; c < (1u << D); c++) {
-            const uint32_t bx = c & 1u, by = (c >> 1) & 1u, bz = (c >> 2) & 1u;
-            float w = bx ? w1[0] : w0[0];
-            w *= by ? w1[1] : w0[1];
-            uint32_t idx;
+            // Index of corner (bx, by, bz): hashed levels xor prime multiples, dense levels (and tiled grids) add strided coordinates.  ONE
+            // expression serves both, ((x ^ yh) + yt ^ zh) + zt with the unused half of each pair zeroed by the level's mask (use_hash is
+            // all ones or zero; it is zero on every level of a tiled grid): two v_xad_u32 per corner instead of both index forms and a
+            // select, one quarter-rate integer multiply per dimension instead of two.
+            const uint32_t hm = use_hash, dm = ~use_hash;
+            const uint32_t my = hm ? P1 : s1;
+            const uint32_t y0 = g[1] * my, y1 = y0 + my;
+            const uint32_t yh[2] = {y0 & hm, y1 & hm}, yt[2] = {y0 & dm, y1 & dm};
+            uint32_t zh[2] = {0u, 0u}, zt[2] = {0u, 0u};
             if constexpr (D == 3) {
-                w *= bz ? w1[2] : w0[2];
-                idx = (gridtype == 0 && use_hash) ? (ix[bx] ^ iy[by] ^ iz[bz]) : (ix[bx] + iy[by] + iz[bz]);
-            } else {
-                idx = (gridtype == 0 && use_hash) ? (ix[bx] ^ iy[by]) : (ix[bx] + iy[by]);
+                const uint32_t mz = hm ? P2 : s2;
+                const uint32_t z0 = g[2] * mz, z1 = z0 + mz;
+                zh[0] = z0 & hm; zh[1] = z1 & hm; zt[0] = z0 & dm; zt[1] = z1 & dm;
             }
-            const float2 v = rows[row_off + (idx & mask)];
-            o0 += w * v.x;
-            o1 += w * v.y;
+            const uint32_t ix[2] = {g[0], g[0] + 1u};
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NC; c++) {
+                const uint32_t bx = c & 1u, by = (c >> 1) & 1u, bz = (c >> 2) & 1u;
+                uint32_t idx = (ix[bx] ^ yh[by]) + yt[by];
+                if constexpr (D == 3) idx = (idx ^ zh[bz]) + zt[bz];
+                v[k][c] = rows[row_off + (idx & mask)];
+            }
         }
-        f[l * 2 + 0] = oob ? 0.0f : o0;
-        f[l * 2 + 1] = oob ? 0.0f : o1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < LB; k++) {
+            const int l = b * LB + k;
+            float w1[D], w0[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) { w1[d] = pw[k][d]; w0[d] = 1 - pw[k][d]; }
+            float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NC; c++) {
+                const uint32_t bx = c & 1u, by = (c >> 1) & 1u, bz = (c >> 2) & 1u;
+                float w = bx ? w1[0] : w0[0];
+                w *= by ? w1[1] : w0[1];
+                if constexpr (D == 3) w *= bz ? w1[2] : w0[2];
+                o0 += w * v[k][c].x;
+                o1 += w * v[k][c].y;
+            }
+            f[l * 2 + 0] = oob ? 0.0f : o0;
+            f[l * 2 + 1] = oob ? 0.0f : o1;
+        }
     }
 }
+
 
 // Input gradient of the 2-D lookup for the fused training backward: this lane's eight levels at point x, output gradients gf[16] =
 // [level][channel] -> the lane's share of d loss / d x (the caller adds the two lane halves).  Same derivative as kernel_grid's dy_dx
