@@ -3,6 +3,7 @@ train_field._bwd_stream_index) against the host packers / the documented stream 
 import ctypes as C
 
 import numpy as np
+import pytest
 import torch
 
 from geneface_amd import fused, train_field
@@ -123,3 +124,65 @@ def test_split_pack_reconstructs_the_weights(hip_lib):
     assert abs(rec[0, 10, 5, 7] - 3e-8) < 2.0 ** -35                                 # ws[2][5, 7]: wave 0, group SP_SIG1, lane 5 (row 5), i = 7
     ws[5][3, 20] = 1e5
     assert L.gf_head_pack_split(*[p(w) for w in ws], p(out)) != 0 and b"f16 range" in L.gf_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The fused lookup's corner index (csrc/grid_core.hpp::encode8) is ONE expression for hashed and dense levels:
+#     ((x ^ yh) + yt ^ zh) + zt,   y* = g_y * (hashed ? P1 : s1) masked by the level's use_hash / ~use_hash, likewise z
+# Restated here in numpy from the level metadata (make_level_meta) and compared with the reference's rule (gridencoder.cu:97-123: strided
+# index while the running stride fits the table, the xor-prime hash otherwise, modulo the table size) on every level shape the head uses.
+def _reference_row(gridtype, size, res, pos):
+    stride, index = 1, 0
+    for d in range(len(pos)):
+        if stride <= size:
+            index = (index + int(pos[d]) * stride) & 0xFFFFFFFF
+            stride *= res + 1
+    if gridtype == 0 and stride > size:
+        primes = (1, 2654435761, 805459861)
+        index = 0
+        for d in range(len(pos)):
+            index ^= (int(pos[d]) * primes[d]) & 0xFFFFFFFF
+    return index % size
+
+
+def _level_meta(gridtype, size, res, D):
+    stride, sd = 1, [0, 0, 0]
+    for d in range(D):
+        if stride <= size:
+            sd[d] = stride
+            stride *= res + 1
+    mask = 0xFFFFFFFF if stride <= size else size - 1
+    use_hash = 0xFFFFFFFF if (gridtype == 0 and stride > size) else 0
+    return sd[1], sd[2], mask, use_hash
+
+
+def _unified_row(meta, pos):
+    s1, s2, mask, hm = meta
+    dm = ~hm & 0xFFFFFFFF
+    P1, P2 = 2654435761, 805459861
+    y = (int(pos[1]) * (P1 if hm else s1)) & 0xFFFFFFFF
+    idx = ((int(pos[0]) ^ (y & hm)) + (y & dm)) & 0xFFFFFFFF
+    if len(pos) == 3:
+        z = (int(pos[2]) * (P2 if hm else s2)) & 0xFFFFFFFF
+        idx = ((idx ^ (z & hm)) + (z & dm)) & 0xFFFFFFFF
+    return idx & mask
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("gridtype", [0, 1])
+def test_fused_lookup_index_expression_matches_the_reference_rule(D, gridtype):
+    rng = np.random.default_rng(5 + D + 10 * gridtype)
+    log2_T = 16
+    for res in (16, 23, 31, 43, 59, 81, 112, 154, 213, 294, 406, 561, 774, 1069, 1476, 2048):
+        full = (res + 1) ** D
+        size = min(1 << log2_T, -(-full // 8) * 8)          # grid.py:118-134: ceil to 8, capped by the hash-map size
+        meta = _level_meta(gridtype, size, res, D)
+        if meta[2] != 0xFFFFFFFF:
+            assert size & (size - 1) == 0                   # wrapped levels have power-of-two tables (gf_grid_levels_fusable)
+        # cell origin g = floor(x * (res - 1) + 0.5) for x in [0, 1]: 0 .. res - 1, so a corner coordinate is at most res
+        pts = rng.integers(0, res, size=(200, D))
+        pts[:4] = [[0] * D, [res - 1] * D, [res - 1, 0, res - 1][:D], [1, res - 1, 0][:D]]
+        for g in pts:
+            for corner in range(1 << D):
+                pos = [int(g[d]) + ((corner >> d) & 1) for d in range(D)]
+                assert _unified_row(meta, pos) == _reference_row(gridtype, size, res, pos), (D, gridtype, res, pos)
