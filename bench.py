@@ -47,8 +47,11 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--impl", default=None, choices=[None, "ops", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="oracle frames timed for cpu_baseline (bounded sample)")
-    ap.add_argument("--parity-frames", type=int, default=8, help="frames, spread over the sequence, compared with the oracle (the timed cpu_baseline frames are among them)")
+    ap.add_argument("--parity-frames", type=int, default=8, help="how many of the parity fixture's frames (PARITY_FRAMES) are compared with the oracle; "
+                                                               "the oracle's runs on them are also the bounded cpu_baseline sample")
+    ap.add_argument("--rank-parity", action="store_true", help="run the N > 1 line's every-rank parity check (one common frame per rank against one oracle "
+                                                                "frame) at N = 1 as well (the GPU test of the 1-rank RCCL path uses it)")
+    ap.add_argument("--no-grazing", action="store_true", help="skip the grazing-ray probe (two more oracle frames per parity frame)")
     ap.add_argument("--profile-frames", type=int, default=8)
     ap.add_argument("--in-flight", type=int, default=0, help="frames enqueued concurrently on separate streams (fused path); 0 = the pipeline's default")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: frames do not overlap (per-kernel profiling runs)")
@@ -72,60 +75,169 @@ def parse(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
-def oracle_frames(hp, sd, seq, indices, torso=True, timed=2):
-    """The oracle (CPU port of the reference's render path: torch-fp32 layers over the C kernels) on frames `indices`; the first `timed`
-    of them, after one warm-up frame, are the bounded cpu_baseline sample."""
+# The parity fixture is FIXED: these frames of a PARITY_T-frame sequence of the same generator (same seeds: frame i of it is frame i of any
+# longer bench sequence), whatever --steps / --warmup say.  Round 3's driver line (--steps 20 --warmup 5) compared frames the builder had
+# never rendered and showed max|d rgb| = 0.0896 on frame 14: one ray grazing an occupied cell, with the two sides fed rays that differed
+# in the last ulp (torch's get_rays on the GPU for the product, on the CPU for the oracle).  Frame 14 is therefore in the set.
+PARITY_T = 32
+PARITY_FRAMES = (1, 4, 8, 11, 14, 17, 21, 24)
+PARITY_PRIORITY = (14, 1, 24, 8, 17, 4, 21, 11)      # which of them a smaller --parity-frames keeps
+GRAZE_MOVE = 1e-3      # a pixel is "grazing" when the ORACLE's own value moves by more than this under a 1-ulp change of its ray direction
+
+
+def host_inputs(sample):
+    """The bits the product is about to see, copied to the host for the oracle: rays (the reference builds them on the GPU,
+    tasks/radnerfs/dataset_utils.py:172-178), window, background coordinates, euler pose, background.  "Identical inputs" means these."""
     import torch
+    return {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
+
+
+def oracle_render(hp, sd, inp, torso, rays_d=None):
+    """oracle/radnerf_ref.render (CPU restatement of the reference's render path: torch-fp32 layers over the C kernels) on host inputs."""
     from oracle import radnerf_ref as R
-    H, W = seq["H"], seq["W"]
-    bgc = R.get_bg_coords(H, W)
-    bg = torch.from_numpy(seq["bg_img"]).view(1, -1, 3)
-
-    def one(i):
-        pose = torch.from_numpy(seq["poses"][i:i + 1])
-        ro, rd = R.get_rays(pose, seq["intrinsics"], H, W)
-        return R.render(sd, hp, ro, rd, torch.from_numpy(seq["cond_wins"][i]), bgc, R.convert_poses(pose), bg, torso=torso)
-    one(indices[0])  # warm-up (thread pools, page faults)
-    frames, dt = {}, 0.0
-    for k, i in enumerate(indices):
-        t0 = time.perf_counter()
-        frames[i] = one(i)
-        if k < timed:
-            dt += time.perf_counter() - t0
-    return frames, dt
+    return R.render(sd, hp, inp["rays_o"], inp["rays_d"] if rays_d is None else rays_d, inp["cond_wins"], inp["bg_coords"], inp["pose"],
+                    inp["bg_img"], torso=torso)
 
 
-def cpu_baseline(hp, sd, seq, indices, torso=True, timed=2):
+def set_cpu_threads(t):
+    """torch's intra-op pool and the OpenMP runtime of the C oracle kernels (one libgomp)."""
+    import ctypes
     import torch
-    H, W = seq["H"], seq["W"]
-    frames, dt = oracle_frames(hp, sd, seq, indices, torso, timed)
-    n = min(timed, len(indices))
-    out = {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{n} {'head+torso' if torso else 'head-only'} {H}x{W} frames after 1 warm-up, oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels)"}
-    out["legacy_nerf"] = legacy_nerf_baseline(seq)
-    return out, frames
+    torch.set_num_threads(int(t))
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(t))
+    except OSError:
+        pass
 
 
-def parity_vs_oracle(pipe, frames):
-    """BASELINE.json's "PSNR vs reference": oracle frames against the same frames from the product (module API -> fp32 rgb_map, and
-    the frame loop's uint8 output)."""
+class OracleClock:
+    """cpu_baseline: the oracle timed on a bounded sample -- the parity frames themselves, so no oracle frame is rendered twice.  A
+    512x512 frame is ~1 M field evaluations in 128-row torch layers plus OpenMP C kernels; it does not scale to a two-socket host (round 3
+    reported 0.16 fps "on 128 cores", which 8 cores beat 2.5x).  So: the first frames are timed one per thread count (all cores, 64, 32,
+    16, 8), the rest at the best of them, and `value` is the rate at that count."""
+
+    def __init__(self):
+        import torch
+        self.all = torch.get_num_threads()
+        self.counts = sorted({t for t in (self.all, 64, 32, 16, 8) if t <= self.all}, reverse=True)
+        self.sweep, self.best, self.times, self.warm = {}, None, [], False
+
+    def run(self, fn):
+        if not self.warm:
+            fn()                       # thread pools, page faults, the C library's first load
+            self.warm = True
+        if self.best is None:
+            t = self.counts[len(self.sweep)]
+            set_cpu_threads(t)
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        if self.best is None:
+            self.sweep[t] = dt
+            if len(self.sweep) == len(self.counts):
+                self.best = min(self.sweep, key=self.sweep.get)
+                self.times.append(self.sweep[self.best])
+                set_cpu_threads(self.best)
+        else:
+            self.times.append(dt)
+        return out
+
+    def result(self, what):
+        import torch
+        best = self.best if self.best is not None else (min(self.sweep, key=self.sweep.get) if self.sweep else self.all)
+        times = self.times or [self.sweep[best]]
+        set_cpu_threads(self.all)
+        return {"value": len(times) / sum(times), "unit": "frames/s", "cores": best, "host_cores": os.cpu_count(), "kind": "port",
+                "s_per_frame_by_threads": {str(k): round(v, 3) for k, v in self.sweep.items()},
+                "sample": f"{len(times)} {what} frames at {best} threads (the best of one frame each at {self.counts} threads, after 1 warm-up), "
+                          f"oracle/radnerf_ref.render (torch fp32 + OpenMP C kernels); {torch.get_num_threads()} threads available"}
+
+
+def parity_vs_oracle(pipe, hp, sd, torso, frames=PARITY_FRAMES, clock=None, grazing=True, cache=None):
+    """BASELINE.json's "PSNR vs reference" on the parity fixture.  Per frame, ONE set of input bits for both sides:
+      module API   run_model(sample(i)) -- rays from get_rays on the GPU, as the reference's dataset builds them -- against the oracle on
+                   those same tensors copied to the host: max|d rgb| over ALL pixels (nothing excluded), PSNR;
+      frame loop   render_frame(i) (rays generated inside the kernel from the pose, uint8 out) against the oracle's uint8 frame.  In-kernel
+                   rays may differ from get_rays' in the last ulp (its rotation is a BLAS matmul), so a ray that grazes an occupied cell can gain
+                   or lose a sample: every pixel off by more than 1 LSB is re-rendered by the oracle ON THE KERNEL'S OWN RAYS (gf_pinhole_rays:
+                   the device function k_frame_init runs) and must then agree -- `unexplained` counts those that do not;
+      grazing      how many pixels of the frame are that sensitive at all: the oracle re-run with every ray direction moved one ulp up / one
+                   ulp down; a pixel whose ORACLE value moves by more than GRAZE_MOVE is counted, reported, never excluded."""
     import numpy as np
     import torch
-    psnrs, max_abs, lsb = [], 0.0, 1.0
-    for i, ref in sorted(frames.items()):
-        rgb_ref = ref["rgb_map"].reshape(-1, 3).double()
+    per, psnrs = [], []
+    worst = {"max_abs_rgb": 0.0}
+    lsb_frac, off_total, unexplained, graze_total, graze_max = 1.0, 0, 0, 0, 0.0
+    H, W = pipe.H, pipe.W
+    for i in frames:
         with torch.no_grad():
-            out = pipe.run_model(pipe.sample(i))["rgb_map"].reshape(-1, 3).double().cpu()
+            smp = pipe.sample(i)
+            inp = host_inputs(smp)
+            hit = cache.get(i) if cache is not None else None
+            if hit is not None and all(torch.equal(hit["inp"][k], inp[k]) for k in ("rays_o", "rays_d", "cond_wins", "pose", "bg_coords")):
+                ref = hit["ref"]          # another tier of the same model on the same fixture frame: the same input bits, the same oracle frame
+            else:
+                run = (lambda: oracle_render(hp, sd, inp, torso))
+                ref = clock.run(run) if clock is not None else run()
+                if cache is not None:
+                    cache[i] = {"inp": inp, "ref": ref}
+            rgb_ref = ref["rgb_map"].reshape(-1, 3)
+            out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
             u8 = pipe.render_frame(i)
             pipe.wait()
-        mse = float(((out - rgb_ref) ** 2).mean())
-        psnrs.append(150.0 if mse == 0 else -10.0 * np.log10(mse))
-        max_abs = max(max_abs, float((out - rgb_ref).abs().max()))
-        ref8 = (rgb_ref.float() * 255).to(torch.uint8).reshape(u8.shape).int()
-        lsb = min(lsb, float(((u8.int() - ref8).abs() <= 1).float().mean()))
-    return {"psnr_db": min(psnrs), "max_abs_rgb": max_abs, "uint8_within_1_lsb": lsb, "frames": len(psnrs), "frame_indices": sorted(frames),
-            "reference": "oracle/radnerf_ref.render (CPU restatement, pinned against the reference's own kernels) on the same inputs",
-            "tolerance": "BASELINE.md section 4: max|d rgb| <= 1e-4 strict, PSNR >= 40 dB fast tier"}
+            u8 = u8.clone().reshape(-1, 3).int()
+        d = (out.double() - rgb_ref.double()).abs()
+        mse = float((d ** 2).mean())
+        psnr = 150.0 if mse == 0 else float(-10.0 * np.log10(mse))
+        dmax = float(d.max())
+        pix = int(d.max(dim=1).values.argmax())
+        rec = {"frame": int(i), "max_abs_rgb": dmax, "psnr_db": round(psnr, 2), "worst_pixel": [pix // W, pix % W]}
+        if dmax > worst["max_abs_rgb"]:
+            worst = {"max_abs_rgb": dmax, "frame": int(i), "pixel": [pix // W, pix % W]}
+        psnrs.append(psnr)
+        # frame loop (pose mode) vs the oracle's uint8 frame
+        ref8 = (rgb_ref * 255).to(torch.uint8).int()
+        off = ((u8 - ref8).abs() > 1).any(dim=1)
+        lsb_frac = min(lsb_frac, float(((u8 - ref8).abs() <= 1).float().mean()))
+        n_off = int(off.sum())
+        rec["pose_mode_pixels_off_by_more_than_1_lsb"] = n_off
+        if n_off:
+            with torch.no_grad():
+                kin = host_inputs(pipe.kernel_sample(i))
+            kref = oracle_render(hp, sd, kin, torso)
+            k8 = (kref["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8).int()
+            still = int(((u8 - k8).abs() > 1).any(dim=1).sum())      # over the WHOLE frame, not just the flagged pixels
+            rec["pose_mode_unexplained_on_kernel_rays"] = still
+            unexplained += still
+            off_total += n_off
+        if grazing:
+            rd = inp["rays_d"]
+            moved = torch.zeros(rgb_ref.shape[0])
+            for toward in (float("inf"), float("-inf")):
+                pr = oracle_render(hp, sd, inp, torso, rays_d=torch.nextafter(rd, torch.full_like(rd, toward)))
+                moved = torch.maximum(moved, (pr["rgb_map"].reshape(-1, 3) - rgb_ref).abs().max(dim=1).values)
+            g = moved > GRAZE_MOVE
+            rec["grazing_pixels"] = int(g.sum())
+            rec["grazing_max_move"] = float(moved.max())
+            rec["max_abs_rgb_on_grazing_pixels"] = float(d.max(dim=1).values[g].max()) if bool(g.any()) else 0.0
+            graze_total += int(g.sum())
+            graze_max = max(graze_max, float(moved.max()))
+        per.append(rec)
+    out = {"psnr_db": min(psnrs), "max_abs_rgb": worst["max_abs_rgb"], "worst": worst, "uint8_within_1_lsb": lsb_frac, "frames": len(per),
+           "frame_indices": [int(i) for i in frames], "per_frame": per,
+           "inputs": "one set of bits for both sides: the device tensors of FramePipeline.sample(i) (get_rays on the GPU, as the reference's dataset "
+                     "does) copied to the host for the oracle; every pixel counts",
+           "pose_mode": {"pixels_off_by_more_than_1_lsb": off_total, "unexplained_after_oracle_on_kernel_rays": unexplained,
+                         "note": "frame loop: in-kernel rays (last-ulp differences from get_rays); flagged frames are re-rendered by the oracle on the "
+                                 "kernel's own rays (gf_pinhole_rays) and compared over the whole frame"},
+           "reference": "oracle/radnerf_ref.render (CPU restatement, pinned against the reference's own kernels)",
+           "tolerance": "BASELINE.md section 4: max|d rgb| <= 1e-4 strict, PSNR >= 40 dB fast tier",
+           "fixture": f"frames {list(frames)} of a {PARITY_T}-frame sequence, independent of --steps / --warmup"}
+    if grazing:
+        out["grazing"] = {"pixels": graze_total, "max_oracle_move": graze_max, "threshold": GRAZE_MOVE,
+                          "probe": "oracle re-run with every ray direction component one ulp up, and one ulp down; a pixel whose oracle value "
+                                   "moves by more than `threshold` is counted (never excluded from max_abs_rgb)"}
+    return out
 
 
 def legacy_nerf_baseline(seq, rays=4096):
@@ -248,6 +360,15 @@ class Job:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, values, dtype=None):
+        """[world][len(values)] on every rank (all_gather of one small tensor)."""
+        t = self.torch.tensor(list(values), dtype=dtype or self.torch.float64, device=self.dev)
+        if not self.use_dist:
+            return [t.cpu().tolist()]
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+
     def close(self):
         if self.use_dist:
             self.barrier()
@@ -266,6 +387,8 @@ def timed_pass(job, pipe, first, K, prepare=True):
         pipe.render_frame(i)
         if i - first + 1 == free:
             timed_pass.enqueue_s = (time.perf_counter() - t0) / free     # host time to describe + enqueue ONE frame (incl. its share of prepare())
+    job.sync()
+    timed_pass.local_s = time.perf_counter() - t0      # this rank's own K frames have reached host memory (before the closing barrier)
     job.barrier()
     return job.reduce(time.perf_counter() - t0, "max")
 
@@ -275,10 +398,13 @@ def timed_loop(job, pipe, first, K, args):
     pipeline fill and drain, and invisible to a utilisation sampler); every rank derives the same repeat count from the reduced time
     of the first pass.  Reports the median pass."""
     dts, enq = [timed_pass(job, pipe, first, K, not args.no_prepare)], []
+    local = [timed_pass.local_s]
     reps = args.repeats or int(min(400, max(1, -(-args.min_seconds // dts[0]))))
     while len(dts) < reps:
         dts.append(timed_pass(job, pipe, first, K, not args.no_prepare))
+        local.append(timed_pass.local_s)
         enq.append(timed_pass.enqueue_s)
+    timed_loop.local_median_s = sorted(local)[len(local) // 2]      # this rank's own clock (the line's per_rank block gathers them)
     timed_loop.host_enqueue_ms_per_step = (sorted(enq)[len(enq) // 2] * 1e3) if enq else None     # if this approaches ms_per_step the host is the limiter
     return sorted(dts)[len(dts) // 2], dts
 
@@ -334,13 +460,23 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
     # every rank reports in: the line's `rccl_ranks` is the all-reduced count, so it proves the collective layer saw N ranks
     ranks_seen = int(round(job.reduce(1.0, "sum")))
 
-    # CPU baseline FIRST (rank 0, N = 1): the GPU legs then run back to back at the end of the process, where a utilisation sampler sees them
-    cpu, parity, parity_idx, oframes = None, None, [], None
+    # what every rank holds after the broadcast: an exact checksum of the replica (int64 sum of the bit patterns), gathered -- equal rows prove
+    # the one collective of the data path delivered rank 0's weights everywhere
+    replica_sums = job.gather([replica_checksum(pipe.model)], dtype=torch.int64) if real else None
+
+    # CPU legs FIRST (rank 0, N = 1): the GPU legs then run back to back at the end of the process, where a utilisation sampler sees them
+    cpu, parity, cache, pframes = None, None, {}, []
     if real and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_par = max(args.cpu_frames, min(args.parity_frames, per_rank))
-        parity_idx = sorted({int(round(1 + k * (per_rank - 2) / max(n_par - 1, 1))) for k in range(n_par)})
-        cpu, oframes = cpu_baseline(hp, sd, seq, parity_idx, torso, timed=args.cpu_frames)
-        parity = parity_vs_oracle(pipe, oframes)
+        pframes = sorted(PARITY_PRIORITY[:max(1, min(args.parity_frames, len(PARITY_PRIORITY)))])
+        clock = OracleClock()
+        ppipe = build_pipe(args, job, hp, torso, S.make_sequence(PARITY_T, args.size, args.size, hp), sd, (0, PARITY_T))
+        parity = parity_vs_oracle(ppipe, hp, sd, torso, pframes, clock, grazing=not args.no_grazing, cache=cache)
+        cpu = clock.result(f"{'head+torso' if torso else 'head-only'} {args.size}x{args.size}")
+        cpu["legacy_nerf"] = legacy_nerf_baseline(seq)
+        del ppipe
+    rank_parity = None
+    if real and ((world > 1 and not args.no_cpu_baseline) or args.rank_parity):
+        rank_parity = every_rank_parity(args, job, hp, torso, sd)
 
     with torch.no_grad():
         for i in range(Wm):
@@ -351,6 +487,9 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
         if real and rank == 0:
             roofline = measure_roofline(pipe, args.impl, Wm, min(args.profile_frames, K), PEAK_F32_MFMA_TFLOPS, precision=args.precision)
 
+    # every rank's own clock and replica checksum, gathered: the line shows N separate measurements, not just the max
+    mine = [K / timed_loop.local_median_s if getattr(timed_loop, "local_median_s", None) else 0.0, float(frames[0]), float(frames[1])]
+    per_rank_rows = job.gather(mine)
     if rank == 0:
         dtype = {"fp32": "f32", "fast": "f16 operands / f32 accumulate (fast tier)",
                  "split": "f32 values as two-term f16 splits on the f16 matrix pipe, f32 accumulate (strict tolerance)"}[args.precision]
@@ -373,6 +512,15 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             "roofline": roofline,
             "parity": parity,
         }
+        fps_r = [r[0] for r in per_rank_rows]
+        line["per_rank"] = {"fps": fps_r, "fps_min": min(fps_r), "fps_max": max(fps_r), "frames": [[int(r[1]), int(r[2])] for r in per_rank_rows],
+                            "replica_checksum_equal": (len({tuple(r) for r in replica_sums}) == 1) if replica_sums else None,
+                            "parity_first_frame": rank_parity,
+                            "note": "fps: each rank's own clock over its K frames (median pass); `value` uses the max over ranks of every pass.  "
+                                    "replica_checksum: int64 sum of the bit patterns of every parameter and buffer after the RCCL broadcast"}
+        if roofline and roofline.get("samples_per_frame"):
+            # fixtures differ in samples per frame (0.86 M here, 1.6 M on the heavy one): this rate is what compares across them
+            line["msamples_per_s"] = roofline["samples_per_frame"] * (K / dt) * world / 1e6
         if roofline and args.precision == "fp32" and roofline.get("samples_per_frame") and world == 1:
             # The same algorithmic FLOPs priced against the WHOLE frame time of the timed region (several frames in flight: the uneven end of one
             # launch -- 12 % of the kernel alone, DESIGN.md 4.2 -- is filled by the next frame's workgroups, but the frame also pays for the
@@ -384,16 +532,17 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             if args.png_frames > 0:
                 line["with_png"] = png_leg(pipe, Wm, min(args.png_frames, K))
             if not args.no_stress and args.impl == "fused":
-                line["stress_fixture"] = fixture_leg(args, job, hp, torso, seq, dict(sigma_row_scale=0.02), parity_idx[:2] if parity else [],
+                two = [f for f in (1, 14) if f in pframes] if parity else []
+                line["stress_fixture"] = fixture_leg(args, job, hp, torso, seq, dict(sigma_row_scale=0.02), two,
                                                      "density row of sigma_net scaled by 0.02 (sigma ~ 1): no ray terminates early, every hit ray marches its full budget")
-                line["heavy_fixture"] = fixture_leg(args, job, hp, torso, None, dict(sigma_row_scale=HEAVY_SIGMA_SCALE), [],
+                line["heavy_fixture"] = fixture_leg(args, job, hp, torso, None, dict(sigma_row_scale=HEAVY_SIGMA_SCALE), two,
                                                     f"camera at radius {HEAVY_RADIUS} instead of 3.35 (the head fills the frame) and the density row scaled by "
                                                     f"{HEAVY_SIGMA_SCALE}: the sample count SURVEY.md 8d expects of a trained May model (1.5-1.7 M per frame)",
                                                     radius=HEAVY_RADIUS)
                 if torso:
-                    line["head_only"] = head_only_leg(args, job)
+                    line["head_only"] = head_only_leg(args, job, two)
                 if args.precision == "fp32":
-                    line["split_tier"] = split_tier_leg(args, job, hp, torso, seq, sd, oframes if parity else None)
+                    line["split_tier"] = split_tier_leg(args, job, hp, torso, seq, sd, pframes if parity else [], cache)
         line["cpu_baseline"] = cpu
         if emit is not None:
             emit(line)
@@ -406,9 +555,9 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
 HEAVY_RADIUS, HEAVY_SIGMA_SCALE = 2.75, 0.3
 
 
-def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_idx, what, radius=None):
+def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_frames, what, radius=None):
     """Sensitivity of `value` to the fixture: the same pipeline on another synthetic scene -- fps, samples per frame, the kernel's roofline
-    fraction (which should not move with the sample count) and, for `parity_idx`, parity against the oracle on that scene."""
+    fraction (which should not move with the sample count) and, on `parity_frames` of that scene's parity fixture, parity against the oracle."""
     import torch
     from geneface_amd import synthetic as S
     n = args.steps + args.warmup
@@ -417,29 +566,34 @@ def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_idx, what, radius=None)
     sd = S.make_state_dict(hp, torso, **sd_kw)
     pipe = build_pipe(args, job, hp, torso, seq, sd, (0, n))
     parity = None
-    if parity_idx:
-        oframes, _ = oracle_frames(hp, sd, seq, parity_idx, torso, timed=0)
-        parity = parity_vs_oracle(pipe, oframes)
+    if parity_frames:
+        pseq = S.make_sequence(PARITY_T, args.size, args.size, hp, radius=radius)
+        parity = parity_vs_oracle(build_pipe(args, job, hp, torso, pseq, sd, (0, PARITY_T)), hp, sd, torso, parity_frames, grazing=False)
     with torch.no_grad():
         for i in range(args.warmup):
             pipe.render_frame(i)
         dt, dts = timed_loop(job, pipe, args.warmup, args.steps, args)
         r = measure_roofline(pipe, args.impl, args.warmup, min(4, args.steps), PEAK_F32_MFMA_TFLOPS, precision=args.precision)
-    return {"value": args.steps / dt, "unit": "frames/s", "repeats": len(dts), "samples_per_frame": r.get("samples_per_frame"),
+    spf = r.get("samples_per_frame")
+    return {"value": args.steps / dt, "unit": "frames/s", "repeats": len(dts), "samples_per_frame": spf,
+            "msamples_per_s": spf * args.steps / dt / 1e6 if spf else None,
             "samples_composited_per_frame": r.get("samples_composited_per_frame"),
             "roofline_frac": r.get("frac"), "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "tile_fill": r.get("tile_fill"),
             "example_frame": r.get("example_frame"), "parity": parity, "fixture": what}
 
 
-def split_tier_leg(args, job, hp, torso, seq, sd, oracle_frames_or_none):
+def split_tier_leg(args, job, hp, torso, seq, sd, parity_frames, cache):
     """Beside the headline (which stays exact fp32): the same workload on the split tier -- fp32 VALUES as two-term f16 splits on the f16
-    matrix pipe, held to the same strict tolerance.  `python bench.py --precision split` prints its full line."""
+    matrix pipe, held to the same strict tolerance.  `python bench.py --precision split` prints its full line.  Parity on
+    the same fixture frames as the headline (the oracle's frames are reused: the inputs are the same bits)."""
     import torch
+    from geneface_amd import synthetic as S
     n = args.steps + args.warmup
     pipe = build_pipe(args, job, hp, torso, seq, sd, (0, n), precision="split")
     parity = None
-    if oracle_frames_or_none:
-        parity = parity_vs_oracle(pipe, dict(list(sorted(oracle_frames_or_none.items()))[:4]))
+    if parity_frames:
+        ppipe = build_pipe(args, job, hp, torso, S.make_sequence(PARITY_T, args.size, args.size, hp), sd, (0, PARITY_T), precision="split")
+        parity = parity_vs_oracle(ppipe, hp, sd, torso, parity_frames, grazing=False, cache=cache)
     with torch.no_grad():
         for i in range(args.warmup):
             pipe.render_frame(i)
@@ -452,7 +606,7 @@ def split_tier_leg(args, job, hp, torso, seq, sd, oracle_frames_or_none):
             "note": "opt-in (model.render_precision = 'split'): strict tolerance, not fp32 bit patterns; the headline `value` is the exact-fp32 tier"}
 
 
-def head_only_leg(args, job):
+def head_only_leg(args, job, parity_frames=()):
     """BASELINE.json configs[1] beside the headline: May lm3d_radnerf head-only on the same frames (no torso pass: background blend only)."""
     import torch
     from geneface_amd import hparams as HP
@@ -460,13 +614,67 @@ def head_only_leg(args, job):
     hp = HP.may_hparams(False)
     n = args.steps + args.warmup
     seq = S.make_sequence(n, args.size, args.size, hp)
-    pipe = build_pipe(args, job, hp, False, seq, S.make_state_dict(hp, False), (0, n))
+    sd = S.make_state_dict(hp, False)
+    pipe = build_pipe(args, job, hp, False, seq, sd, (0, n))
+    parity = None
+    if parity_frames:
+        pseq = S.make_sequence(PARITY_T, args.size, args.size, hp)
+        parity = parity_vs_oracle(build_pipe(args, job, hp, False, pseq, sd, (0, PARITY_T)), hp, sd, False, parity_frames, grazing=False)
     with torch.no_grad():
         for i in range(args.warmup):
             pipe.render_frame(i)
         dt, dts = timed_loop(job, pipe, args.warmup, args.steps, args)
-    return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "repeats": len(dts),
+    return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "repeats": len(dts), "parity": parity,
             "workload": f"May lm3d_radnerf head-only {args.size}x{args.size}, {args.steps} frames (BASELINE.json configs[1])"}
+
+
+def replica_checksum(model):
+    """Exact, order-independent checksum of a replica: the int64 sum of the bit patterns of every parameter and buffer."""
+    import torch
+    tot = 0
+    with torch.no_grad():
+        for _, t in sorted(list(model.named_parameters()) + list(model.named_buffers()), key=lambda kv: kv[0]):
+            t = t.detach().contiguous()
+            if t.numel() == 0:
+                continue
+            if t.element_size() == 4:
+                v = t.view(torch.int32)
+            elif t.element_size() == 2:
+                v = t.view(torch.int16)
+            elif t.element_size() == 8:
+                v = t.view(torch.int64)
+            else:
+                v = t.view(torch.uint8)
+            tot += int(v.to(torch.int64).sum().item())
+    return tot % (1 << 62)
+
+
+def every_rank_parity(args, job, hp, torso, sd_rank0):
+    """N > 1: every rank renders ONE common frame of the parity fixture from ITS replica (module API, rays from get_rays on its GPU); the fp32
+    frames are gathered and rank 0 compares each with one oracle frame.  A rank whose broadcast, device or library went wrong shows up here,
+    not as a plausible fps."""
+    import torch
+    from geneface_amd import synthetic as S
+    i = PARITY_PRIORITY[0]
+    pseq = S.make_sequence(PARITY_T, args.size, args.size, hp)
+    ppipe = build_pipe(args, job, hp, torso, pseq, sd_rank0 if job.rank == 0 else None, (0, PARITY_T))
+    with torch.no_grad():
+        smp = ppipe.sample(i)
+        rgb = ppipe.run_model(smp)["rgb_map"].reshape(-1).float().contiguous()
+    rows = [torch.empty_like(rgb) for _ in range(job.world)]
+    if job.use_dist:
+        job.dist.all_gather(rows, rgb)
+    else:
+        rows = [rgb]
+    out = None
+    if job.rank == 0:
+        set_cpu_threads(max(1, min(16, (os.cpu_count() or 8) // job.world)))      # torchrun exports OMP_NUM_THREADS=1 for N > 1
+        ref = oracle_render(hp, sd_rank0, host_inputs(smp), torso)["rgb_map"].reshape(-1)
+        errs = [float((r.cpu() - ref).abs().max()) for r in rows]
+        out = {"frame": int(i), "max_abs_rgb_by_rank": errs, "max_abs_rgb": max(errs), "identical_across_ranks": all(torch.equal(rows[0], r) for r in rows),
+               "tolerance": 1e-4}
+    job.barrier()
+    return out
 
 
 def png_leg(pipe, first, n):

@@ -166,8 +166,10 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
 // Round 2: the LDS accumulators are 64-bit FIXED POINT.  tools/lds_atomic_probe.hip: ds_add_f32 retires 0.38 adds per clock and CU on gfx950
 // (exactly the rate the float version of this kernel ran at), ds_add_u32 11.6 and ds_add_u64 6.7 -- the float atomic is ~20x slower than the
 // integer ones.  Every contribution w * g is scaled by 2^40 / max|g| of its level (k_grid_absmax, one pass over the gradient), rounded and
-// added as int64: no overflow below 2^23 full-size contributions per entry, a quantum of 9e-13 of the level's largest gradient, and -- integer
-// adds commute -- a table partial that does not depend on the order the points arrive in.  Round 3: the scale was 2^30 with int32 rounding, which
+// added as int64: no overflow below 2^23 full-size contributions per entry and slice (dispatch_backward_c keeps a slice at <= 2^20 points), a
+// quantum of 9e-13 of the level's largest gradient, and -- integer adds commute -- a fixed-point partial that does not depend on the order the
+// points arrive in (the float-atomic path below for contributions under 2^14 quanta, and the float flush into the table, are order dependent
+// at the last-ulp level like any atomic scatter).  Round 3: the scale was 2^30 with int32 rounding, which
 // turned every contribution below 5e-10 of the level's maximum into an exact zero; the reference trains these tables with Adam eps = 1e-15
 // (tasks/radnerfs/radnerf.py:63) precisely so that rarely-hit entries with tiny gradients still take full-size steps.  Now a contribution
 // below 2^14 quanta (1.5e-8 of the maximum) goes to the table as a float atomic instead, so every entry keeps fp32 RELATIVE accuracy over
@@ -442,6 +444,11 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     // spend on flush atomics; min_slices keeps the fine levels' point lists short enough to balance the chip.
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
     if (B < (1u << 16)) wgs = 32;
+    // int64 headroom (kGbFixedOne = 2^40): an entry takes at most 2^D <= 8 full-size contributions per point of a slice, so a slice holds at most
+    // 2^20 points (8 x 2^20 x 2^40 = 2^63); a point list longer than min_slices x 2^20 gets more slices (and the workgroups for them)
+    const uint32_t need = (uint32_t)(((uint64_t)B + (1u << 20) - 1) >> 20);
+    if (need > min_slices) min_slices = need;
+    if (wgs < min_slices * kGbMaxParts) wgs = min_slices * kGbMaxParts;
     // per-level scale of the fixed-point accumulators: handed in by the caller (the kernel that produced the gradient knows its maxima), or one
     // max pass over the gradient into a slot of a small device ring (calls on different streams take different slots)
     const uint32_t* lvl_max = level_max;

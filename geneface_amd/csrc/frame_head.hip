@@ -1277,7 +1277,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     if ((uint32_t)blockIdx.x * pool_cap >= limit) return;  // not even one refill's worth of work for this workgroup
     // the three loop-invariant scalars live in LDS from here on (s.misc[13..15]): with ~100 SGPRs already parked in VGPR lanes the allocator
     // put them into scratch instead, and a launch that touches scratch at all pays for it
-    if (tid == 0) { s.misc[13] = budget; s.misc[14] = limit; s.misc[15] = pool_cap; }
 #ifdef GF_DIAG
     if (a.poison) {   // any read of LDS this workgroup has not written itself now returns NaN (fp32 and f16 views alike)
         __syncthreads();
@@ -1287,6 +1286,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     }
     uint32_t dg_round = 0;
 #endif
+    if (tid == 0) { s.misc[13] = budget; s.misc[14] = limit; s.misc[15] = pool_cap; }   // (after the diagnostic poison fill, which covers all of LDS)
 
     for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
     if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
@@ -1959,6 +1959,31 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------- frame setup
+// Pinhole ray of pixel n: pixel centres at +0.5, row-major pixels (utils.py:296-363), same operation order as the torch code, no
+// contraction.  ONE definition for k_frame_init (pose mode) and k_pinhole_rays (gf_pinhole_rays: the same rays as tensors), so a frame
+// rendered from explicit gf_pinhole_rays rays sees the bits a pose-mode frame generates for itself.
+__device__ __forceinline__ void pinhole_ray(uint32_t n, uint32_t img_w, float fx, float fy, float cx, float cy, const float* pose,
+                                            float& dx, float& dy, float& dz) {
+#pragma clang fp contract(off)
+    const uint32_t row = n / img_w, col = n - row * img_w;
+    const float xs = ((float)col + 0.5f - cx) / fx, ys = ((float)row + 0.5f - cy) / fy, zs = 1.0f;
+    const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+    const float ux = xs / nrm, uy = ys / nrm, uz = zs / nrm;
+    dx = ux * pose[0] + uy * pose[1] + uz * pose[2];
+    dy = ux * pose[4] + uy * pose[5] + uz * pose[6];
+    dz = ux * pose[8] + uy * pose[9] + uz * pose[10];
+}
+
+struct PinholeArgs { float pose[12]; float fx, fy, cx, cy; uint32_t img_w, N; float *rays_o, *rays_d; };
+__global__ void __launch_bounds__(256) k_pinhole_rays(const PinholeArgs a) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    float dx, dy, dz;
+    pinhole_ray(n, a.img_w, a.fx, a.fy, a.cx, a.cy, a.pose, dx, dy, dz);
+    a.rays_d[(size_t)n * 3] = dx; a.rays_d[(size_t)n * 3 + 1] = dy; a.rays_d[(size_t)n * 3 + 2] = dz;
+    a.rays_o[(size_t)n * 3] = a.pose[3]; a.rays_o[(size_t)n * 3 + 1] = a.pose[7]; a.rays_o[(size_t)n * 3 + 2] = a.pose[11];
+}
+
 struct InitArgs {
     gf::MarchParams mp;
     const float* rays_o_in; const float* rays_d_in;  // explicit rays, or NULL
@@ -1988,15 +2013,7 @@ __global__ void __launch_bounds__(kInitThreads) k_frame_init(const InitArgs a) {
             ox = a.rays_o_in[(size_t)n * 3]; oy = a.rays_o_in[(size_t)n * 3 + 1]; oz = a.rays_o_in[(size_t)n * 3 + 2];
             dx = a.rays_d_in[(size_t)n * 3]; dy = a.rays_d_in[(size_t)n * 3 + 1]; dz = a.rays_d_in[(size_t)n * 3 + 2];
         } else {
-            // pinhole rays, pixel centres at +0.5, row-major pixels (utils.py:296-363), same operation order as the torch code
-#pragma clang fp contract(off)
-            const uint32_t row = n / a.img_w, col = n - row * a.img_w;
-            const float xs = ((float)col + 0.5f - a.cx) / a.fx, ys = ((float)row + 0.5f - a.cy) / a.fy, zs = 1.0f;
-            const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
-            const float ux = xs / nrm, uy = ys / nrm, uz = zs / nrm;
-            dx = ux * a.pose[0] + uy * a.pose[1] + uz * a.pose[2];
-            dy = ux * a.pose[4] + uy * a.pose[5] + uz * a.pose[6];
-            dz = ux * a.pose[8] + uy * a.pose[9] + uz * a.pose[10];
+            pinhole_ray(n, a.img_w, a.fx, a.fy, a.cx, a.cy, a.pose, dx, dy, dz);
             ox = a.pose[3]; oy = a.pose[7]; oz = a.pose[11];
         }
         float near, far;
@@ -2312,6 +2329,20 @@ GF_EXPORT uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field) {
 }
 
 GF_EXPORT uint64_t gf_frame_sizeof(void) { return sizeof(gf_frame_t); }
+
+// get_rays, N = -1 branch (utils.py:282-363) as ONE launch: the rays a pose-mode frame generates inside k_frame_init, as tensors.
+GF_EXPORT int gf_pinhole_rays(const float* pose12_host, const float* intrinsics4_host, uint32_t img_h, uint32_t img_w, float* rays_o,
+                              float* rays_d, void* stream) {
+    if (!pose12_host || !intrinsics4_host || !rays_o || !rays_d) return gf_set_error(GF_ERR_INVALID, "pinhole_rays: null pointer");
+    const uint64_t N = (uint64_t)img_h * img_w;
+    if (N == 0 || N >= (1ull << 32)) return gf_set_error(GF_ERR_INVALID, "pinhole_rays: img_h*img_w must be in [1, 2^32)");
+    PinholeArgs pa;
+    for (int i = 0; i < 12; i++) pa.pose[i] = pose12_host[i];
+    pa.fx = intrinsics4_host[0]; pa.fy = intrinsics4_host[1]; pa.cx = intrinsics4_host[2]; pa.cy = intrinsics4_host[3];
+    pa.img_w = img_w; pa.N = (uint32_t)N; pa.rays_o = rays_o; pa.rays_d = rays_d;
+    hipLaunchKernelGGL(k_pinhole_rays, dim3(gf_div_up((uint32_t)N, 256u)), dim3(256), 0, gf_stream(stream), pa);
+    return gf_check_launch("pinhole_rays");
+}
 
 // HOST: do the fused kernels support these grid tables (see grid_core.hpp, LevelMeta)?  offsets_host = GridEncoder.offsets [L+1].
 GF_EXPORT int gf_grid_levels_fusable(const int32_t* offsets_host, uint32_t L, uint32_t D, float S, uint32_t H) {

@@ -438,8 +438,21 @@ def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_al
 
 def head_aware_coin(model) -> bool:
     """radnerf_torso.py:175-179: with torso_head_aware the reference flips a coin PER FRAME, at inference too -- heads: the torso field sees
-    the head's colour and opacity at each pixel; tails: zeros.  Same draw (random.random() < 0.5) so a seeded run decides alike."""
-    return bool(getattr(model, "torso_head_aware", False)) and random.random() < 0.5
+    the head's colour and opacity at each pixel; tails: zeros.  Same draw (random.random() < 0.5) so a seeded run decides alike.  The
+    reference draws inside `if mask.any():` (:174), i.e. only when the torso occupancy selects at least one pixel: a model whose torso grid
+    is empty draws nothing (mask = grid_sample(density_grid_torso) > min(density_thresh_torso, mean_density_torso), and an all-zero grid
+    with a non-negative threshold selects nothing), which keeps a seeded run's random stream aligned with the reference's."""
+    if not bool(getattr(model, "torso_head_aware", False)):
+        return False
+    st = getattr(model, "_torso_occ_any", None)
+    grid = getattr(model, "density_grid_torso", None)
+    key = (grid._version, grid.data_ptr()) if grid is not None else None
+    if st is None or st[0] != key:
+        thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
+        any_px = bool((grid > thresh).any()) if grid is not None else False    # bilinear samples of a grid that is nowhere above the threshold are not either
+        st = (key, any_px)
+        object.__setattr__(model, "_torso_occ_any", st)
+    return st[1] and random.random() < 0.5
 
 
 def cond_encode_batch(model, st, cond_wins, poses6=None, ha_branch=False):
@@ -597,6 +610,24 @@ def field_forward(model, position, direction, cond_feat, individual_code):
         check(lib().gf_field_forward(C.byref(f), ptr(x, torch.float32), ptr(d, torch.float32), M, ptr(col_bias, torch.float32, allow_none=True),
                                      ptr(sigma), ptr(rgb), ptr(amb), current_stream(dev)))
         return sigma, rgb, amb
+
+
+def pinhole_rays(pose, intrinsics, H: int, W: int, device=None):
+    """get_rays(poses, intrinsics, H, W, -1) of utils.py:282-363 for ONE pose in one launch (gf_pinhole_rays): rays_o, rays_d [1, H*W, 3].
+    Bit for bit the rays a pose-mode frame generates inside k_frame_init (one device function serves both), so the module API fed with
+    these tensors and the frame loop render the same frame; torch's get_rays can differ from them in the last ulp (its rotation is a
+    BLAS matmul).  `pose` [4,4] / [1,4,4] / [3,4] cam2world, ngp axes."""
+    pose = torch.as_tensor(pose)
+    dev = torch.device(device) if device is not None else pose.device
+    if dev.type != "cuda":
+        raise RuntimeError("pinhole_rays needs a HIP device (there is no CPU path)")
+    p = np.ascontiguousarray(pose.detach().float().cpu().numpy().reshape(-1, 4)[:3].reshape(12))
+    k = np.ascontiguousarray(np.asarray([float(v) for v in intrinsics], dtype=np.float32))
+    with torch.cuda.device(dev):
+        rays_o = torch.empty(1, H * W, 3, dtype=torch.float32, device=dev)
+        rays_d = torch.empty(1, H * W, 3, dtype=torch.float32, device=dev)
+        check(lib().gf_pinhole_rays(_hp(p), _hp(k), int(H), int(W), ptr(rays_o), ptr(rays_d), current_stream(dev)))
+    return rays_o, rays_d
 
 
 def frame_stats(ctrl: torch.Tensor, N: int, max_steps: int) -> dict:

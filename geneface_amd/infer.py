@@ -135,7 +135,8 @@ class FramePipeline:
                 return                     # an encoder the kernel does not implement: every frame runs the torch modules as before
             ev = torch.cuda.Event()
             ev.record()
-        self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": r[2], "stamp": st.stamp, "event": ev, "waited": set()}
+        self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": r[2], "stamp": st.stamp, "event": ev, "waited": set(),
+                     "inputs": (self.cond_wins._version, self.pose6._version)}
 
     def prepared(self, i: int):
         """(amb_bias [128], torso_bias [96] or None) of frame i from the current pass's batched launch, or None.  Called on the frame's
@@ -144,8 +145,8 @@ class FramePipeline:
         if pre is None or not (pre["first"] <= i < pre["stop"]):
             return None
         from .fused import get_state
-        if get_state(self.model).stamp != pre["stamp"]:      # the weights changed since the batch was encoded
-            self._pre = None
+        if get_state(self.model).stamp != pre["stamp"] or pre["inputs"] != (self.cond_wins._version, self.pose6._version):
+            self._pre = None      # the weights, or the windows / poses (edited in place), changed since the batch was encoded
             return None
         cur = torch.cuda.current_stream(self.device)
         if cur.cuda_stream not in pre["waited"]:
@@ -159,6 +160,14 @@ class FramePipeline:
         rays = utils.get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
         return {"cond_wins": self.cond_wins[i], "rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "bg_coords": self.bg_coords,
                 "pose": self.pose6[i:i + 1], "idx": int(self.frame_ids[i]), "bg_img": self.bg, "H": self.H, "W": self.W}
+
+    def kernel_sample(self, i: int) -> dict:
+        """`sample(i)` with the rays the frame loop generates for itself (fused.pinhole_rays: the device function k_frame_init runs), as
+        tensors: run_model(kernel_sample(i)) and render_frame(i) see the same ray bits."""
+        from .fused import pinhole_rays
+        s = self.sample(i)
+        s["rays_o"], s["rays_d"] = pinhole_rays(self.poses[i], self.intrinsics, self.H, self.W, self.device)
+        return s
 
     def run_model(self, sample: dict) -> dict:
         """RADNeRF(Torso)Task.run_model(sample, infer=True) (tasks/radnerfs/radnerf.py:166-170, radnerf_torso.py:113-117)."""
@@ -213,8 +222,11 @@ class FramePipeline:
         reused): consumers copy it or hand it to an encoder that does (png.FrameWriter.submit)."""
         pending = []
         indices = list(indices)
-        if indices and indices == list(range(indices[0], indices[-1] + 1)) and self.prepared(indices[0]) is None:
-            self.prepare(indices[0], indices[-1] + 1)      # every window of the block is resident: one encoder launch for all of them
+        if indices and indices == list(range(indices[0], indices[-1] + 1)):
+            pre = getattr(self, "_pre", None)
+            covered = pre is not None and pre["first"] <= indices[0] and indices[-1] < pre["stop"] and self.prepared(indices[0]) is not None
+            if not covered:      # no batch, a stale one, or one that covers only part of the block (the rest would fall back to per-frame launches)
+                self.prepare(indices[0], indices[-1] + 1)      # every window of the block is resident: one encoder launch for all of them
         for i in indices:
             buf = self.render_frame(i)
             pending.append((i, buf, self._events[(self._slot - 1) % self._depth]))

@@ -116,17 +116,21 @@ def _render_block(model, hparams, dataset, batches, device, rank, world_size, tm
     if tmp_imgs_dir:
         from .png import FrameWriter
         os.makedirs(tmp_imgs_dir, exist_ok=True)
-        writer = FrameWriter(tmp_imgs_dir)
+        # ~5 ms of deflate per 512x512 frame: four workers would cap the loop near 830 fps, below the split and fast tiers.  This rank's share
+        # of the host cores, at most 32 (bench.py's PNG leg sizes its pool the same way)
+        writer = FrameWriter(tmp_imgs_dir, workers=max(2, min(32, (os.cpu_count() or 4) // max(1, world_size))))
     pipe = pipeline_cls(model, hparams, seq, device, frames=(lo, hi), impl="fused" if torch.device(device).type == "cuda" else None)
     out = np.empty((hi - lo, dataset.H, dataset.W, 3), dtype=np.uint8) if collect else None
-    with torch.no_grad():
-        for k, frame in pipe.stream(range(hi - lo)):
-            if out is not None:
-                out[k] = frame
-            if writer is not None:
-                writer.submit(lo + k, frame)      # FrameWriter.submit copies the (reused) pinned buffer
-    if writer is not None:
-        writer.close()
+    try:
+        with torch.no_grad():
+            for k, frame in pipe.stream(range(hi - lo)):
+                if out is not None:
+                    out[k] = frame
+                if writer is not None:
+                    writer.submit(lo + k, frame)      # FrameWriter.submit copies the (reused) pinned buffer
+    finally:
+        if writer is not None:
+            writer.close()      # joins the native threads and raises the writer's first error, also when the loop above failed
     return lo, out
 
 
@@ -243,17 +247,38 @@ class LM3d_RADNeRFInfer:
             # One node by design, so the blocks travel as .npy files in a directory rank 0 names (no pickling of 300 MB blocks through the
             # collective layer); the other ranks return their own block.
             import shutil
+            import socket
             import tempfile
-            box = [tempfile.mkdtemp(prefix="gf_blocks_") if self.proc_rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            np.save(os.path.join(box[0], f"block_{lo:07d}.npy"), out)
-            dist.barrier()
+            hosts = [None] * world
+            dist.all_gather_object(hosts, socket.gethostname())
+            if len(set(hosts)) != 1:
+                raise RuntimeError(f"infer_once under torchrun gathers the ranks' blocks through a local directory: one node only, got hosts {sorted(set(hosts))} "
+                                   "(render with inp['shard'] per node, or collect=False and read the PNGs)")
+            box = [None, None]
             if self.proc_rank == 0:
                 try:
+                    box[0] = tempfile.mkdtemp(prefix="gf_blocks_")
+                except OSError as e:          # the other ranks must not wait at a barrier for a directory that never came
+                    box[1] = repr(e)
+            dist.broadcast_object_list(box, src=0)
+            if box[1] is not None:
+                raise RuntimeError(f"rank 0 could not create the block directory: {box[1]}")
+            err = None
+            try:
+                np.save(os.path.join(box[0], f"block_{lo:07d}.npy"), out)
+            except OSError as e:
+                err = repr(e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)     # (also the barrier behind the writes: every rank learns of any rank's failure instead of hanging)
+            try:
+                if any(errs):
+                    raise RuntimeError(f"writing the frame blocks failed: {[e for e in errs if e]}")
+                if self.proc_rank == 0:
                     out = np.concatenate([np.load(os.path.join(box[0], f)) for f in sorted(os.listdir(box[0]))], axis=0)
-                finally:
+            finally:
+                dist.barrier()
+                if self.proc_rank == 0:
                     shutil.rmtree(box[0], ignore_errors=True)
-            dist.barrier()
             return out
         world = int(world_size) if world_size is not None else (self.num_gpus if self.use_ddp else 1)
         if world <= 1:

@@ -236,6 +236,12 @@ uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/c
  * field 9: rays with at least one sample), field 6 only for those and only when explicit rays were passed in (rays generated from
  * the pose share one origin, which travels by value).  Returns UINT64_MAX for an unknown field. */
 uint64_t gf_frame_field_offset(uint32_t n_rays, uint32_t field);
+/* get_rays, full-image branch (modules/radnerfs/utils.py:282-363 with N = -1; the reference's dataset calls it on the GPU,
+ * tasks/radnerfs/dataset_utils.py:172-178) in one launch: rays_o, rays_d [img_h*img_w, 3], row-major pixels.  pose12_host = the 3x4
+ * cam2world (row-major, ngp axes), intrinsics4_host = fx, fy, cx, cy: HOST pointers, read before the call returns.  Bit for bit the rays a
+ * pose-mode frame (gf_frame_t.rays_o == NULL) generates for itself: both run the same device function. */
+int gf_pinhole_rays(const float* pose12_host, const float* intrinsics4_host, uint32_t img_h, uint32_t img_w, float* rays_o, float* rays_d,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Occupancy-grid maintenance on the device: NeRFRenderer.update_extra_state (renderer.py:199-260) in three launches,

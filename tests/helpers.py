@@ -30,6 +30,35 @@ def frame_inputs(seq, idx):
                 bg=torch.from_numpy(seq["bg_img"]).view(1, -1, 3))
 
 
+def kernel_ray_inputs(seq, idx, device="cuda:0"):
+    """frame_inputs with the rays the frame loop generates for itself (gf_pinhole_rays: the device function k_frame_init runs) -- what the
+    oracle must be fed to arbitrate a pose-mode pixel.  GPU tests only."""
+    from geneface_amd.fused import pinhole_rays
+    fi = frame_inputs(seq, idx)
+    ro, rd = pinhole_rays(torch.from_numpy(seq["poses"][idx]), seq["intrinsics"], seq["H"], seq["W"], device)
+    fi["rays_o"], fi["rays_d"] = ro.cpu(), rd.cpu()
+    return fi
+
+
+def oracle_u8(sd, hp, fi, torso=True, **kw):
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso, **kw)
+    return (ref["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8)
+
+
+def oracle_threads(limit=16):
+    """The oracle's 128-row torch layers and OpenMP loops do not scale to a two-socket host (6 s per 512x512 frame at 128 threads, ~1.5 s
+    at 16): cap the pools for the tests that render many oracle frames."""
+    import ctypes
+    import os
+    t = max(1, min(limit, os.cpu_count() or limit))
+    torch.set_num_threads(t)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(t)
+    except OSError:
+        pass
+    return t
+
+
 def psnr(a, b):
     mse = float(((a.double() - b.double()) ** 2).mean())
     return 99.0 if mse == 0 else -10 * np.log10(mse)

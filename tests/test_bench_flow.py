@@ -87,6 +87,11 @@ def test_bench_control_flow_world2_gloo(tmp_path):
     assert line["ms_per_step"] >= 6.0
     assert abs(line["value"] - 2 * 6 / (line["ms_per_step"] * 6 / 1e3)) < 1e-6 * line["value"]
     assert line["higher_is_better"] is True and line["vs_baseline"] is None
+    # every rank's own clock and shard are in the line: the slow rank is visible as such, not just as the max
+    pr = line["per_rank"]
+    assert len(pr["fps"]) == 2 and pr["frames"] == [[0, 8], [8, 16]]
+    assert pr["fps"][0] > 1.5 * pr["fps"][1] > 0 and pr["fps_min"] == min(pr["fps"]) and pr["fps_max"] == max(pr["fps"])
+    assert line["value"] <= 2 * pr["fps_min"] * 1.05
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
@@ -134,3 +139,95 @@ def test_bench_self_fan_out_runs_end_to_end_on_cpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["steps"] == 5 and line["data"].startswith("selftest")
     assert line["value"] > 0
+
+
+class _OraclePipe:
+    """CPU stand-in for FramePipeline in the parity harness: the "product" is the oracle itself (optionally with one corrupted pixel, or with
+    frame-loop rays that differ from sample()'s in the last ulp), so the harness's bookkeeping can be checked without a GPU."""
+
+    def __init__(self, hp, sd, seq, torso, corrupt=None, pose_mode_ulp=False):
+        import torch
+        from geneface_amd import utils
+        self.hp, self.sd, self.seq, self.torso, self.corrupt, self.pose_mode_ulp = hp, sd, seq, torso, corrupt, pose_mode_ulp
+        self.H, self.W = seq["H"], seq["W"]
+        self.poses = torch.from_numpy(seq["poses"]).float()
+        self.pose6 = utils.convert_poses(self.poses)
+        self.bg = torch.from_numpy(seq["bg_img"]).float().view(1, -1, 3)
+        self.bg_coords = utils.get_bg_coords(self.H, self.W, "cpu")
+        self.cond = torch.from_numpy(seq["cond_wins"]).float()
+
+    def sample(self, i):
+        from geneface_amd import utils
+        r = utils.get_rays(self.poses[i:i + 1], [float(v) for v in self.seq["intrinsics"]], self.H, self.W, -1)
+        return {"cond_wins": self.cond[i], "rays_o": r["rays_o"].contiguous(), "rays_d": r["rays_d"].contiguous(), "bg_coords": self.bg_coords,
+                "pose": self.pose6[i:i + 1], "idx": i, "bg_img": self.bg, "H": self.H, "W": self.W}
+
+    def kernel_sample(self, i):
+        import torch
+        s = self.sample(i)
+        if self.pose_mode_ulp:
+            s["rays_d"] = torch.nextafter(s["rays_d"], torch.full_like(s["rays_d"], float("inf")))
+        return s
+
+    def run_model(self, smp):
+        import bench
+        out = bench.oracle_render(self.hp, self.sd, bench.host_inputs(smp), self.torso)
+        rgb = out["rgb_map"].clone()
+        if self.corrupt is not None:
+            rgb.view(-1, 3)[self.corrupt, 1] += 0.25
+        return {"rgb_map": rgb}
+
+    def render_frame(self, i):
+        import torch
+        import bench
+        out = bench.oracle_render(self.hp, self.sd, bench.host_inputs(self.kernel_sample(i)), self.torso)
+        return (out["rgb_map"].view(self.H, self.W, 3) * 255).to(torch.uint8)
+
+    def wait(self):
+        pass
+
+
+def test_parity_harness_bookkeeping_on_cpu():
+    """bench.parity_vs_oracle with the oracle standing in for the product: identical inputs -> exactly zero; a corrupted pixel is found, located
+    and NOT excused; the fixture's frame set does not depend on the timing flags; the thread sweep reports the best count; the oracle frame of
+    one tier is reused by the next only when the input bits are equal."""
+    import bench
+    from helpers import model_fixture
+    from geneface_amd import synthetic as S
+    hp, sd = model_fixture(True)
+    seq = S.make_sequence(bench.PARITY_T, 32, 32, hp)
+    clock, cache = bench.OracleClock(), {}
+    par = bench.parity_vs_oracle(_OraclePipe(hp, sd, seq, True), hp, sd, True, frames=(1, 14), clock=clock, grazing=True, cache=cache)
+    assert par["max_abs_rgb"] == 0.0 and par["frames"] == 2 and par["frame_indices"] == [1, 14] and par["uint8_within_1_lsb"] == 1.0
+    assert par["pose_mode"]["pixels_off_by_more_than_1_lsb"] == 0 and par["grazing"]["pixels"] >= 0 and len(par["per_frame"]) == 2
+    cpu = clock.result("head+torso 32x32")
+    assert cpu["value"] > 0 and cpu["cores"] in clock.counts and str(cpu["cores"]) in cpu["s_per_frame_by_threads"] and cpu["kind"] == "port"
+    assert set(cache) == {1, 14}
+    # a wrong pixel: reported at its place with its size, whatever the grazing probe says
+    bad = bench.parity_vs_oracle(_OraclePipe(hp, sd, seq, True, corrupt=37), hp, sd, True, frames=(14,), grazing=False, cache=cache)
+    assert abs(bad["max_abs_rgb"] - 0.25) < 1e-3 and bad["worst"]["frame"] == 14 and bad["worst"]["pixel"] == [37 // 32, 37 % 32]
+    # frame-loop rays one ulp away from get_rays': whatever moves by more than 1 LSB must be explained by the oracle on those rays
+    ulp = bench.parity_vs_oracle(_OraclePipe(hp, sd, seq, True, pose_mode_ulp=True), hp, sd, True, frames=(1, 14), grazing=False)
+    assert ulp["pose_mode"]["unexplained_after_oracle_on_kernel_rays"] == 0 and ulp["max_abs_rgb"] == 0.0
+    # the fixture, not the flags, picks the frames; a smaller --parity-frames keeps frame 14 (round 3's escape)
+    assert bench.PARITY_PRIORITY[0] == 14 and sorted(bench.PARITY_PRIORITY) == sorted(bench.PARITY_FRAMES) and max(bench.PARITY_FRAMES) < bench.PARITY_T - 3
+    a, b = S.make_sequence(bench.PARITY_T, 32, 32, hp), S.make_sequence(25, 32, 32, hp)
+    import numpy as np
+    for i in (1, 14, 21):
+        assert np.array_equal(a["poses"][i], b["poses"][i]) and np.array_equal(a["cond_wins"][i], b["cond_wins"][i])
+
+
+def test_replica_checksum_sees_one_flipped_bit():
+    import torch
+    import bench
+    from helpers import model_fixture
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd = model_fixture(True)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    a = bench.replica_checksum(m)
+    assert a == bench.replica_checksum(m)
+    with torch.no_grad():
+        w = m.sigma_net.net[1].weight
+        w.view(torch.int32)[3, 5] ^= 1
+    assert bench.replica_checksum(m) != a

@@ -97,7 +97,13 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         ref8 = (ref["rgb_map"] * 255).view(64, 64, 3).to(torch.uint8)
         got = torch.from_numpy(frames[i])
         from test_gpu_render import check_u8
-        check_u8(got, ref8)          # >= 99.9 % of the bytes identical, <= 1 LSB, PSNR >= 55 dB, up to 4 grazing-ray pixels excepted
+
+        def on_kernel_rays(i=i, pose=pose):
+            from geneface_amd.fused import pinhole_rays
+            kro, krd = pinhole_rays(pose[0], inf.dataset.intrinsics, 64, 64, "cuda:0")
+            r = R.render(sd, hp, kro.cpu(), krd.cpu(), torch.from_numpy(samples[i]["cond_wins"]), bgc, R.convert_poses(pose), bg, torso=True)
+            return (r["rgb_map"] * 255).view(64, 64, 3).to(torch.uint8)
+        check_u8(got, ref8, rerender=on_kernel_rays)      # >= 99.9 % of the bytes identical, <= 1 LSB, PSNR >= 55 dB; nothing excused (see check_u8)
 
 
 def _save_reference_checkpoint(path, model_sd, step, extra_children=True):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import frame_inputs, model_fixture, psnr, sequence
+from helpers import frame_inputs, kernel_ray_inputs, model_fixture, oracle_u8, psnr, sequence
 from oracle import radnerf_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -51,18 +51,26 @@ def check(out, ref, torso):
             assert (out[k].cpu() - r).abs().max().item() < tol, k
 
 
-def check_u8(frame, ref8, graze=4):
+def check_u8(frame, ref8, rerender=None):
     """Bar for uint8 frames whose rays were generated inside the kernel: >= 99.9 % of the bytes identical, nothing off by more than 1 LSB,
-    PSNR >= 55 dB -- except for at most `graze` pixels.  In-kernel rays can differ from torch's get_rays in the last ulp (the reference
-    builds them with a matmul whose summation order is the BLAS library's); a ray that grazes an occupied cell of the density grid within
-    that ulp gains or loses its first sample, and its pixel changes by a visible amount.  Measured: 0-1 such pixels per frame."""
-    frame, ref8 = torch.as_tensor(frame), torch.as_tensor(ref8)
-    diff = (frame.int() - ref8.int()).abs().reshape(-1, 3)
+    PSNR >= 55 dB.  In-kernel rays can differ from torch's get_rays in the last ulp (the reference builds them with a matmul whose summation
+    order is the BLAS library's); a ray that grazes an occupied cell of the density grid within that ulp gains or loses a sample, and its
+    pixel changes by a visible amount (0-1 such pixels per frame).  No pixel is excused on that suspicion: when any is off by more than
+    1 LSB, `rerender()` must return the reference frame rendered FROM THE KERNEL'S OWN RAYS (helpers.kernel_ray_inputs -> gf_pinhole_rays, the
+    device function k_frame_init runs) and the whole frame must then agree within 1 LSB."""
+    frame, ref8 = torch.as_tensor(frame).reshape(-1, 3), torch.as_tensor(ref8).reshape(-1, 3)
+    diff = (frame.int() - ref8.int()).abs()
     off = (diff > 1).any(dim=1)
-    assert int(off.sum()) <= graze, int(off.sum())
+    n_off = int(off.sum())
+    if n_off:
+        assert rerender is not None, f"{n_off} pixels off by more than 1 LSB and no arbitration on the kernel's own rays"
+        assert n_off <= 8, n_off           # grazing rays are rare; more than a handful is something else
+        ref8 = torch.as_tensor(rerender()).reshape(-1, 3)
+        diff = (frame.int() - ref8.int()).abs()
+        assert int(diff.max()) <= 1, (n_off, int((diff > 1).any(dim=1).sum()), "still off after re-rendering the reference on the kernel's rays")
     assert (diff == 0).float().mean().item() > 0.999
-    keep = ~off
-    assert psnr(frame.reshape(-1, 3)[keep].float() / 255, ref8.reshape(-1, 3)[keep].float() / 255) > 55
+    assert psnr(frame.float() / 255, ref8.float() / 255) > 55
+    return n_off
 
 
 @pytest.mark.parametrize("impl", ["ops", "fused"])
@@ -180,12 +188,20 @@ def test_frame_pipeline_pose_mode_vs_oracle(torso):
         fi = frame_inputs(seq, i)
         ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
         ref8 = (ref["rgb_map"] * 255).view(128, 128, 3).to(torch.uint8)
-        check_u8(frame, ref8)
-        # the ops-path pipeline must give the same picture
+        check_u8(frame, ref8, rerender=lambda: oracle_u8(sd, hp, kernel_ray_inputs(seq, i), torso))
+        # the ops-path pipeline must give the same picture (its rays are torch's get_rays: arbitration = the ops path on the kernel's rays)
         pipe_ops = FramePipeline(model, hp, seq, DEV, impl="ops")
         frame_ops = pipe_ops.render_frame(i).clone()
         torch.cuda.synchronize()
-        check_u8(frame_ops, frame)
+
+        def ops_on_kernel_rays():
+            with torch.no_grad():
+                return (pipe_ops.run_model(pipe_ops.kernel_sample(i))["rgb_map"] * 255).to(torch.uint8).cpu()
+        check_u8(frame, frame_ops, rerender=ops_on_kernel_rays)
+        # and the module API fed the kernel's own rays IS the frame loop's frame, byte for byte
+        with torch.no_grad():
+            same = (pipe.run_model(pipe.kernel_sample(i))["rgb_map"] * 255).to(torch.uint8).view(128, 128, 3).cpu()
+        assert torch.equal(same, frame.cpu())
 
 
 def test_cond_encode_kernel_vs_oracle():
@@ -575,7 +591,8 @@ def test_torso_head_aware_vs_oracle(branch, impl, monkeypatch):
         pipe = FramePipeline(m, hp, seq, DEV, impl="fused")
         frame = pipe.render_frame(2)
         pipe.wait()
-        check_u8(frame, (ref["rgb_map"] * 255).view(96, 96, 3).to(torch.uint8))
+        check_u8(frame, (ref["rgb_map"] * 255).view(96, 96, 3).to(torch.uint8),
+                 rerender=lambda: oracle_u8(sd, hp, kernel_ray_inputs(seq, 2), True, head_aware_branch=branch))
         # a weight update reaches the head-aware packs as well (index-map refresh, no host round trip)
         with torch.no_grad():
             m.head_color_weights_encoder[4].weight.mul_(0.5)

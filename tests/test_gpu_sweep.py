@@ -1,0 +1,149 @@
+"""-m gpu: the WHOLE sequence of the driver's bench command (`bench.py --gpus 1 --steps 20 --warmup 5`: 25 frames) at the headline shape,
+512x512 head+torso, every frame, every tier -- not one or two sampled frames.
+
+Round 3's driver line showed max|d rgb| = 0.0896 on frame 14 of this sequence, a frame no test had rendered.  The cause:
+one ray grazing an occupied cell, with the two sides of the comparison fed rays that differed in the last ulp (torch's get_rays on the GPU for
+the product, on the CPU for the oracle).  A once-per-14-frames event is invisible to tests that sample a frame or two, so:
+  * identical rays (the device tensors of FramePipeline.sample(i), copied to the host for the oracle): ZERO pixels above the strict 1e-4, on
+    every frame, for the fused fp32 path, the op-by-op path and the split tier;
+  * the frame loop (rays generated inside the kernel): the module API fed gf_pinhole_rays' tensors gives the frame loop's bytes exactly, and
+    every pixel that is off by more than 1 LSB from the oracle's uint8 frame is re-rendered by the oracle on the kernel's own rays and must
+    then agree -- no pixel is excused on suspicion of grazing;
+  * the grazing pixel itself is pinned: on frame 14 the oracle fed CPU-built rays and the oracle fed GPU-built rays disagree by ~0.1 at one
+    pixel -- the oracle against ITSELF -- which is what the driver's line recorded.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import model_fixture, oracle_threads, sequence
+from oracle import radnerf_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RGB_ATOL = 1e-4          # BASELINE.md section 4, strict tier
+T_DRIVER = 25            # --steps 20 --warmup 5
+
+
+def _model(precision="fp32", impl="fused"):
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd = model_fixture(True)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m.render_impl, m.render_precision = impl, precision
+    return hp, sd, m.to(DEV).eval()
+
+
+def _host(smp):
+    return {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in smp.items()}
+
+
+def _oracle(hp, sd, inp):
+    return R.render(sd, hp, inp["rays_o"], inp["rays_d"], inp["cond_wins"], inp["bg_coords"], inp["pose"], inp["bg_img"], torso=True)
+
+
+def test_sweep_driver_sequence_512_every_frame_every_tier():
+    from geneface_amd.infer import FramePipeline
+    oracle_threads(16)
+    seq = sequence(T_DRIVER, 512, 512)
+    hp, sd, m32 = _model("fp32", "fused")
+    _, _, mops = _model("fp32", "ops")
+    _, _, msp = _model("split", "fused")
+    pipes = {"fused": FramePipeline(m32, hp, seq, DEV, impl="fused"), "ops": FramePipeline(mops, hp, seq, DEV, impl="ops"),
+             "split": FramePipeline(msp, hp, seq, DEV, impl="fused")}
+    worst, flagged, report = {k: 0.0 for k in pipes}, 0, []
+    for i in range(T_DRIVER):
+        with torch.no_grad():
+            smp = pipes["fused"].sample(i)
+            inp = _host(smp)
+            ref = _oracle(hp, sd, inp)["rgb_map"].reshape(-1, 3)
+            for name, pipe in pipes.items():
+                out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+                d = (out - ref).abs()
+                err = float(d.max())
+                worst[name] = max(worst[name], err)
+                n_bad = int((d.max(dim=1).values > RGB_ATOL).sum())
+                pix = int(d.max(dim=1).values.argmax())
+                assert n_bad == 0, f"frame {i} [{name}]: {n_bad} pixels above {RGB_ATOL}; worst {err:.3g} at pixel {pix} (row {pix // 512}, col {pix % 512})"
+            # frame loop: in-kernel rays.  (a) the module API on gf_pinhole_rays' tensors is the frame loop's frame, byte for byte
+            for name in ("fused", "split"):
+                pipe = pipes[name]
+                u8 = pipe.render_frame(i)
+                pipe.wait()
+                u8 = u8.clone().reshape(-1, 3)
+                ksmp = pipe.kernel_sample(i)
+                same = (pipe.run_model(ksmp)["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8).cpu()
+                assert torch.equal(same, u8), f"frame {i} [{name}]: pose mode and explicit kernel rays differ in {int((same != u8).sum())} bytes"
+                # (b) against the oracle's uint8 frame: anything off by more than 1 LSB goes to arbitration on the kernel's own rays
+                ref8 = (ref * 255).to(torch.uint8)
+                off = ((u8.int() - ref8.int()).abs() > 1).any(dim=1)
+                if bool(off.any()):
+                    flagged += int(off.sum())
+                    k8 = (_oracle(hp, sd, _host(ksmp))["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8)
+                    still = ((u8.int() - k8.int()).abs() > 1).any(dim=1)
+                    report.append((i, name, int(off.sum()), int(still.sum())))
+                    assert not bool(still.any()), f"frame {i} [{name}]: {int(still.sum())} pixels off by > 1 LSB even on the kernel's own rays"
+                    assert int(off.sum()) <= 8
+    print(f"sweep: worst max|d rgb| {worst}; pose-mode pixels sent to arbitration: {flagged} {report}")
+    assert max(worst.values()) < RGB_ATOL
+
+
+def test_frame_14_the_oracle_moves_under_a_last_ulp_ray_change():
+    """The mechanism of round 3's 0.0896, pinned: on frame 14 of the driver's sequence the ORACLE fed rays built on the CPU and the oracle fed
+    the same rays built on the GPU (torch's get_rays both times; the rotation matmul rounds differently) disagree at pixel (497, 248) by
+    about 0.1 and nowhere else above 1e-3 -- while the product agrees with the oracle to 1e-4 whichever of the two ray sets BOTH are fed."""
+    from geneface_amd.infer import FramePipeline
+    oracle_threads(16)
+    seq = sequence(T_DRIVER, 512, 512)
+    hp, sd, m = _model("fp32", "fused")
+    pipe = FramePipeline(m, hp, seq, DEV, impl="fused")
+    with torch.no_grad():
+        smp = pipe.sample(14)
+        inp_dev = _host(smp)
+        pose = torch.from_numpy(seq["poses"][14:15])
+        ro, rd = R.get_rays(pose, seq["intrinsics"], 512, 512)
+        inp_cpu = dict(inp_dev, rays_o=ro.contiguous(), rays_d=rd.contiguous())
+        ulp_diff = float((inp_cpu["rays_d"] != inp_dev["rays_d"]).float().mean())
+        ref_dev, ref_cpu = _oracle(hp, sd, inp_dev)["rgb_map"].reshape(-1, 3), _oracle(hp, sd, inp_cpu)["rgb_map"].reshape(-1, 3)
+        out_dev = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+        smp_cpu = dict(smp, rays_o=inp_cpu["rays_o"].to(DEV), rays_d=inp_cpu["rays_d"].to(DEV))
+        out_cpu = pipe.run_model(smp_cpu)["rgb_map"].reshape(-1, 3).cpu()
+    assert (out_dev - ref_dev).abs().max().item() < RGB_ATOL and (out_cpu - ref_cpu).abs().max().item() < RGB_ATOL
+    move = (ref_dev - ref_cpu).abs().max(dim=1).values
+    print(f"frame 14: {ulp_diff:.1%} of the direction components differ between CPU- and GPU-built rays; the oracle moves by {float(move.max()):.4f} at pixel "
+          f"{int(move.argmax())}; pixels moved by > 1e-3: {int((move > 1e-3).sum())}")
+    if ulp_diff > 0:     # (a BLAS that happens to round like the CPU's leaves nothing to show)
+        assert int((move > 1e-3).sum()) <= 4
+        # the product moves with the oracle: the cross comparison (what round 3's bench did) inherits exactly the oracle's own movement
+        cross = (out_dev - ref_cpu).abs().max(dim=1).values
+        assert abs(float(cross.max()) - float(move.max())) < 2e-4
+
+
+def test_bench_one_rank_under_torchrun_uses_rccl():
+    """The N > 1 launch path on the one GPU a test box has: `torchrun --nproc-per-node 1 bench.py` creates the RCCL process group, broadcasts
+    the weights, all-reduces the rank count, gathers the per-rank block and runs the every-rank parity check -- the calls a 2/4/8-GPU run makes."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--rank-parity", "--no-stress",
+           "--png-frames", "0", "--min-seconds", "0.2", "--profile-frames", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["config"]["collective_backend"] == "nccl" and line["config"]["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    pr = line["per_rank"]
+    assert pr["replica_checksum_equal"] is True and len(pr["fps"]) == 1 and pr["fps"][0] > 0 and pr["frames"] == [[0, 7]]
+    par = pr["parity_first_frame"]
+    assert par["frame"] == 14 and par["max_abs_rgb"] < RGB_ATOL and par["identical_across_ranks"] is True
+    assert line["value"] > 25 and line["roofline"]["frac"] > 0.4

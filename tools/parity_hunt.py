@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Round 4, VERDICT item 1(a): reproduce and arbitrate the parity escape of the driver's round-3 line.
+
+`BENCH_r03.json`: `python3 bench.py --gpus 1 --steps 20 --warmup 5` -> parity.max_abs_rgb = 0.0896 on frames [1,4,8,11,14,17,21,24] of the
+25-frame sequence.  That bench compared the product rendered from rays built by torch's get_rays ON THE GPU with the oracle fed rays built by
+the same function ON THE CPU.  This script renders those frames every way round and prints who disagrees with whom, and where:
+
+    product(dev rays)  vs oracle(dev rays)     identical inputs: the parity claim
+    product(dev rays)  vs oracle(cpu rays)     what round 3's bench compared
+    oracle(dev rays)   vs oracle(cpu rays)     the oracle against itself under a last-ulp ray change
+    product(cpu rays)  vs oracle(cpu rays)     identical inputs again, the other ray set
+    product(dev rays)  vs reference kernels on the GPU (oracle/_ref, the reference's own .cu built for gfx950) fed the same device rays
+and, for all 25 frames, product vs the reference kernels' pipeline on identical device rays (GPU only, no CPU oracle involved).
+
+    python tools/parity_hunt.py [--out gpurun_out/r4a/parity_hunt.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from helpers import model_fixture, oracle_threads, sequence      # noqa: E402
+from oracle import radnerf_ref as R                               # noqa: E402
+from oracle import ref_kernels                                    # noqa: E402
+
+DEV = "cuda:0"
+
+
+def host(smp):
+    return {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in smp.items()}
+
+
+def oracle(hp, sd, inp):
+    return R.render(sd, hp, inp["rays_o"], inp["rays_d"], inp["cond_wins"], inp["bg_coords"], inp["pose"], inp["bg_img"], torso=True)["rgb_map"].reshape(-1, 3)
+
+
+def cmp(a, b, W=512):
+    d = (a.double() - b.double()).abs().max(dim=1).values
+    pix = int(d.argmax())
+    return {"max": float(d.max()), "pixel": pix, "row_col": [pix // W, pix % W], "n_above_1e-4": int((d > 1e-4).sum()), "n_above_1e-3": int((d > 1e-3).sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_hunt.json"))
+    ap.add_argument("--frames", default="1,4,8,11,14,17,21,24")
+    ap.add_argument("--T", type=int, default=25)
+    args = ap.parse_args()
+    from geneface_amd.infer import FramePipeline
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    threads = oracle_threads(16)
+    hp, sd = model_fixture(True)
+    seq = sequence(args.T, 512, 512)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.render_impl = "fused"
+    pipe = FramePipeline(m, hp, seq, DEV, impl="fused")
+    have_ref = ref_kernels.available("fast")
+    sd_g = {k: v.to(DEV) for k, v in sd.items()}
+
+    def ref_gpu(smp):
+        with R.kernel_backend(ref_kernels.load("fast")):
+            return R.render(sd_g, hp, smp["rays_o"], smp["rays_d"], smp["cond_wins"], smp["bg_coords"], smp["pose"], smp["bg_img"], True)["rgb_map"].reshape(-1, 3).cpu()
+
+    report = {"command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
+              "frames": {}, "sweep_vs_reference_kernels": []}
+    t0 = time.time()
+    for i in [int(x) for x in args.frames.split(",")]:
+        with torch.no_grad():
+            smp = pipe.sample(i)
+            dev_in = host(smp)
+            ro, rd = R.get_rays(torch.from_numpy(seq["poses"][i:i + 1]), seq["intrinsics"], 512, 512)
+            cpu_in = dict(dev_in, rays_o=ro.contiguous(), rays_d=rd.contiguous())
+            out_dev = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+            smp_c = dict(smp, rays_o=cpu_in["rays_o"].to(DEV), rays_d=cpu_in["rays_d"].to(DEV))
+            out_cpu = pipe.run_model(smp_c)["rgb_map"].reshape(-1, 3).cpu()
+            o_dev, o_cpu = oracle(hp, sd, dev_in), oracle(hp, sd, cpu_in)
+            rec = {"ray_components_differing": float((dev_in["rays_d"] != cpu_in["rays_d"]).float().mean()),
+                   "max_ray_ulp_difference": int((dev_in["rays_d"].view(torch.int32) - cpu_in["rays_d"].view(torch.int32)).abs().max()),
+                   "product(dev) vs oracle(dev)": cmp(out_dev, o_dev), "product(dev) vs oracle(cpu) [round 3's comparison]": cmp(out_dev, o_cpu),
+                   "oracle(dev) vs oracle(cpu)": cmp(o_dev, o_cpu), "product(cpu) vs oracle(cpu)": cmp(out_cpu, o_cpu)}
+            if have_ref:
+                rec["product(dev) vs reference kernels on GPU(dev)"] = cmp(out_dev, ref_gpu(smp))
+                rec["oracle(dev) vs reference kernels on GPU(dev)"] = cmp(o_dev, ref_gpu(smp))
+        report["frames"][str(i)] = rec
+        print(i, json.dumps(rec), flush=True)
+    if have_ref:
+        for i in range(args.T):
+            with torch.no_grad():
+                smp = pipe.sample(i)
+                out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+                c = cmp(out, ref_gpu(smp))
+            c["frame"] = i
+            report["sweep_vs_reference_kernels"].append(c)
+        print("sweep vs reference kernels (identical device rays): worst", max(c["max"] for c in report["sweep_vs_reference_kernels"]), flush=True)
+    report["seconds"] = time.time() - t0
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(report, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
