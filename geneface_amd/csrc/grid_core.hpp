@@ -197,6 +197,108 @@ __device__ __forceinline__ LevelMeta make_level_meta(float scale, uint32_t resol
     return m;
 }
 
+// A 16-byte read at an 8-byte-aligned address (two x-adjacent 2-channel rows): global memory needs dword alignment only, and the texture
+// path charges a wave instruction the same whether its lanes fetch 8 or 16 bytes, at even or odd rows (tools/gather_probe.hip, modes 1 / 4:
+// 2x the rows per clock of 8-byte reads at every table size).
+struct __attribute__((aligned(8))) RowPair { float x0, y0, x1, y1; };
+
+// encode8 for TILED grids (gridtype 1: no level hashes; the May configuration): the two x-corners of a cell are ADJACENT rows on every
+// level -- idx(x + 1, y, z) = (idx(x, y, z) + 1) & mask -- so each (y, z) corner pair travels as ONE 16-byte read: half the load
+// instructions and index arithmetic of the per-corner form, the same values consumed in the same (reference) corner order, hence the
+// same bits.  The one exception is a wrapped level's last row (idx == mask: its x-neighbour is row 0 of the level): those lanes read
+// rows (mask - 1, mask) instead -- never past the level, so never past the table -- and a wave-level rare branch (2^-16 of the pairs on a
+// 2^16-row level) fetches row 0 and re-sorts the pair.
+template <uint32_t D>
+__device__ __forceinline__ void encode8_tiled(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t interp,
+                                              const float (&x)[D], float (&f)[16]) {
+    static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
+#ifndef GF_TILED_LB3
+#define GF_TILED_LB3 4
+#endif
+#ifndef GF_TILED_LB2
+#define GF_TILED_LB2 8
+#endif
+    constexpr int LB = D == 3 ? GF_TILED_LB3 : GF_TILED_LB2, NP = 1 << (D - 1), NC = 1 << D;
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
+#pragma unroll
+    for (int b = 0; b < 8 / LB; b++) {
+        RowPair v[LB][NP];
+        float pw[LB][D];
+        uint32_t wrap = 0;     // bit k * NP + p: pair p of level k sits on the last row of a wrapped level
+#pragma unroll
+        for (int k = 0; k < LB; k++) {
+            const int l = b * LB + k;
+            const uint4 m0 = reinterpret_cast<const uint4*>(meta8)[2 * l];
+            const uint32_t row_off = reinterpret_cast<const uint32_t*>(meta8)[8 * l + 4];
+            const float scale = __uint_as_float(m0.x);
+            const uint32_t s1 = m0.y, s2 = m0.z, mask = m0.w;
+            uint32_t g[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
+                const float fl = floorf(p);
+                g[d] = (uint32_t)fl;
+                p -= fl;
+                if (interp == 1) p = p * p * (3.0f - 2.0f * p);
+                pw[k][d] = p;
+            }
+            const uint32_t y0 = g[1] * s1;
+            const uint32_t yy[2] = {g[0] + y0, g[0] + y0 + s1};
+            uint32_t zz[2] = {0u, 0u};
+            if constexpr (D == 3) { zz[0] = g[2] * s2; zz[1] = zz[0] + s2; }
+            const uint32_t last = mask - 1u;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                uint32_t i0 = yy[p & 1];
+                if constexpr (D == 3) i0 += zz[p >> 1];
+                i0 &= mask;
+                wrap |= (i0 == mask ? 1u : 0u) << (k * NP + p);
+                const uint32_t ild = i0 < last ? i0 : last;      // (dense levels: mask is all ones, nothing changes)
+                v[k][p] = *reinterpret_cast<const RowPair*>(rows + row_off + ild);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef GF_EXP_NOWRAP
+        if (__builtin_expect(__any(wrap != 0u), 0)) {
+#pragma unroll
+            for (int k = 0; k < LB; k++) {
+                const uint32_t row_off = reinterpret_cast<const uint32_t*>(meta8)[8 * (b * LB + k) + 4];
+#pragma unroll
+                for (int p = 0; p < NP; p++)
+                    if ((wrap >> (k * NP + p)) & 1u) {
+                        const float2 r0 = rows[row_off];
+                        v[k][p].x0 = v[k][p].x1; v[k][p].y0 = v[k][p].y1;
+                        v[k][p].x1 = r0.x; v[k][p].y1 = r0.y;
+                    }
+            }
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < LB; k++) {
+            const int l = b * LB + k;
+            float w1[D], w0[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) { w1[d] = pw[k][d]; w0[d] = 1 - pw[k][d]; }
+            float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)NC; c++) {
+                const uint32_t bx = c & 1u, by = (c >> 1) & 1u, bz = (c >> 2) & 1u;
+                float w = bx ? w1[0] : w0[0];
+                w *= by ? w1[1] : w0[1];
+                if constexpr (D == 3) w *= bz ? w1[2] : w0[2];
+                const RowPair& r = v[k][c >> 1];
+                o0 += w * (bx ? r.x1 : r.x0);
+                o1 += w * (bx ? r.y1 : r.y0);
+            }
+            f[l * 2 + 0] = oob ? 0.0f : o0;
+            f[l * 2 + 1] = oob ? 0.0f : o1;
+        }
+    }
+}
+
 // Eight consecutive levels at one point x (already mapped to [0,1]) -> f[16] = [level][channel].
 // Two explicit steps per batch of levels (four 3-D levels = 32 reads, all eight 2-D levels = 32 reads): every table read of the batch is
 // ISSUED, then a scheduling barrier, then the interpolation consumes them in the reference's corner order.  Left to itself the scheduler
@@ -208,6 +310,16 @@ __device__ __forceinline__ void encode8(const float* __restrict__ table, const L
     static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
     constexpr int LB = D == 3 ? 4 : 8, NC = 1 << D;
+#ifdef GF_TILED_ONLY
+    encode8_tiled<D>(table, meta8, interp, x, f);
+    return;
+#endif
+#ifndef GF_NO_PAIRED_ROWS
+    if (gridtype == 1u) {   // wave-uniform (a kernel argument): tiled grids take the paired-row form
+        encode8_tiled<D>(table, meta8, interp, x, f);
+        return;
+    }
+#endif
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);

@@ -30,14 +30,16 @@ def frame_inputs(seq, idx):
                 bg=torch.from_numpy(seq["bg_img"]).view(1, -1, 3))
 
 
-def kernel_ray_inputs(seq, idx, device="cuda:0"):
-    """frame_inputs with the rays the frame loop generates for itself (gf_pinhole_rays: the device function k_frame_init runs) -- what the
-    oracle must be fed to arbitrate a pose-mode pixel.  GPU tests only."""
-    from geneface_amd.fused import pinhole_rays
-    fi = frame_inputs(seq, idx)
-    ro, rd = pinhole_rays(torch.from_numpy(seq["poses"][idx]), seq["intrinsics"], seq["H"], seq["W"], device)
-    fi["rays_o"], fi["rays_d"] = ro.cpu(), rd.cpu()
-    return fi
+def pipe_inputs(pipe, idx, kernel_rays=True):
+    """The bits a FramePipeline feeds frame `idx` with, copied to the host in frame_inputs' layout -- rays (kernel_rays: the ones the frame
+    loop generates for itself, gf_pinhole_rays = the device function k_frame_init runs; else torch's get_rays on the GPU), background
+    coordinates, euler pose, window, background: what the oracle must be fed to arbitrate a pose-mode pixel.  EVERY input comes from the
+    device: torch on the GPU divides by a scalar as a multiplication by its reciprocal, so even get_bg_coords differs from the CPU's in the last
+    ulp -- and the torso mask `occ > 0` (radnerf_torso.py:167-172) is a step function of those coordinates wherever a bilinear sample lands on
+    a node of the 128 x 128 occupancy grid (every pixel of a 128 x 128 frame).  GPU tests only."""
+    s = pipe.kernel_sample(idx) if kernel_rays else pipe.sample(idx)
+    c = lambda t: t.detach().cpu().contiguous()
+    return dict(rays_o=c(s["rays_o"]), rays_d=c(s["rays_d"]), bg_coords=c(s["bg_coords"]), cond=c(s["cond_wins"]), pose6=c(s["pose"]), bg=c(s["bg_img"]))
 
 
 def oracle_u8(sd, hp, fi, torso=True, **kw):

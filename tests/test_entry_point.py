@@ -98,10 +98,12 @@ def test_infer_once_end_to_end_vs_oracle(tmp_path):
         got = torch.from_numpy(frames[i])
         from test_gpu_render import check_u8
 
-        def on_kernel_rays(i=i, pose=pose):
+        def on_kernel_rays(i=i, pose=pose):      # every input as the device computes it (rays, background coordinates, euler pose)
+            from geneface_amd import utils
             from geneface_amd.fused import pinhole_rays
             kro, krd = pinhole_rays(pose[0], inf.dataset.intrinsics, 64, 64, "cuda:0")
-            r = R.render(sd, hp, kro.cpu(), krd.cpu(), torch.from_numpy(samples[i]["cond_wins"]), bgc, R.convert_poses(pose), bg, torso=True)
+            r = R.render(sd, hp, kro.cpu(), krd.cpu(), torch.from_numpy(samples[i]["cond_wins"]), utils.get_bg_coords(64, 64, "cuda:0").cpu(),
+                         utils.convert_poses(pose.to("cuda:0")).cpu(), bg, torso=True)
             return (r["rgb_map"] * 255).view(64, 64, 3).to(torch.uint8)
         check_u8(got, ref8, rerender=on_kernel_rays)      # >= 99.9 % of the bytes identical, <= 1 LSB, PSNR >= 55 dB; nothing excused (see check_u8)
 
