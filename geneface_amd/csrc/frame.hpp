@@ -15,7 +15,10 @@ struct FrameWs {
     uint32_t* ctrl;  // [kCtrlWords]
     size_t bytes;
 };
-constexpr uint32_t kMaxSteps = 64;  // largest max_steps the fused path accepts
+constexpr uint32_t kMaxSteps = 1024;  // largest max_steps the fused path accepts: the reference's own default (renderer.py:263) and the top of
+                                      // its viewer's slider (radnerf_gui.py:466-471).  (64 until round 4: the size of the LDS histogram, which now
+                                      // only holds the first kHistLds bins; later terminal indices go to the control block directly.)
+constexpr uint32_t kHistLds = 66;     // terminal indices d < kHistLds are counted per workgroup in LDS and flushed once
 // Control block (uint32 words), zeroed by a memset node at the head of every frame.  Three groups on separate 128-byte lines (round 3): L2
 // retires atomics on one line at ~10 ns each, and the queue heads -- on the critical path of every pool refill -- used to share a line with
 // the statistics and the histogram that every retiring workgroup adds to.
@@ -31,7 +34,8 @@ constexpr uint32_t kCtrlStatB = 36;    // [2 phases] uint64: workgroup rounds (l
                                        //     that terminates inside a round leaves the rest of its slots of that round evaluated but unused)
 // lines 2..4: terminal-index histogram
 constexpr uint32_t kCtrlHist = 64;     // [kMaxSteps + 2] rays that terminate at cumulative sample index d (d = 1 .. max_steps)
-constexpr uint32_t kCtrlWords = 160;
+constexpr uint32_t kCtrlWords = 1152;  // 64 + kMaxSteps + 2, rounded up to whole 128-byte lines; a frame zeroes only the words its max_steps needs
+inline uint32_t ctrl_words_used(uint32_t max_steps) { return kCtrlHist + max_steps + 2; }
 
 inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
     FrameWs w;

@@ -51,7 +51,7 @@ constexpr int kPass = 128;            // sample slots per round (four 32-column 
 constexpr int kPool = 128;            // live rays per workgroup
 constexpr int kHS = 132;              // floats per activation row (128 + 4: rows 16 B apart in bank space -> conflict-free b128)
 constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 2 * 16 * 8 /*level meta*/;
-constexpr int kHistBins = gf::kMaxSteps + 2;
+constexpr int kHistBins = gf::kHistLds;   // LDS bins of the terminal-index histogram (d < kHistBins; larger d: global atomics, rare)
 #ifndef GF_MARCH_SLACK
 #define GF_MARCH_SLACK 12
 #endif
@@ -1255,8 +1255,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         budget = a.max_steps;
         limit = a.ctrl[gf::kCtrlNHit];
     } else {
+        // the histogram of phase 0 (complete: this launch follows it in stream order) is staged in LDS by all lanes -- one parallel read instead
+        // of max_steps dependent global loads on lane 0 -- in the activation buffer, which nothing uses yet
+        uint32_t* hs = reinterpret_cast<uint32_t*>(s.H);
+        for (uint32_t i = tid; i <= a.max_steps; i += kThreads) hs[i] = a.ctrl[gf::kCtrlHist + i];
+        __syncthreads();
         if (tid == 0) {
-            const uint32_t B = replay_budget(a.ctrl + gf::kCtrlHist, a.N, a.max_steps);
+            const uint32_t B = replay_budget(hs, a.N, a.max_steps);
             s.misc[8] = B;
             if (blockIdx.x == 0) a.ctrl[gf::kCtrlBudget] = B;
         }
@@ -1506,7 +1511,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 a.depth[ray] = acc.depth;
                 a.image[(size_t)ray * 3 + 0] = acc.r; a.image[(size_t)ray * 3 + 1] = acc.g; a.image[(size_t)ray * 3 + 2] = acc.b;
                 if (finished) a.rays_t[ray] = r_t;
-                if (died && a.phase == 0) atomicAdd(&s.hist[d], 1u);
+                if (died && a.phase == 0) {
+                    if (d < (uint32_t)kHistBins) atomicAdd(&s.hist[d], 1u);
+                    else atomicAdd(&a.ctrl[gf::kCtrlHist + d], 1u);     // max_steps > 64 only: a ray that outlives 64 samples before it ends
+                }
                 survivor = finished && a.phase == 0;
             }
             if (died || finished) {
@@ -1535,7 +1543,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     __syncthreads();
     {   // the lane index is re-derived here (mbcnt) rather than kept: the allocator had parked `4 * tid` in scratch from the first line to this one
         const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (a.phase == 0 && tid_e >= 1 && tid_e <= (int)a.max_steps) {
+        if (a.phase == 0 && tid_e >= 1 && tid_e <= (int)a.max_steps && tid_e < kHistBins) {
             const uint32_t v = s.hist[tid_e];
             if (v) atomicAdd(&a.ctrl[gf::kCtrlHist + tid_e], v);
         }
@@ -2096,7 +2104,7 @@ int check_frame(const gf_frame_t* f) {
     if ((f->rays_o == nullptr) != (f->rays_d == nullptr)) return gf_set_error(GF_ERR_INVALID, "frame: rays_o and rays_d must both be given or both NULL");
     if (!f->rays_o && (uint64_t)f->img_h * f->img_w != f->n_rays) return gf_set_error(GF_ERR_INVALID, "frame: img_h*img_w != n_rays");
     if (f->max_steps == 0 || f->cascade == 0 || f->grid_size == 0 || f->grid_size > 1024) return gf_set_error(GF_ERR_INVALID, "frame: bad marcher configuration");
-    if (f->max_steps > gf::kMaxSteps) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u needs the op-by-op path", gf::kMaxSteps);
+    if (f->max_steps > gf::kMaxSteps) return gf_set_error(GF_ERR_UNSUPPORTED, "frame: max_steps > %u (the reference's own default and viewer maximum)", gf::kMaxSteps);
     if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "frame: gridtype/interp must be 0 or 1");
     if (f->precision > 2) return gf_set_error(GF_ERR_INVALID, "frame: precision must be 0 (fp32), 1 (fast) or 2 (split)");
     if (f->precision == 1 && !f->head_pack16) return gf_set_error(GF_ERR_INVALID, "frame: precision = 1 needs head_pack16");
@@ -2107,7 +2115,7 @@ int check_frame(const gf_frame_t* f) {
 int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 6 events around the two phase kernels (0..3) and k_frame_init (4, 5) */) {
     const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
     const uint32_t N = f->n_rays;
-    if (hipMemsetAsync(w.ctrl, 0, gf::kCtrlWords * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "frame: hipMemsetAsync failed");
+    if (hipMemsetAsync(w.ctrl, 0, gf::ctrl_words_used(f->max_steps) * sizeof(uint32_t), s) != hipSuccess) return gf_set_error(GF_ERR_HIP, "frame: hipMemsetAsync failed");
 
     InitArgs ia;
     gf::fill_march_params(ia.mp, f->bitfield, f->bound, f->dt_gamma, f->max_steps, f->cascade, f->grid_size);

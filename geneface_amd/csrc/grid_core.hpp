@@ -206,10 +206,11 @@ struct __attribute__((aligned(8))) RowPair { float x0, y0, x1, y1; };
 // level -- idx(x + 1, y, z) = (idx(x, y, z) + 1) & mask -- so each (y, z) corner pair travels as ONE 16-byte read: half the load
 // instructions and index arithmetic of the per-corner form, the same values consumed in the same (reference) corner order, hence the
 // same bits.  The one exception is a wrapped level's last row (idx == mask: its x-neighbour is row 0 of the level): those lanes read
-// rows (mask - 1, mask) instead -- never past the level, so never past the table -- and a wave-level rare branch (2^-16 of the pairs on a
-// 2^16-row level) fetches row 0 and re-sorts the pair.
+// rows (mask - 1, mask) instead -- never past the level, so never past the table -- and report it (return value): the caller then redoes
+// the wave's lookup corner by corner (2^-16 of the pairs on a 2^16-row level).  (A fix-up of just the affected pairs inside this function
+// kept the 64 loaded registers live across a branch and pushed all three head kernels into scratch.)
 template <uint32_t D>
-__device__ __forceinline__ void encode8_tiled(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t interp,
+__device__ __forceinline__ bool encode8_tiled(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t interp,
                                               const float (&x)[D], float (&f)[16]) {
     static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
 #ifndef GF_TILED_LB3
@@ -223,11 +224,11 @@ __device__ __forceinline__ void encode8_tiled(const float* __restrict__ table, c
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
     const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
+    bool wrapped = false;      // some pair of this lane sits on the last row of a wrapped level: the caller redoes the lookup corner by corner
 #pragma unroll
     for (int b = 0; b < 8 / LB; b++) {
         RowPair v[LB][NP];
         float pw[LB][D];
-        uint32_t wrap = 0;     // bit k * NP + p: pair p of level k sits on the last row of a wrapped level
 #pragma unroll
         for (int k = 0; k < LB; k++) {
             const int l = b * LB + k;
@@ -255,27 +256,12 @@ __device__ __forceinline__ void encode8_tiled(const float* __restrict__ table, c
                 uint32_t i0 = yy[p & 1];
                 if constexpr (D == 3) i0 += zz[p >> 1];
                 i0 &= mask;
-                wrap |= (i0 == mask ? 1u : 0u) << (k * NP + p);
+                wrapped |= i0 == mask;
                 const uint32_t ild = i0 < last ? i0 : last;      // (dense levels: mask is all ones, nothing changes)
                 v[k][p] = *reinterpret_cast<const RowPair*>(rows + row_off + ild);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef GF_EXP_NOWRAP
-        if (__builtin_expect(__any(wrap != 0u), 0)) {
-#pragma unroll
-            for (int k = 0; k < LB; k++) {
-                const uint32_t row_off = reinterpret_cast<const uint32_t*>(meta8)[8 * (b * LB + k) + 4];
-#pragma unroll
-                for (int p = 0; p < NP; p++)
-                    if ((wrap >> (k * NP + p)) & 1u) {
-                        const float2 r0 = rows[row_off];
-                        v[k][p].x0 = v[k][p].x1; v[k][p].y0 = v[k][p].y1;
-                        v[k][p].x1 = r0.x; v[k][p].y1 = r0.y;
-                    }
-            }
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < LB; k++) {
             const int l = b * LB + k;
@@ -297,6 +283,7 @@ __device__ __forceinline__ void encode8_tiled(const float* __restrict__ table, c
             f[l * 2 + 1] = oob ? 0.0f : o1;
         }
     }
+    return wrapped;
 }
 
 // Eight consecutive levels at one point x (already mapped to [0,1]) -> f[16] = [level][channel].
@@ -310,15 +297,11 @@ __device__ __forceinline__ void encode8(const float* __restrict__ table, const L
     static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
     constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
     constexpr int LB = D == 3 ? 4 : 8, NC = 1 << D;
-#ifdef GF_TILED_ONLY
-    encode8_tiled<D>(table, meta8, interp, x, f);
-    return;
-#endif
 #ifndef GF_NO_PAIRED_ROWS
-    if (gridtype == 1u) {   // wave-uniform (a kernel argument): tiled grids take the paired-row form
-        encode8_tiled<D>(table, meta8, interp, x, f);
-        return;
-    }
+    // wave-uniform (gridtype is a kernel argument): tiled grids take the paired-row form; the per-corner form below serves hashed grids and
+    // redoes the rare wave (2-3 % of them at 2^16-row levels) in which some lane's pair wrapped around the end of a level -- same bits for
+    // every other lane, the right rows for that one
+    if (gridtype == 1u && !__any(encode8_tiled<D>(table, meta8, interp, x, f))) return;
 #endif
     bool oob = false;
 #pragma unroll

@@ -502,11 +502,6 @@ def _per_frame_vectors(model, st, cond, poses6=None, ha_branch=False):
     return cond_feat, amb_bias, torso_bias
 
 
-def _check_args(perturb, max_steps):
-    if max_steps > 64:
-        raise NotImplementedError("fused render path: max_steps > 64 is only available with render_impl='ops'")
-
-
 def _perturb_noise(perturb, perturb_noise, N, dev):
     """perturb=True at inference (renderer.py:338-342): U[0,1) per ray for the first march iteration -- the caller's draws, or fresh ones."""
     if not perturb:
@@ -521,7 +516,6 @@ def _perturb_noise(perturb, perturb_noise, N, dev):
 
 def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh, perturb_noise=None):
     """NeRFRenderer.render (renderer.py:263-367, inference) on the fused path."""
-    _check_args(perturb, max_steps)
     with torch.no_grad():
         st = get_state(model)
         prefix = rays_o.shape[:-1]
@@ -545,7 +539,6 @@ def render_head_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, b
 def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, bg_color, perturb, max_steps, T_thresh,
                        return_deform=True, perturb_noise=None):
     """RADNeRFTorso.render (radnerf_torso.py:86-198, inference) on the fused path."""
-    _check_args(perturb, max_steps)
     with torch.no_grad():
         st = get_state(model)
         prefix = rays_o.shape[:-1]

@@ -43,7 +43,7 @@ def _mark_written(*tensors):
 
 class NeRFRenderer(nn.Module):
     #: execution strategy of render(): "fused", "ops", or "auto" = fused whenever the call is inside what the fused
-    #: kernels cover (max_steps <= 64, the GeneFace layer shapes), op-by-op otherwise.  Both run on
+    #: kernels cover (max_steps <= 1024 -- the reference's default and its viewer's maximum --, the GeneFace layer shapes), op-by-op otherwise.  Both run on
     #: the GPU through libgeneface_hip.so; neither has a CPU fallback.
     render_impl = "auto"
     #: arithmetic of the fused head field: "fp32" (strict parity: everything in fp32, the offline inference path of the reference) or
@@ -216,7 +216,7 @@ class NeRFRenderer(nn.Module):
     def _pick_impl(self, impl, perturb, max_steps):
         if impl != "auto":
             return impl
-        if max_steps > 64:
+        if max_steps > 1024:      # beyond the reference's own default and viewer maximum (renderer.py:263, radnerf_gui.py:466-471)
             return "ops"
         ok = getattr(self, "_fused_arch_ok", None)
         if ok is None:

@@ -369,15 +369,56 @@ def test_edge_empty_occupancy():
 
 
 def test_edge_full_occupancy_and_long_budgets():
-    """Every cell occupied (rays march from the box entry, budgets are what the schedule gives them) and the three budget
-    regimes of the fused path: max_steps below, at and above the May value, up to the fused limit of 64."""
+    """Every cell occupied (rays march from the box entry, budgets are what the schedule gives them) and the budget regimes of the fused
+    path: max_steps below, at and above the May value, through the old fused limit of 64 to the reference's own default of 1024
+    (renderer.py:263; the top of its viewer's slider, radnerf_gui.py:466-471) -- terminal indices beyond the LDS histogram go to the control
+    block directly, phase 1 replays the schedule from an LDS copy.  With dt_gamma = 1/256 and with dt_gamma = 0 (fixed step 2 sqrt(3) /
+    max_steps: every ray takes hundreds of samples at max_steps = 1024)."""
+    from geneface_amd.fused import frame_stats
     hp, sd = model_fixture(False)
     sd = dict(sd, density_bitfield=torch.full_like(sd["density_bitfield"], 255))
     fi = frame_inputs(sequence(4, 48, 48), 2)
-    for ms in (4, 16, 64):
-        ref, outs = _render_both(hp, sd, fi, torso=False, max_steps=ms)
-        for out in outs.values():
+    for ms, dtg in ((4, None), (16, None), (64, None), (65, None), (128, None), (256, 0.0), (1024, None), (1024, 0.0)):
+        over = dict(max_steps=ms) if dtg is None else dict(max_steps=ms, dt_gamma=dtg)
+        hp_o = dict(hp, **over)
+        trace = []
+        ref = R.render(sd, hp_o, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=False, trace=trace)
+        for impl in ("ops", "fused"):
+            from geneface_amd.radnerf import RADNeRF
+            m = RADNeRF(hp_o)
+            m.load_state_dict(sd, strict=True)
+            m.render_impl = impl
+            m = m.to(DEV).eval()
+            assert m._pick_impl("auto", False, ms) == "fused"
+            out = render_gpu(m, hp_o, fi)
             check(out, ref, False)
+            if impl == "fused":      # the schedule replay arrives at the reference's iteration list and total budget, whatever the histogram's home
+                fs = frame_stats(m.last_ctrl, 48 * 48, ms)
+                assert [n for _, n in fs["schedule"]] == [t["n_step"] for t in trace], (ms, dtg)
+                assert fs["budget"] == fs["budget_device"] == sum(t["n_step"] for t in trace)
+
+
+def test_long_budget_occupancy_fixture_and_the_split_tier():
+    """max_steps = 1024 on the analytic head (most rays end by leaving the occupied region after a few dozen samples, some terminate on
+    transmittance): head+torso 96 x 96 against the oracle, fp32 and split tiers, and the pose-mode frame loop."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd = model_fixture(True)
+    for dtg in (1.0 / 256, 0.0):
+        hp_o = dict(hp, max_steps=1024, dt_gamma=dtg)
+        seq = sequence(4, 96, 96)
+        fi = frame_inputs(seq, 1)
+        ref = R.render(sd, hp_o, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True)
+        for precision in ("fp32", "split"):
+            from geneface_amd.radnerf_torso import RADNeRFTorso
+            m = RADNeRFTorso(hp_o)
+            m.load_state_dict(sd, strict=True)
+            m.render_impl, m.render_precision = "fused", precision
+            m = m.to(DEV).eval()
+            check(render_gpu(m, hp_o, fi), ref, True)
+            pipe = FramePipeline(m, hp_o, seq, DEV, impl="fused")
+            frame = pipe.render_frame(1)
+            pipe.wait()
+            check_u8(frame, (ref["rgb_map"] * 255).view(96, 96, 3).to(torch.uint8), rerender=lambda: oracle_u8(sd, hp_o, pipe_inputs(pipe, 1), True))
 
 
 @pytest.mark.parametrize("H,W", [(1, 1), (1, 3), (37, 50), (5, 129)])

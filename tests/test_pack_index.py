@@ -186,3 +186,55 @@ def test_fused_lookup_index_expression_matches_the_reference_rule(D, gridtype):
             for corner in range(1 << D):
                 pos = [int(g[d]) + ((corner >> d) & 1) for d in range(D)]
                 assert _unified_row(meta, pos) == _reference_row(gridtype, size, res, pos), (D, gridtype, res, pos)
+
+
+# Round 4: on TILED grids encode8 fetches the two x-corners of a cell as ONE 16-byte read (csrc/grid_core.hpp::encode8_tiled): the pair of
+# (y, z) corner p starts at row i0 = (g_x + y * s1 + z * s2) & mask and its second row is i0 + 1 -- except on the last row of a wrapped
+# level (i0 == mask), where the read is moved to rows (mask - 1, mask) and the lane reports `wrapped` (the wave then redoes the lookup
+# corner by corner).  Restated here: the rows the pair read returns are the reference's rows whenever `wrapped` is false, the wrap case is
+# exactly i0 == mask, and no read ever leaves its level.
+def _paired_rows(meta, g, p):
+    s1, s2, mask, _ = meta
+    i0 = int(g[0]) + int(g[1] + (p & 1)) * s1
+    if len(g) == 3:
+        i0 += int(g[2] + (p >> 1)) * s2
+    i0 &= mask
+    ild = min(i0, (mask - 1) & 0xFFFFFFFF)
+    return (ild, ild + 1), i0 == mask
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_paired_row_reads_of_tiled_grids_match_the_reference_rule(D):
+    rng = np.random.default_rng(40 + D)
+    n_wrapped = 0
+    for res in (16, 23, 31, 43, 59, 81, 112, 154, 213, 294, 406, 561, 774, 1069, 1476, 2048):
+        full = (res + 1) ** D
+        size = min(1 << 16, -(-full // 8) * 8)
+        meta = _level_meta(1, size, res, D)
+        assert meta[3] == 0                                  # no level of a tiled grid hashes
+        pts = rng.integers(0, res, size=(300, D))
+        pts[:4] = [[0] * D, [res - 1] * D, [res - 1, 0, res - 1][:D], [1, res - 1, 0][:D]]
+        if meta[2] != 0xFFFFFFFF:                            # wrapped level: plant cells whose pair base is the level's last row
+            s1, s2, mask, _ = meta
+            planted = 0
+            for gz in (range(res) if D == 3 else [0]):
+                for gy in range(res):
+                    gx = (mask - gy * s1 - gz * s2) % (mask + 1)
+                    if gx < res and planted < 3:
+                        pts[4 + planted] = [gx, gy, gz][:D]
+                        planted += 1
+                if planted >= 3:
+                    break
+        for g in pts:
+            for p in range(1 << (D - 1)):
+                (r0, r1), wrapped = _paired_rows(meta, g, p)
+                assert 0 <= r0 and r1 < size, (res, g, p)    # the 16-byte read stays inside the level (so inside the table)
+                pos0 = [int(g[0]), int(g[1]) + (p & 1)] + ([int(g[2]) + (p >> 1)] if D == 3 else [])
+                pos1 = [pos0[0] + 1] + pos0[1:]
+                want = (_reference_row(1, size, res, pos0), _reference_row(1, size, res, pos1))
+                if wrapped:
+                    n_wrapped += 1
+                    assert want == (size - 1, 0) and (r0, r1) == (size - 2, size - 1)
+                else:
+                    assert (r0, r1) == want, (D, res, g, p)
+    assert n_wrapped > 0
