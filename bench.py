@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=8, help="how many of the parity fixture's frames (PARITY_FRAMES) are compared with the oracle; "
                                                                "the oracle's runs on them are also the bounded cpu_baseline sample")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-block (SURVEY 8f-2: ms per step, gradient parity, the reference kernels' rate)")
     ap.add_argument("--rank-parity", action="store_true", help="run the N > 1 line's every-rank parity check (one common frame per rank against one oracle "
                                                                 "frame) at N = 1 as well (the GPU test of the 1-rank RCCL path uses it)")
     ap.add_argument("--no-grazing", action="store_true", help="skip the grazing-ray probe (two more oracle frames per parity frame)")
@@ -543,6 +544,9 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
                     line["head_only"] = head_only_leg(args, job, two)
                 if args.precision == "fp32":
                     line["split_tier"] = split_tier_leg(args, job, hp, torso, seq, sd, pframes if parity else [], cache)
+                if not args.no_train:
+                    torch.cuda.synchronize()
+                    line["train_step"] = train_step_leg(args, job)
         line["cpu_baseline"] = cpu
         if emit is not None:
             emit(line)
@@ -626,6 +630,77 @@ def head_only_leg(args, job, parity_frames=()):
         dt, dts = timed_loop(job, pipe, args.warmup, args.steps, args)
     return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "repeats": len(dts), "parity": parity,
             "workload": f"May lm3d_radnerf head-only {args.size}x{args.size}, {args.steps} frames (BASELINE.json configs[1])"}
+
+
+def train_step_leg(args, job):
+    """SURVEY 8f-2 beside the headline, outside `value`: the training step of the RAD-NeRF head (tasks/radnerfs/radnerf.py:185-216: grid update
+    every 16 steps, render in training mode on 65 536 random rays, loss, backward, Adam) -- ms per step of the product (tools/bench_train.py
+    in a fresh process), the same host code over the reference's own kernels built for gfx950 (tests/train_rate_reference.py; oracle/_ref,
+    test infrastructure, only when present), and the parity of ONE step's gradients against the oracle's autograd on the CPU."""
+    import subprocess
+
+    def run(script):
+        try:
+            r = subprocess.run([sys.executable, script, "--steps", "24", "--warmup", "16"], capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout"}
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or "no output")[-400:]}
+    prod = run(os.path.join(ROOT, "tools", "bench_train.py"))
+    out = {"ms_per_step": prod.get("ms_per_step"), "steps_per_s": prod.get("value"), "hours_for_250k_steps": prod.get("hours_for_250k_steps"),
+           "workload": prod.get("metric"), "points_last_step": prod.get("points_last_step"), "error": prod.get("error"),
+           "reference_published": prod.get("reference_published"),
+           "note": "secondary measurement, never part of `value`; fused Adam, fp32; synthetic fixture (the rate, not the loss, is what is measured)"}
+    from oracle import ref_kernels
+    if ref_kernels.available("fast"):
+        refk = run(os.path.join(ROOT, "tests", "train_rate_reference.py"))
+        out["reference_kernels_same_host_code"] = {"ms_per_step": refk.get("ms_per_step"), "steps_per_s": refk.get("value"), "error": refk.get("error"),
+                                                   "what": "oracle/_ref: the reference's four .cu extensions compiled for gfx950, swapped in under the same Python"}
+        if refk.get("ms_per_step") and prod.get("ms_per_step"):
+            out["speedup_vs_reference_kernels"] = refk["ms_per_step"] / prod["ms_per_step"]
+    if not args.no_cpu_baseline:
+        out["gradient_parity"] = train_gradient_parity(job)
+    return out
+
+
+def train_gradient_parity(job, size=40):
+    """One training step (loss of tests/test_oracle_train.py) on a size x size frame: every parameter gradient of the product's training branch
+    against the oracle's differentiable restatement on the CPU -- relative L2 error per tensor, the worst of them reported."""
+    import torch
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf import RADNeRF
+    from oracle import radnerf_ref as R
+    hp = HP.may_hparams(False)
+    sd = S.make_state_dict(hp, False)
+    seq = S.make_sequence(4, size, size, hp)
+    pose = torch.from_numpy(seq["poses"][2:3])
+    ro, rd = R.get_rays(pose, seq["intrinsics"], size, size)
+    cond, bgc, bg = torch.from_numpy(seq["cond_wins"][2]), R.get_bg_coords(size, size), torch.from_numpy(seq["bg_img"]).view(1, -1, 3)
+    target = torch.rand(1, size * size, 3, generator=torch.Generator().manual_seed(8))
+    loss = lambda o, t: ((o["rgb_map"] - t) ** 2).mean() + 1e-3 * o["weights_sum"].mean() + 1e-4 * o["ambient"].mean()
+    sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith(("aabb", "density")) else v) for k, v in sd.items()}
+    ref = R.render_train(sd_g, hp, ro.contiguous(), rd.contiguous(), cond, bgc, R.convert_poses(pose), bg, torso=False)
+    loss(ref, target).backward()
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(job.dev).train()
+    to = lambda t: t.to(job.dev)
+    out = model.render(to(ro.contiguous()), to(rd.contiguous()), to(cond), to(bgc), None, index=0, staged=False, bg_color=to(bg), perturb=False,
+                       force_all_rays=True, **hp)
+    loss(out, to(target)).backward()
+    worst, worst_name, n = 0.0, None, 0
+    for name, p in model.named_parameters():
+        gr = sd_g[name].grad
+        if gr is None or p.grad is None:
+            continue
+        l2 = float((p.grad.cpu() - gr).double().norm() / gr.double().norm().clamp(min=1e-20))
+        n += 1
+        if l2 > worst:
+            worst, worst_name = l2, name
+    return {"tensors": n, "worst_relative_l2": worst, "worst_tensor": worst_name, "tolerance": 1e-2,
+            "rgb_max_abs": float((out["rgb_map"].detach().cpu() - ref["rgb_map"].detach()).abs().max()),
+            "what": f"one step on {size}x{size} rays, product training branch (fused field forward / hand-written backward) vs oracle/radnerf_ref.render_train autograd (CPU)"}
 
 
 def replica_checksum(model):

@@ -3,9 +3,10 @@
 
 dtype: the reference dispatches on the table's scalar type (AT_DISPATCH_FLOATING_TYPES_AND_HALF) and its wrapper hands the backend HALF
 tables, outputs, dy_dx and gradients whenever autocast is on (grid.py:41-44, the May config's `amp: true` on the training and viewer
-paths); inputs stay float.  The library computes in fp32 only, so half tensors are converted at this seam: same call, same in-place
+paths); inputs stay float.  The library computes in fp32: a half TABLE is read as it is (gf_grid_encode_forward_f16 widens each row on load;
+the backward never reads the table), the B-sized half outputs / dy_dx / gradients are converted at this seam: same call, same in-place
 semantics, fp32 arithmetic inside (at least as accurate as the half kernels; the table gradient in particular is accumulated in fp32
-instead of with half atomics).
+instead of with half atomics, then added into the caller's half buffer once).
 """
 import torch
 
@@ -24,10 +25,18 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, 
     half = embeddings.dtype != _F
     out = torch.empty(outputs.shape, dtype=_F, device=outputs.device) if half else outputs
     dx = (torch.empty(dy_dx.shape, dtype=_F, device=dy_dx.device) if half else dy_dx) if dy_dx is not None else None
-    x, e = _f32(inputs).contiguous(), _f32(embeddings)     # named: a converted copy must outlive the launch
-    check(lib().gf_grid_encode_forward(ptr(x, _F), ptr(e, _F), ptr(offsets, torch.int32), ptr(out, _F),
-                                       B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True), gridtype, int(bool(align_corners)), interp,
-                                       current_stream(inputs.device)))
+    x = _f32(inputs).contiguous()     # named: a converted copy must outlive the launch
+    if half and C in (2, 4, 8):
+        # the half table is read as it is (gf_grid_encode_forward_f16: rows widened on load) -- until round 4 the whole table (6.9 MB for the
+        # position grid) was converted to fp32 on every call, on top of the reference's own fp32 -> half cast of it (grid.py:43)
+        check(lib().gf_grid_encode_forward_f16(ptr(x, _F), ptr(embeddings, torch.float16), ptr(offsets, torch.int32), ptr(out, _F),
+                                               B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True), gridtype, int(bool(align_corners)), interp,
+                                               current_stream(inputs.device)))
+    else:
+        e = _f32(embeddings)
+        check(lib().gf_grid_encode_forward(ptr(x, _F), ptr(e, _F), ptr(offsets, torch.int32), ptr(out, _F),
+                                           B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True), gridtype, int(bool(align_corners)), interp,
+                                           current_stream(inputs.device)))
     if half:
         outputs.copy_(out)
         if dy_dx is not None:
@@ -39,8 +48,10 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     g_emb = torch.zeros(grad_embeddings.shape, dtype=_F, device=grad_embeddings.device) if half else grad_embeddings
     g_in = (torch.zeros(grad_inputs.shape, dtype=_F, device=grad_inputs.device) if grad_inputs.dtype != _F else grad_inputs) \
         if grad_inputs is not None else None
-    g, x, e, dx = _f32(grad).contiguous(), _f32(inputs).contiguous(), _f32(embeddings), _f32(dy_dx)
-    check(lib().gf_grid_encode_backward(ptr(g, _F), ptr(x, _F), ptr(e, _F),
+    g, x, dx = _f32(grad).contiguous(), _f32(inputs).contiguous(), _f32(dy_dx)
+    # (the table gradient does not depend on the table's values -- gridencoder.cu:248-341 never reads `grid` -- so the half table the
+    # reference saved is not converted, or even passed: the C entry ignores that argument)
+    check(lib().gf_grid_encode_backward(ptr(g, _F), ptr(x, _F), None,
                                         ptr(offsets, torch.int32), ptr(g_emb, _F), B, D, C, L, float(S), H, ptr(dx, _F, allow_none=True),
                                         ptr(g_in, _F, allow_none=True), gridtype, int(bool(align_corners)), interp, current_stream(grad.device)))
     if half:

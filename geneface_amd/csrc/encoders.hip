@@ -14,8 +14,8 @@ constexpr int kBlock = 256;
 
 // LAYOUT_BLC == false : outputs [L,B,C] (what the pybind seam promises, grid.py:47)
 // LAYOUT_BLC == true  : outputs [B,L*C] directly (what GridEncoder.forward returns after its permute)
-template <uint32_t D, uint32_t C, bool LAYOUT_BLC>
-__global__ void __launch_bounds__(kBlock) k_grid_encode(const float* __restrict__ inputs, const float* __restrict__ embeddings,
+template <uint32_t D, uint32_t C, bool LAYOUT_BLC, class T = float>
+__global__ void __launch_bounds__(kBlock) k_grid_encode(const float* __restrict__ inputs, const T* __restrict__ embeddings,
                                                         const int* __restrict__ offsets, float* __restrict__ outputs, uint32_t B,
                                                         gf::GridLevels lv, float* __restrict__ dy_dx, uint32_t gridtype,
                                                         bool align_corners, uint32_t interp) {
@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(kBlock) k_grid_encode(const float* __restrict_
     } else {
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-        gf::grid_level_lookup<D, C>(embeddings + (size_t)off * C, hashmap_size, lv.scale[level], lv.resolution[level], gridtype,
-                                    align_corners, interp, x, res, dd);
+        gf::grid_level_lookup<D, C, T>(embeddings + (size_t)off * C, hashmap_size, lv.scale[level], lv.resolution[level], gridtype,
+                                       align_corners, interp, x, res, dd);
     }
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) out[c] = res[c];
@@ -79,6 +79,20 @@ int dispatch_c(uint32_t C, bool blc, const float* inputs, const float* embedding
         case 8: return launch_grid<D, 8>(blc, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
         default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
     }
+}
+
+// Half TABLES (binary16 bit patterns), fp32 everything else: C in {2, 4, 8} as the reference's wrapper guarantees (grid.py:43: C % 2 == 0).
+template <uint32_t D>
+int dispatch_c_f16(uint32_t C, const float* inputs, const _Float16* embeddings, const int* offsets, float* outputs, uint32_t B,
+                   const gf::GridLevels& lv, float* dy_dx, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s) {
+    const dim3 grid(gf_div_up(B, (uint32_t)kBlock), lv.L), block(kBlock);
+    switch (C) {
+        case 2: hipLaunchKernelGGL((k_grid_encode<D, 2, false, _Float16>), grid, block, 0, s, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp); break;
+        case 4: hipLaunchKernelGGL((k_grid_encode<D, 4, false, _Float16>), grid, block, 0, s, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp); break;
+        case 8: hipLaunchKernelGGL((k_grid_encode<D, 8, false, _Float16>), grid, block, 0, s, inputs, embeddings, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp); break;
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding (half tables): C must be 2, 4, or 8.");
+    }
+    return gf_check_launch("grid_encode_forward_f16");
 }
 
 int grid_encode_any(bool blc, const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
@@ -496,6 +510,27 @@ GF_EXPORT int gf_grid_encode_forward(const float* inputs, const float* embedding
                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
                                      int align_corners, uint32_t interp, void* stream) {
     return grid_encode_any(false, inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, stream);
+}
+
+GF_EXPORT int gf_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings_f16, const int32_t* offsets, float* outputs, uint32_t B,
+                                         uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
+                                         uint32_t interp, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!inputs || !embeddings_f16 || !offsets || !outputs) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward_f16: null pointer");
+    if (gridtype > 1 || interp > 1) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward_f16: gridtype/interp must be 0 or 1");
+    if ((uintptr_t)embeddings_f16 & (2u * C - 1u) & 15u) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward_f16: embeddings misaligned");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_forward_f16: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    const _Float16* e = reinterpret_cast<const _Float16*>(embeddings_f16);
+    switch (D) {
+        case 2: return dispatch_c_f16<2>(C, inputs, e, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 3: return dispatch_c_f16<3>(C, inputs, e, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 4: return dispatch_c_f16<4>(C, inputs, e, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        case 5: return dispatch_c_f16<5>(C, inputs, e, offsets, outputs, B, lv, dy_dx, gridtype, ac, interp, s);
+        default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: D must be 2, 3, 4, or 5.");
+    }
 }
 
 GF_EXPORT int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,

@@ -62,6 +62,18 @@ template <> struct VecOf<1> { using type = float; };
 template <> struct VecOf<2> { using type = float2; };
 template <> struct VecOf<4> { using type = float4; };
 
+// Row of a binary16 table (the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF branch, gridencoder.cu:375-398: under autocast its wrapper
+// hands the backend half tables, grid.py:41-44), widened to fp32: the arithmetic stays fp32 (the reference's half kernel rounds its running
+// sum to half after every corner).
+template <uint32_t C>
+__device__ __forceinline__ void load_row(const _Float16* __restrict__ table, uint32_t row, float (&v)[C]) {
+    static_assert(C == 2 || C == 4 || C == 8, "half tables: C must be even (grid.py:43)");
+    typedef _Float16 hvec __attribute__((ext_vector_type(C)));
+    const hvec h = reinterpret_cast<const hvec*>(table)[row];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) v[c] = (float)h[c];
+}
+
 template <uint32_t C>
 __device__ __forceinline__ void load_row(const float* __restrict__ table, uint32_t row, float (&v)[C]) {
     if constexpr (C == 8) {
@@ -81,8 +93,8 @@ __device__ __forceinline__ void load_row(const float* __restrict__ table, uint32
 
 // Interpolate one level at one point.  x[] in [0,1] (caller has already ruled out-of-range points out).
 // When dy_dx != nullptr it receives D*C derivatives laid out [d][c].
-template <uint32_t D, uint32_t C>
-__device__ __forceinline__ void grid_level_lookup(const float* __restrict__ table, uint32_t hashmap_size, float scale,
+template <uint32_t D, uint32_t C, class T = float>
+__device__ __forceinline__ void grid_level_lookup(const T* __restrict__ table, uint32_t hashmap_size, float scale,
                                                   uint32_t resolution, uint32_t gridtype, bool align_corners,
                                                   uint32_t interp, const float (&x)[D], float (&out)[C], float* dy_dx) {
     float pos[D], pos_deriv[D];

@@ -100,7 +100,13 @@ int gf_grid_encode_backward(const float* grad, const float* inputs, const float*
  * normalised total-variation gradient of the table around the lattice node every input [B,D] in [0,1] falls on, times weight/(2D). */
 int gf_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets, float weight, uint32_t B,
                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream);
-/* same arithmetic, outputs laid out [B, L*C] (what GridEncoder.forward returns after grid.py:57's permute). */
+/* The same forward for a HALF table (binary16 bit patterns): the branch the reference reaches through AT_DISPATCH_FLOATING_TYPES_AND_HALF
+ * (gridencoder.cu:375-398) when autocast is on -- its wrapper casts the table to half on every call (grid.py:41-44).  Rows are widened to fp32
+ * on load; inputs, arithmetic, outputs and dy_dx stay fp32 (the caller narrows them if its buffers are half).  C must be 2, 4 or 8. */
+int gf_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings_f16, const int32_t* offsets, float* outputs, uint32_t B,
+                               uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
+                               uint32_t interp, void* stream);
+/* same arithmetic as gf_grid_encode_forward, outputs laid out [B, L*C] (what GridEncoder.forward returns after grid.py:57's permute). */
 int gf_grid_encode_forward_blc(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs, uint32_t B,
                                uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype,
                                int align_corners, uint32_t interp, void* stream);

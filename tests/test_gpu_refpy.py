@@ -155,3 +155,42 @@ def test_reference_training_step_under_autocast_over_compat(ref):
     scaler.step(opt)
     scaler.update()
     assert scaler.get_scale() >= 1024.0
+
+
+def test_autocast_step_costs_what_the_fp32_step_costs(ref):
+    """Seam 1 under autocast: the compat grid encoder reads the half table the reference's wrapper hands it as it is (gf_grid_encode_forward_f16)
+    and the backward no longer touches the table at all -- until round 4 every call converted the whole 6.9 MB table to fp32 and back.
+    The reference's training step (its Python, its autograd wrappers) under fp16 autocast against the same step in fp32, same rays."""
+    import time
+    from test_oracle_train import _loss
+    model, hp, sd = ref(False, train=True)
+    fi = frame_inputs(sequence(4, 64, 64), 2)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+
+    def step(amp):
+        opt.zero_grad(set_to_none=True)
+        if amp:
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = _loss(_render(model, hp, fi), target)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            _loss(_render(model, hp, fi), target).backward()
+            opt.step()
+
+    def timed(amp, n=8):
+        for _ in range(3):
+            step(amp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(amp)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    ms32, ms16 = timed(False), timed(True)
+    ms32b = timed(False)
+    print(f"reference training step over compat, 64x64 rays: fp32 {min(ms32, ms32b):.2f} ms, fp16 autocast {ms16:.2f} ms ({ms16 / min(ms32, ms32b):.2f}x)")
+    assert ms16 < 1.25 * max(ms32, ms32b)
