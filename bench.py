@@ -33,7 +33,7 @@ FLOP_PER_TORSO_PIXEL = 32_768    # 2*(104*64+64*64+64*2 + 136*32
 BYTES_PER_HEAD_SAMPLE = 1_536    # fp32 table gathers: 16 levels * (8 + 4 corners) * 8 B
 BYTES_PER_TORSO_PIXEL = 512
 BYTES_PER_RAY = 56
-INIT_BYTES_PER_RAY, INIT_BYTES_PER_HIT = 28, 24   # k_frame_init: near, far, zeroed accumulators per ray; direction, clock, far bound, list entry per hit ray
+INIT_BYTES_PER_RAY, INIT_BYTES_PER_HIT = 28, 24   # k_frame_init (NOTES.md 4.1): near, far, zeroed accumulators per ray; direction, clock, far bound, list entry per hit ray
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense MFMA peak for f32 inputs
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16 / FP16 MFMA peak (32x32x16); the split tier spends three f16 MFMAs per fp32 product term set
 PEAK_HBM_GBS = 8000.0
@@ -524,7 +524,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             line["msamples_per_s"] = roofline["samples_per_frame"] * (K / dt) * world / 1e6
         if roofline and args.precision == "fp32" and roofline.get("samples_per_frame") and world == 1:
             # The same algorithmic FLOPs priced against the WHOLE frame time of the timed region (several frames in flight: the uneven end of one
-            # launch -- 12 % of the kernel alone, DESIGN.md 4.2 -- is filled by the next frame's workgroups, but the frame also pays for the
+            # launch -- 12 % of the kernel alone, NOTES.md 4.2 -- is filled by the next frame's workgroups, but the frame also pays for the
             # small kernels).  A lower bound of what the head kernel sustains in the pipelined product configuration.
             tf = roofline["samples_per_frame"] * FLOP_PER_HEAD_SAMPLE * (K / dt) / 1e12
             roofline["pipelined"] = {"achieved": tf, "frac": tf / roofline["peak"], "unit": roofline["unit"],
@@ -588,7 +588,7 @@ def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_frames, what, radius=No
 
 def split_tier_leg(args, job, hp, torso, seq, sd, parity_frames, cache):
     """Beside the headline (which stays exact fp32): the same workload on the split tier -- fp32 VALUES as two-term f16 splits on the f16
-    matrix pipe, held to the same strict tolerance.  `python bench.py --precision split` prints its full line.  Parity on
+    matrix pipe, held to the same strict tolerance (NOTES.md 4.8).  `python bench.py --precision split` prints its full line.  Parity on
     the same fixture frames as the headline (the oracle's frames are reused: the inputs are the same bits)."""
     import torch
     from geneface_amd import synthetic as S

@@ -22,7 +22,7 @@ def _runtime_is_up():
 def _more_hardware_queues():
     """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The frame pipeline keeps several
     frames in flight on side streams next to the copy and default streams; with the default, a fourth frame in flight shares a hardware queue
-    with something else and costs 5 % instead of gaining 2.5 %.  The variable is read when the runtime starts, so it is
+    with something else and costs 5 % instead of gaining 2.5 % (NOTES.md section 5).  The variable is read when the runtime starts, so it is
     only set here if nobody has set it and the process has not opened the GPU yet (importing torch alone does not start the runtime).
     An embedding application that does not want its environment touched sets GENEFACE_AMD_KEEP_ENV=1 (or GPU_MAX_HW_QUEUES itself): the
     pipeline then keeps three frames in flight on the runtime's default queues."""

@@ -25,7 +25,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch=
 # EVERY translation unit is built WITHOUT the SLP vectoriser, i.e. without packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 /
 # v_pk_add_f32).  In k_head_phase<true> the low half of one v_pk_fma_f32 of the 2-D grid lookup -- the one fed by a broadcast-form
 # v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,1] -- intermittently lost its product in lanes 32..63 whenever two workgroups shared a CU
-# (tools/fast_diag.py).  The mechanism is not established, so since round 3 the instruction class is banned from the whole
+# (NOTES.md 4.7, tools/fast_diag.py).  The mechanism is not established, so since round 3 the instruction class is banned from the whole
 # library, not just from the kernel it was caught in (encoders.hip's k_encode8<2> held two instances of exactly that pair):
 # tests/test_build_invariants.py disassembles every code object and asserts the count is zero.  Scalar FMAs compute the same values (the
 # packed form was only ever two independent FMAs); measured cost: head fp32 719 vs 717 fps, fast tier 1890 vs 1845 fps (round 2, A/B on

@@ -187,7 +187,7 @@ __device__ __forceinline__ float4 load_group(const char* __restrict__ Ws, uint32
 // The stream is consumed strictly in order (frame.hpp: G_AMB1 .. G_COL1G), so a few register quads form a FIFO that runs kAhead groups
 // (of 16 MFMAs = 1 024 cycles with four sample tiles) ahead of the MFMAs, across layer boundaries and barriers: q[g % kAhead] holds group g
 // from the moment group g - kAhead has been issued.  Three ahead in the frame kernels; two in the training kernels, which need the four
-// registers more than the slack (with three they spill, and a launch that uses scratch at all pays for it: DESIGN.md 4.7).
+// registers more than the slack (with three they spill, and a launch that uses scratch at all pays for it: NOTES.md 4.7).
 template <int A>
 struct WPipeT { static constexpr int kAhead = A; float4 q[A]; };
 constexpr int kWAhead = 3, kWAheadTrain = 2;
@@ -1281,7 +1281,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
 #endif
     if ((uint32_t)blockIdx.x * pool_cap >= limit) return;  // not even one refill's worth of work for this workgroup
     // the three loop-invariant scalars live in LDS from here on (s.misc[13..15]): with ~100 SGPRs already parked in VGPR lanes the allocator
-    // put them into scratch instead, and a launch that touches scratch at all pays for it
+    // put them into scratch instead, and a launch that touches scratch at all pays for it (NOTES.md 4.7)
 #ifdef GF_DIAG
     if (a.poison) {   // any read of LDS this workgroup has not written itself now returns NaN (fp32 and f16 views alike)
         __syncthreads();

@@ -71,7 +71,7 @@ class FramePipeline:
         self.intrinsics = [float(v) for v in seq["intrinsics"]]
         self.bg = torch.from_numpy(np.ascontiguousarray(seq["bg_img"])).float().view(1, -1, 3).to(dev)
         self.bg_coords = utils.get_bg_coords(self.H, self.W, dev)
-        # frames enqueued concurrently (streams, frame slots, host buffers).  Measured on MI355X: the strict fp32 head
+        # frames enqueued concurrently (streams, frame slots, host buffers).  Measured on MI355X (NOTES.md section 5): the strict fp32 head
         # kernel's persistent grid drains slowly, the next frames' workgroups fill the CUs it leaves: 2 / 3 in flight = 690 / 723 fps, and a
         # fourth helps (746) only when it gets a hardware queue of its own (GPU_MAX_HW_QUEUES >= 8, which the package sets by default when it
         # is imported before the HIP runtime starts; with the runtime's default of 4 queues four in flight give 685).  Fast tier: 3 (1 845 ->

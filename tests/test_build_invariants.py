@@ -1,8 +1,8 @@
 """CPU: properties of the BUILT device code that the design relies on, read from the code objects (tools/kernel_resources.py).
 
-* no packed-FP32 VALU instruction anywhere in the library (a v_pk_mul_f32 -> v_pk_fma_f32 pair lost a term when two
+* no packed-FP32 VALU instruction anywhere in the library (NOTES.md 4.7: a v_pk_mul_f32 -> v_pk_fma_f32 pair lost a term when two
   workgroups shared a CU; the instruction class is banned, not just the one kernel it was caught in);
-* no kernel uses scratch (a launch that touches scratch at all costs ~45 us more) and none spills VGPRs;
+* no kernel uses scratch (a launch that touches scratch at all costs ~45 us more, NOTES.md 4.7) and none spills VGPRs;
 * the field kernels run on the matrix pipe, the stand-alone ops do not pretend to.
 """
 import os

@@ -797,7 +797,7 @@ def test_pipeline_depth_follows_the_scene(thin, monkeypatch):
 def test_full_size_frames_are_reproducible(precision):
     """Run-to-run reproducibility where it was once lost: at 512x512 the persistent head grid puts two workgroups on every CU (a 160x160
     frame leaves each CU with one, which is why the test above never saw it).  The fast tier's 2-D grid lookup then dropped one corner of
-    its last level now and then -- a packed-FP32 instruction pair the compiler had formed (tools/fast_diag.py pins it sample
+    its last level now and then -- a packed-FP32 instruction pair the compiler had formed (NOTES.md 4.7; tools/fast_diag.py pins it sample
     by sample) -- in about half of all frames rendered ALONE.  40 renders alone and 120 with three in flight must be identical bytes."""
     from geneface_amd.infer import FramePipeline
     hp, sd, model = build(True, "fused")

@@ -1,5 +1,5 @@
 // Does the SHAPE of the load -- matrix-pipe bursts between barriers, with gather / VALU / LDS pieces in between -- hold the shader clock
-// below what a steady MFMA stream gets?  (k_head_phase runs at 2.13 GHz, tools/mfma_probe.hip at 2.40 GHz.)
+// below what a steady MFMA stream gets?  (NOTES.md 4.2: k_head_phase runs at 2.13 GHz, tools/mfma_probe.hip at 2.40 GHz.)
 // Two workgroups per CU (68 KB of LDS each), free running.  Per iteration: an MFMA burst of `groups` x 16 v_mfma_f32_32x32x2_f32, a barrier,
 // a filler piece of `fill` steps, a barrier.  Clock = s_memtime ticks / s_memrealtime (100 MHz) over the workgroup's life.
 //   filler 0 none   1 VALU transcendentals   2 LDS read/write   3 random 8-byte gathers (8 MB table)   4 s_sleep   5 gathers + transcendentals

@@ -5,7 +5,7 @@
 
 For every translation unit: unbundle the gfx950 code object (.hip_fatbin -> clang-offload-bundler), read the kernel descriptors' notes
 (VGPRs, SGPR spills, scratch = private_segment_fixed_size, static LDS) and count the packed-FP32 VALU instructions (v_pk_fma_f32 /
-v_pk_mul_f32 / v_pk_add_f32: DESIGN.md 4.7 -- the library is built without them) and the MFMAs in the disassembly.  No GPU needed.
+v_pk_mul_f32 / v_pk_add_f32: NOTES.md 4.7 -- the library is built without them) and the MFMAs in the disassembly.  No GPU needed.
 tests/test_build_invariants.py asserts on this.
 """
 import glob

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""How much matrix-pipe time could a better schedule of the two co-resident head workgroups recover?  
+"""How much matrix-pipe time could a better schedule of the two co-resident head workgroups recover?  (NOTES.md 4.2)
 
 k_head_phase<false> keeps two 4-wave workgroups on a CU.  Each alternates MFMA segments (80 K matrix-pipe ticks per 128-sample round)
 with scalar pieces (gathers, skinny layers, write-backs, march, composite: ~47 K ticks alone); the pipe idles whenever BOTH are in a

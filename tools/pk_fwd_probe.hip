@@ -1,4 +1,4 @@
-// Stand-alone probe for the instruction pair behind the fast tier's run-to-run deviations:
+// Stand-alone probe for the instruction pair behind the fast tier's run-to-run deviations (NOTES.md 4.7):
 //
 //     v_pk_mul_f32 W, P, Q op_sel:[0,1] op_sel_hi:[0,1]     ; W.lo = W.hi = P.lo * Q.hi   (the compiler's "broadcast" form)
 //     [s_waitcnt vmcnt(k)]

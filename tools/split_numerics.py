@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Numerics study for the split tier's next step (DESIGN.md "what comes next"): which activation rows could be stored hi-ONLY (one f16 per
+"""Numerics study for the split tier's next step (NOTES.md "what comes next"): which activation rows could be stored hi-ONLY (one f16 per
 value instead of the hi + lo' pair) without leaving the strict tolerance?  Hi-only rows halve the write-back conversions of their layer and
 drop one of the three MFMAs of every product term set that reads them.
 
