@@ -529,24 +529,31 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             tf = roofline["samples_per_frame"] * FLOP_PER_HEAD_SAMPLE * (K / dt) / 1e12
             roofline["pipelined"] = {"achieved": tf, "frac": tf / roofline["peak"], "unit": roofline["unit"],
                                      "note": "algorithmic FLOPs per frame x measured fps; `achieved` / `frac` above are the kernel alone, one frame in flight"}
+        def leg(fn, *a, **kw):
+            """A secondary leg must never cost the headline line: its failure is reported in its place."""
+            try:
+                return fn(*a, **kw)
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc(limit=3)[-600:]}
         if real and world == 1:
             if args.png_frames > 0:
-                line["with_png"] = png_leg(pipe, Wm, min(args.png_frames, K))
+                line["with_png"] = leg(png_leg, pipe, Wm, min(args.png_frames, K))
             if not args.no_stress and args.impl == "fused":
                 two = [f for f in (1, 14) if f in pframes] if parity else []
-                line["stress_fixture"] = fixture_leg(args, job, hp, torso, seq, dict(sigma_row_scale=0.02), two,
+                line["stress_fixture"] = leg(fixture_leg, args, job, hp, torso, seq, dict(sigma_row_scale=0.02), two,
                                                      "density row of sigma_net scaled by 0.02 (sigma ~ 1): no ray terminates early, every hit ray marches its full budget")
-                line["heavy_fixture"] = fixture_leg(args, job, hp, torso, None, dict(sigma_row_scale=HEAVY_SIGMA_SCALE), two,
+                line["heavy_fixture"] = leg(fixture_leg, args, job, hp, torso, None, dict(sigma_row_scale=HEAVY_SIGMA_SCALE), two,
                                                     f"camera at radius {HEAVY_RADIUS} instead of 3.35 (the head fills the frame) and the density row scaled by "
                                                     f"{HEAVY_SIGMA_SCALE}: the sample count SURVEY.md 8d expects of a trained May model (1.5-1.7 M per frame)",
                                                     radius=HEAVY_RADIUS)
                 if torso:
-                    line["head_only"] = head_only_leg(args, job, two)
+                    line["head_only"] = leg(head_only_leg, args, job, two)
                 if args.precision == "fp32":
-                    line["split_tier"] = split_tier_leg(args, job, hp, torso, seq, sd, pframes if parity else [], cache)
+                    line["split_tier"] = leg(split_tier_leg, args, job, hp, torso, seq, sd, pframes if parity else [], cache)
                 if not args.no_train:
                     torch.cuda.synchronize()
-                    line["train_step"] = train_step_leg(args, job)
+                    line["train_step"] = leg(train_step_leg, args, job)
         line["cpu_baseline"] = cpu
         if emit is not None:
             emit(line)
@@ -743,11 +750,14 @@ def every_rank_parity(args, job, hp, torso, sd_rank0):
         rows = [rgb]
     out = None
     if job.rank == 0:
-        set_cpu_threads(max(1, min(16, (os.cpu_count() or 8) // job.world)))      # torchrun exports OMP_NUM_THREADS=1 for N > 1
-        ref = oracle_render(hp, sd_rank0, host_inputs(smp), torso)["rgb_map"].reshape(-1)
-        errs = [float((r.cpu() - ref).abs().max()) for r in rows]
-        out = {"frame": int(i), "max_abs_rgb_by_rank": errs, "max_abs_rgb": max(errs), "identical_across_ranks": all(torch.equal(rows[0], r) for r in rows),
-               "tolerance": 1e-4}
+        try:
+            set_cpu_threads(max(1, min(16, (os.cpu_count() or 8) // job.world)))      # torchrun exports OMP_NUM_THREADS=1 for N > 1
+            ref = oracle_render(hp, sd_rank0, host_inputs(smp), torso)["rgb_map"].reshape(-1)
+            errs = [float((r.cpu() - ref).abs().max()) for r in rows]
+            out = {"frame": int(i), "max_abs_rgb_by_rank": errs, "max_abs_rgb": max(errs), "identical_across_ranks": all(torch.equal(rows[0], r) for r in rows),
+                   "tolerance": 1e-4}
+        except Exception as e:      # noqa: BLE001  (the other ranks wait in the barrier below: never leave them there)
+            out = {"error": f"{type(e).__name__}: {e}"}
     job.barrier()
     return out
 
