@@ -50,6 +50,22 @@ def broadcast_model_(model: torch.nn.Module, src: int = 0):
     return model
 
 
+_STREAMS = {}      # device index -> the frame streams every pipeline of this process shares
+
+
+def frame_streams(device, n):
+    """`n` side streams of `device`, shared by every FramePipeline of the process.  HIP maps streams onto a fixed number of hardware queues
+    (GPU_MAX_HW_QUEUES, 8 here) in creation order: a process that keeps creating pipelines (bench.py builds a dozen, one per leg) would hand the
+    later ones streams that share hardware queues with each other, and two frames "in flight" on one queue are not concurrent -- measured:
+    the split tier's sub-block ran at 1 480-1 510 fps as the thirteenth pipeline of the process against 1 664 fps as the first.  Pipelines
+    are used one after the other, so sharing costs nothing; two used concurrently would merely be ordered more strictly than necessary."""
+    key = torch.device(device).index or 0
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
 class FramePipeline:
     """Device-resident inputs of one rank's frame shard + the per-frame step.
 
@@ -105,7 +121,7 @@ class FramePipeline:
         if dev.type == "cuda" and self.impl == "fused":
             # overlap=False keeps every frame on ONE side stream: kernels of consecutive frames never share the GPU, which is
             # what per-kernel profiling (rocprofv3 durations, HIP-event timing) wants; throughput runs use two
-            self._streams = [torch.cuda.Stream(dev) for _ in range(self.max_in_flight)]
+            self._streams = frame_streams(dev, self.max_in_flight)
             for st in self._streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
 
@@ -124,7 +140,7 @@ class FramePipeline:
         from .fused import cond_encode_batch, get_state
         st = get_state(self.model)
         if getattr(self, "_prep_stream", None) is None:
-            self._prep_stream = torch.cuda.Stream(self.device)
+            self._prep_stream = frame_streams(self.device, 5)[4]      # the fifth shared stream: the pass's batched encoder launch
         ps = self._prep_stream
         ps.wait_stream(torch.cuda.current_stream(self.device))
         for fs in self._streams:          # frames of the previous pass may still be reading the rows this launch's buffers replace

@@ -50,6 +50,13 @@ def main():
     import geneface_amd.raymarching as rmod
     rmod._backend, she._backend, fe._backend = RM, SH, FQ
     ge._grid_encode = _RefGridEncode
+    # the reference's structure: the field is a torch op graph over its encoders (since round 3 the product's training field is ONE fused
+    # autograd node that never reaches the patched seams -- with it this script measured the product against itself), and the density-grid
+    # refresh queries that graph block by block
+    import geneface_amd.radnerf as rn
+    import geneface_amd.renderer as rr
+    rn.RADNeRF.field_impl = "ops"
+    rr.NeRFRenderer._pick_impl = lambda self, impl, perturb, max_steps: "ops"
     import bench_train
     bench_train.main()
 
