@@ -561,6 +561,12 @@ def test_in_kernel_rays_vs_get_rays_512():
         assert torch.equal(ro[0], torch.from_numpy(seq["poses"][i][:3, 3]))          # the one origin, handed to the kernel by value
         err_d = (rays_d[hits] - rd[hits]).abs().max().item()
         assert err_d <= 2 ** -22, err_d                       # <= 2 ulp of a component of magnitude <= 1 (measured: 1.5)
+        # gf_pinhole_rays is the same device function as a stand-alone launch: the rays the kernel kept for its hit rays, bit for bit, and the
+        # same thing for every other pixel (what the oracle is fed to arbitrate a pose-mode pixel, helpers.pipe_inputs)
+        from geneface_amd.fused import pinhole_rays
+        ko, kd = pinhole_rays(torch.from_numpy(seq["poses"][i]), seq["intrinsics"], 512, 512, DEV)
+        assert torch.equal(kd.cpu().view(N, 3)[hits], rays_d[hits]) and torch.equal(ko.cpu().view(N, 3), ro)
+        assert (kd.cpu().view(N, 3) - rd).abs().max().item() <= 2 ** -22
         assert (rays_d[hits].norm(dim=-1) - 1).abs().max().item() < 2e-7
         n_ref, f_ref = R.near_far_from_aabb(ro, rd, sd["aabb_infer"], hp["min_near"])
         hit = f_ref < 1e30

@@ -75,7 +75,7 @@ def main():
     report = {"command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
               "frames": {}, "sweep_vs_reference_kernels": []}
     t0 = time.time()
-    for i in [int(x) for x in args.frames.split(",")]:
+    for i in [int(x) for x in args.frames.split(",") if x.strip()]:
         with torch.no_grad():
             smp = pipe.sample(i)
             dev_in = host(smp)
@@ -102,7 +102,9 @@ def main():
                 c = cmp(out, ref_gpu(smp))
             c["frame"] = i
             report["sweep_vs_reference_kernels"].append(c)
-        print("sweep vs reference kernels (identical device rays): worst", max(c["max"] for c in report["sweep_vs_reference_kernels"]), flush=True)
+        sw = report["sweep_vs_reference_kernels"]
+        print(f"sweep vs reference kernels (identical device rays), {len(sw)} frames: worst", max(c["max"] for c in sw),
+              "frames with a pixel above 1e-4:", sum(1 for c in sw if c["n_above_1e-4"]), flush=True)
     report["seconds"] = time.time() - t0
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(report, open(args.out, "w"), indent=1)
