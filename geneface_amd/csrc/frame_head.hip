@@ -350,6 +350,70 @@ __device__ __forceinline__ void rows_from_lds(const float* Hrow, const float* ro
     for (int c = 0; c < NOUT; c++) res[c] = sum[c] + __shfl_xor(sum[c], 32);
 }
 
+// The same NOUT skinny outputs WITHOUT a trip of the 128-wide activations through LDS (round 4).  The activations a skinny layer reads
+// are the ReLU'd accumulators of the layer before it, and they sit in registers when that layer's MFMAs end: every wave sums its own 32
+// features for all NT tiles (skinny_partials: 16 x NOUT FMAs per tile and lane, the lane halves added with one exchange), lane half 0
+// leaves the wave's partials in 16 bytes of the sample's row ([wave][c], skinny_publish), and after a barrier the sample's lane pair adds
+// the four waves' partials in wave order (skinny_collect).  Against rows_from_lds per layer and round: no 16 ds_write_b128 + 16 ds_read_b128
+// of activations and 4 x NOUT instead of 16 x NOUT weight reads per lane -- a third of the kernel's LDS traffic came from the two write-backs
+// nobody else read (ambient L2, colour L1) and the three row passes.  Fixed summation order (features in register order within a wave, waves
+// 0..3): run-to-run identical; it is a different order from rows_from_lds, i.e. last-ulp different sums -- the tolerance is the oracle's.
+// rows: [NOUT][128] in natural feature order; acc registers 4q..4q+3 of lane half h = features 32 wave + 8q + 4h + 0..3.
+template <int NT, int NOUT>
+__device__ __forceinline__ void skinny_partials(const floatx16 (&acc)[4], const float* rows, int wave, int half, float (&part)[NT][NOUT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) part[t][c] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float4 w4[NOUT];
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) w4[c] = *reinterpret_cast<const float4*>(rows + c * 128 + 32 * wave + 8 * q + 4 * half);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float x0 = relu1(acc[t][4 * q + 0]), x1 = relu1(acc[t][4 * q + 1]), x2 = relu1(acc[t][4 * q + 2]), x3 = relu1(acc[t][4 * q + 3]);
+#pragma unroll
+            for (int c = 0; c < NOUT; c++) {
+                part[t][c] = __builtin_fmaf(w4[c].x, x0, part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].y, x1, part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].z, x2, part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].w, x3, part[t][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) part[t][c] += __shfl_xor(part[t][c], 32);
+}
+// dst = &H[lane & 31][col0 + 4 * wave]: tile t is 32 rows further; one 16-byte (NOUT > 1) or 4-byte write per tile, lane half 0 only
+template <int NT, int NOUT>
+__device__ __forceinline__ void skinny_publish(float* dst, int half, const float (&part)[NT][NOUT]) {
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if constexpr (NOUT == 1) dst[t * 32 * kHS] = part[t][0];
+            else *reinterpret_cast<float4*>(dst + t * 32 * kHS) = float4{part[t][0], part[t][1], NOUT > 2 ? part[t][NOUT > 2 ? 2 : 0] : 0.0f, 0.0f};
+        }
+    }
+}
+// src = &H[sample][col0]: [wave][c] (NOUT > 1: 4 floats per wave) or [wave] (NOUT == 1)
+template <int NOUT>
+__device__ __forceinline__ void skinny_collect(const float* src, float (&res)[NOUT]) {
+    if constexpr (NOUT == 1) {
+        const float4 p = *reinterpret_cast<const float4*>(src);
+        res[0] = ((p.x + p.y) + p.z) + p.w;
+    } else {
+        float4 p[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) p[w] = *reinterpret_cast<const float4*>(src + 4 * w);
+        res[0] = ((p[0].x + p[1].x) + p[2].x) + p[3].x;
+        res[1] = ((p[0].y + p[1].y) + p[2].y) + p[3].y;
+        if constexpr (NOUT > 2) res[2] = ((p[0].z + p[1].z) + p[2].z) + p[3].z;
+    }
+}
+
 __device__ __forceinline__ void store16(float* dst, const float (&f)[16]) {
 #pragma unroll
     for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(dst)[q] = float4{f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
@@ -441,17 +505,32 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     obw_mfma<NT, gf::G_AMB2, 16, GEND>(wp, Ws, lane16, Hb, A);
     GF_PRIO_HI();
     GF_STAMP(13);
+#ifndef GF_SKINNY_FROM_LDS
+    {   // ambient L3 from the accumulators: relu(ambient L2) is read by nothing else and never reaches LDS
+        float part[NT][2];
+        skinny_partials<NT, 2>(A, s.P + P_SMALL + gf::HS_AMB3, wave, half, part);
+        __syncthreads();   // every wave has read its last ambient-L1 activation
+        GF_STAMP(14);
+        skinny_publish<NT, 2>(s.H + j * kHS + 32 + 4 * wave, half, part);   // columns 32..47: the 2-D features go to 0..31 below
+    }
+    if constexpr (SAVE) obw_save<NT, true>(sv->ha2, gbase, Mv, wave, lane, A, sv->m_ha2);
+#else
     __syncthreads();
     GF_STAMP(14);
     obw_store<NT, true>(Hw, A);
     if constexpr (SAVE) obw_save<NT, true>(sv->ha2, gbase, Mv, wave, lane, A, sv->m_ha2);
+#endif
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
     // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 0:32]  (a lane pair only touches its own sample's row)
     if (tile_on) {
         float ambient[2];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<2>(Hrow + 32, ambient);
+#else
         rows_from_lds<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+#endif
         const float th[2] = {tanhf(ambient[0]), tanhf(ambient[1])};
         const float x2[2] = {(th[0] + 1.0f) / 2.0f, (th[1] + 1.0f) / 2.0f};
         if constexpr (AMB_OUT) {
@@ -499,6 +578,13 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(24);
     obw_store<NT, true>(Hw, A);
+#ifndef GF_SKINNY_FROM_LDS
+    {   // the density row's partial sums from the same registers; they travel in the four pad floats of the sample's row
+        float part[NT][1];
+        skinny_partials<NT, 1>(A, s.P + P_SMALL + gf::HS_SIGROW, wave, half, part);
+        skinny_publish<NT, 1>(s.H + j * kHS + 128 + wave, half, part);
+    }
+#endif
     if constexpr (SAVE) obw_save<NT, true>(sv->hs2, gbase, Mv, wave, lane, A, sv->m_hs2);
     GF_STAMP(25);
     __syncthreads();
@@ -507,7 +593,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     float sigma = 0.0f;
     if (tile_on) {
         float h0[1];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<1>(Hrow + 128, h0);
+#else
         rows_from_lds<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+#endif
         sigma = expf(h0[0]);
 #ifdef GF_DIAG
         if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 14] = h0[0];
@@ -574,17 +664,32 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     obw_mfma<NT, gf::G_COL1G, 16>(wp, Ws, lane16, Hb, A);
     GF_PRIO_HI();
     GF_STAMP(31);
+#ifndef GF_SKINNY_FROM_LDS
+    {   // colour L2 from the accumulators: relu(colour L1) never reaches LDS
+        float part[NT][3];
+        skinny_partials<NT, 3>(A, s.P + P_SMALL + gf::HS_COL2, wave, half, part);
+        __syncthreads();   // every wave has read its last geometry feature
+        GF_STAMP(32);
+        skinny_publish<NT, 3>(s.H + j * kHS + 4 * wave, half, part);
+    }
+    if constexpr (SAVE) obw_save<NT, true>(sv->hc1, gbase, Mv, wave, lane, A, sv->m_hc1);
+#else
     __syncthreads();
     GF_STAMP(32);
     obw_store<NT, true>(Hw, A);
     if constexpr (SAVE) obw_save<NT, true>(sv->hc1, gbase, Mv, wave, lane, A, sv->m_hc1);
+#endif
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
     // ---- colour L2 + sigmoid; outputs reuse the position slots (read before the first barrier of this function)
     if (tile_on) {
         float c[3];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<3>(Hrow, c);
+#else
         rows_from_lds<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+#endif
         if (valid && half == 0) {
             s.sx[raw] = sigma;
             s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
@@ -1080,6 +1185,41 @@ __device__ __forceinline__ void store16s(_Float16* dst, const float (&f)[16]) {
 }
 
 // NT: compile-time MFMA tile count of the round (4, or 2 when the round holds <= 64 samples); nt = ceil(Mv / 32) <= NT gates the per-sample work.
+// skinny_partials for the split tier: the activation is the fp32 value the write-back would have split, relu(a1 + a2 * 2^-11), taken from the
+// accumulators (no f16 round trip at all for these two layers: ambient L2 -> L3 and colour L1 -> L2 lose their split write-backs, the
+// density row its 32 row reads).  Explicit builtins only, like the rest of the split round.
+template <int NT, int NOUT>
+__device__ __forceinline__ void skinny_partials_split(const floatx16 (&a1)[NT], const floatx16 (&a2)[NT], const float* rows, int wave, int half,
+                                                      float (&part)[NT][NOUT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) part[t][c] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float4 w4[NOUT];
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) w4[c] = *reinterpret_cast<const float4*>(rows + c * 128 + 32 * wave + 8 * q + 4 * half);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = relu1(__builtin_fmaf(a2[t][4 * q + i], gf::kSplitInv, a1[t][4 * q + i]));
+#pragma unroll
+            for (int c = 0; c < NOUT; c++) {
+                part[t][c] = __builtin_fmaf(w4[c].x, x[0], part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].y, x[1], part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].z, x[2], part[t][c]);
+                part[t][c] = __builtin_fmaf(w4[c].w, x[3], part[t][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int c = 0; c < NOUT; c++) part[t][c] += __shfl_xor(part[t][c], 32);
+}
+
 template <int NT>
 __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
     const int half = lane >> 5, j = lane & 31;
@@ -1127,16 +1267,31 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     // ---- ambient L2
     obws_mfma<NT, gf::SP_AMB2, 8, true>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(13);
+#ifndef GF_SKINNY_FROM_LDS
+    float* Hf = reinterpret_cast<float*>(s.H);     // the same rows as 132 floats (kHSS halves == kHS floats)
+    {
+        float part[NT][2];
+        skinny_partials_split<NT, 2>(A1, A2, s.P + P_SMALL + gf::HS_AMB3, wave, half, part);
+        __syncthreads();
+        GF_STAMP(14);
+        skinny_publish<NT, 2>(Hf + j * kHS + 32 + 4 * wave, half, part);   // floats 32..47 = halves 64..95: between the feature columns and their lo' parts
+    }
+#else
     __syncthreads();
     GF_STAMP(14);
     obws_store<NT, true>(Hw, A1, A2);
+#endif
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
     // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 32:64]; the kept 3-D features -> H[:, 0:32]
     if (tile_on) {
         float ambient[2];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<2>(Hf + sI * kHS + 32, ambient);
+#else
         rows_from_lds_split<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+#endif
         const float th[2] = {tanhf(ambient[0]), tanhf(ambient[1])};
         const float x2[2] = {(th[0] + 1.0f) / 2.0f, (th[1] + 1.0f) / 2.0f};
         float af[16];
@@ -1162,13 +1317,24 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     __syncthreads();
     GF_STAMP(24);
     obws_store<NT, true>(Hw, A1, A2);
+#ifndef GF_SKINNY_FROM_LDS
+    {
+        float part[NT][1];
+        skinny_partials_split<NT, 1>(A1, A2, s.P + P_SMALL + gf::HS_SIGROW, wave, half, part);
+        skinny_publish<NT, 1>(Hf + j * kHS + 128 + wave, half, part);       // the row's 16 pad bytes
+    }
+#endif
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
     // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
     if (tile_on) {
         float h0[1];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<1>(Hf + sI * kHS + 128, h0);
+#else
         rows_from_lds_split<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+#endif
         if (valid && half == 0) s.sx[raw] = expf(h0[0]);     // the position slots were consumed before the first barrier of this function
     }
     obws_mfma<NT, gf::SP_SIG3, 8, true>(wp, Ws, lane32, Hb, A1, A2);
@@ -1214,16 +1380,30 @@ __device__ __forceinline__ void field_round_split(const HeadArgs& a, const Smem&
     }
     obws_mfma<NT, gf::SP_COL1G, 8, false>(wp, Ws, lane32, Hb, A1, A2);
     GF_STAMP(31);
+#ifndef GF_SKINNY_FROM_LDS
+    {
+        float part[NT][3];
+        skinny_partials_split<NT, 3>(A1, A2, s.P + P_SMALL + gf::HS_COL2, wave, half, part);
+        __syncthreads();
+        GF_STAMP(32);
+        skinny_publish<NT, 3>(Hf + j * kHS + 4 * wave, half, part);
+    }
+#else
     __syncthreads();
     GF_STAMP(32);
     obws_store<NT, true>(Hw, A1, A2);
+#endif
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
     // ---- colour L2 + sigmoid
     if (tile_on) {
         float c[3];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<3>(Hf + sI * kHS, c);
+#else
         rows_from_lds_split<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+#endif
         if (valid && half == 0) {
             s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
             s.sz[raw] = 1.0f / (1.0f + __expf(-c[1]));
