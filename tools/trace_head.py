@@ -24,13 +24,13 @@ NAMES = {
     (4, 5): "scan + dense map", (5, 6): "barrier (dense map)", (6, 7): "encode 3-D grid -> H",
     (7, 8): "BARRIER", (8, 9): "mfma amb L1 + sig L1a (K=32+32)",
     (9, 10): "BARRIER ", (10, 11): "store H", (11, 12): "BARRIER  ",
-    (12, 13): "mfma amb L2 (K=128)", (13, 14): "BARRIER   ", (14, 15): "store H ", (15, 16): "BARRIER    ",
-    (16, 17): "amb L3 rows + tanh + encode 2-D grid -> H", (17, 18): "BARRIER     ",
+    (12, 13): "mfma amb L2 (K=128)", (13, 14): "amb L3 partial sums from the accumulators + barrier", (14, 15): "publish partials", (15, 16): "BARRIER    ",
+    (16, 17): "amb L3 collect + tanh + encode 2-D grid -> H", (17, 18): "BARRIER     ",
     (18, 19): "mfma sig L1b (K=32)", (19, 20): "BARRIER      ", (20, 21): "store H  ", (21, 22): "BARRIER       ",
-    (22, 23): "mfma sig L2 (K=128)", (23, 24): "BARRIER        ", (24, 25): "store H   ", (25, 26): "BARRIER         ",
-    (26, 27): "sigma row + exp + mfma sig L3 (K=128)", (27, 28): "BARRIER          ", (28, 29): "store H    ", (29, 30): "BARRIER           ",
-    (30, 31): "SH + mfma col L1 (K=16+128)", (31, 32): "BARRIER            ", (32, 33): "store H     ", (33, 34): "BARRIER             ",
-    (34, 35): "col L2 rows + sigmoid", (35, 36): "barrier end of field", (36, 37): "composite + retire",
+    (22, 23): "mfma sig L2 (K=128)", (23, 24): "BARRIER        ", (24, 25): "store H + density-row partials", (25, 26): "BARRIER         ",
+    (26, 27): "sigma collect + exp + mfma sig L3 (K=128)", (27, 28): "BARRIER          ", (28, 29): "store H    ", (29, 30): "BARRIER           ",
+    (30, 31): "SH + mfma col L1 (K=16+128)", (31, 32): "col L2 partial sums from the accumulators + barrier", (32, 33): "publish partials ", (33, 34): "BARRIER             ",
+    (34, 35): "col L2 collect + sigmoid", (35, 36): "barrier end of field", (36, 37): "composite + retire",
 }
 SLOT_END, SLOT_MV, SLOT_NPOOL, SLOT_N = 37, 38, 39, 40
 
