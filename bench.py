@@ -848,8 +848,8 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
                 # (hi*hi + lo*hi + hi*lo: three v_mfma_f32_32x32x16_f16 per 16 input features and tile)
                 pk = PEAK_F16_MFMA_TFLOPS / 3.0
                 r["mfma"] = {"achieved_f32_equivalent": r["mfma_tflops_f32_equivalent"], "peak": pk, "unit": "TFLOP/s", "frac": r["mfma_tflops_f32_equivalent"] / pk,
-                             "note": "fp32-equivalent algorithmic FLOPs / (f16 dense peak / 3): the matrix pipe is a quarter busy; the round is gathers, "
-                                     "f32 <-> split conversions, march / composite and barriers (profiles/round3/r3s_head_timeline_split.txt)"}
+                             "note": "fp32-equivalent algorithmic FLOPs / (f16 dense peak / 3): the matrix pipe is a third busy; the round is gathers, "
+                                     "f32 <-> split conversions, march / composite and barriers (profiles/round4/r4e_head_timeline_split.txt)"}
             return r
         r["traffic"], r["traffic_source"] = pmc_traffic()
         return r
