@@ -43,7 +43,8 @@ for s in $STEPS; do
            (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_train -o k --output-format csv -- python $REPO/tools/bench_train.py --steps 32 --warmup 16 > $OUT/prof_train.log 2>&1); head -8 $OUT/prof_train/k_kernel_stats.csv | cut -c1-160 ;;
     clock) # shader clock inside the head kernel vs a steady MFMA probe, with the firmware's view (amd-smi)
            timeout 300 bash tools/clock_probe.sh $TAG/clock 8000 2>&1 | tail -30 ;;
-    trace) timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
+    trace) [ -f geneface_amd/csrc/libgeneface_hip_trace.so ] || python -m geneface_amd.csrc.build --trace > /dev/null   # (the instrumented library is not shipped: .gpurunignore)
+           timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     tracev:*) V=${s#tracev:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 300 python tools/trace_head.py > $OUT/trace_$V.txt 2>&1; grep -E "phase ms|lifetime|round =" $OUT/trace_$V.txt ;;
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
     prof)  # one frame in flight: per-kernel durations are those of the kernel alone (what bench.py's roofline leg times)
