@@ -121,7 +121,6 @@ struct Smem {
     float* H;        // [kPass][kHS] activations of the round's samples
     float* P;        // VALU-layer rows, colour bias, ambient bias, per-level grid meta
     float *p_dx, *p_dy, *p_dz;   // [kPool] ray directions by pool slot (read by the SH evaluation of the slot's samples)
-    float *c_x, *c_y, *c_z, *c_dt, *c_t;   // [kPool] the look-ahead sample of the slot's ray (c_dt == 0: none): next round's first sample, not marched twice
     // per-round sample staging (raw slot = rank * n + s); field outputs alias the positions
     float *sx, *sy, *sz, *sdt, *st, *ob;
     uint8_t *d2r, *rcnt, *rbase, *rrank;
@@ -134,12 +133,7 @@ struct Smem {
     uint32_t* dkey;  // [kPass] record index of the sample in raw slot r (0xFFFFFFFF: none)
 #endif
 };
-#ifndef GF_NO_LOOKAHEAD_CACHE
-constexpr int kPoolArrays = 8;        // directions + the cached look-ahead sample
-#else
-constexpr int kPoolArrays = 3;
-#endif
-constexpr int kSmemBase = (kPass * kHS + kPFloats + kPoolArrays * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
+constexpr int kSmemBase = (kPass * kHS + kPFloats + 3 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
 #if defined(GF_TRACE)
 constexpr int kSmemBytes = kSmemBase + 4 * kTraceSlots;
 #elif defined(GF_DIAG)
@@ -155,11 +149,6 @@ __device__ __forceinline__ Smem carve(char* base) {
     s.H = f; f += kPass * kHS;
     s.P = f; f += kPFloats;
     s.p_dx = f; f += kPool; s.p_dy = f; f += kPool; s.p_dz = f; f += kPool;
-#ifndef GF_NO_LOOKAHEAD_CACHE
-    s.c_x = f; f += kPool; s.c_y = f; f += kPool; s.c_z = f; f += kPool; s.c_dt = f; f += kPool; s.c_t = f; f += kPool;
-#else
-    s.c_x = s.c_y = s.c_z = s.c_dt = s.c_t = nullptr;
-#endif
     s.sx = f; f += kPass; s.sy = f; f += kPass; s.sz = f; f += kPass; s.sdt = f; f += kPass; s.st = f; f += kPass; s.ob = f; f += kPass;
     s.hist = reinterpret_cast<uint32_t*>(f); f += kHistBins;
     s.misc = reinterpret_cast<uint32_t*>(f); f += 16;
@@ -1551,9 +1540,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     }
                     r_done = 0;
                     s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
-#ifndef GF_NO_LOOKAHEAD_CACHE
-                    s.c_dt[tid] = 0.0f;
-#endif
                 }
             }
             if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
@@ -1602,45 +1588,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
             }
             const float r_dx = s.p_dx[tid], r_dy = s.p_dy[tid], r_dz = s.p_dz[tid];
-            // Round 4: the look-ahead sample found last round IS this round's first sample (r_t was rewound to its start, and marching from
-            // there reproduces it bit for bit -- march_core.hpp): it waits in the slot's five cache words instead of being marched a second
-            // time.  With one sample per ray and round (the usual case: full pools) that halves the sample visits of this segment.
-            uint32_t has = 0;
-            float t_loc = r_t;
-#ifndef GF_NO_LOOKAHEAD_CACHE
-            {
-                const float cdt = s.c_dt[tid];
-                if (cdt != 0.0f) {
-                    has = 1;
-                    s.sx[base] = s.c_x[tid]; s.sy[base] = s.c_y[tid]; s.sz[base] = s.c_z[tid];
-                    s.sdt[base] = cdt; t_loc = s.c_t[tid]; s.st[base] = t_loc;
-#ifdef GF_DIAG
-                    {
-                        const uint32_t k = (a.phase ? a.max_steps : 0u) + r_done;
-                        uint32_t key = 0xFFFFFFFFu;
-                        if (a.diag && k < a.diag_stride) {
-                            key = (uint32_t)ray * a.diag_stride + k;
-                            float* rec = a.diag + (size_t)key * kDiagWords;
-                            rec[15] = s.c_x[tid]; rec[4] = cdt; rec[5] = t_loc;
-                            reinterpret_cast<uint32_t*>(rec)[18] = a.phase; reinterpret_cast<uint32_t*>(rec)[19] = base;
-                        }
-                        s.dkey[base] = key;
-                    }
-#endif
-                }
-            }
-            float la_x = 0.0f, la_y = 0.0f, la_z = 0.0f, la_dt = 0.0f, la_t = 0.0f;
-#endif
-            mcnt = has + gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u - has, t_loc,
-                                [&](uint32_t q0, float x, float y, float z, float dt, float t_after, float t_at) {
-                                    const uint32_t q = q0 + has;
-                                    if (q >= req) {
-                                        t_next = t_at;
-#ifndef GF_NO_LOOKAHEAD_CACHE
-                                        la_x = x; la_y = y; la_z = z; la_dt = dt; la_t = t_after;
-#endif
-                                        return;
-                                    }
+            mcnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u, r_t,
+                                [&](uint32_t q, float x, float y, float z, float dt, float t_after, float t_at) {
+                                    if (q >= req) { t_next = t_at; return; }
                                     s.sx[base + q] = x; s.sy[base + q] = y; s.sz[base + q] = z;
                                     s.sdt[base + q] = dt; s.st[base + q] = t_after;
 #ifdef GF_DIAG
@@ -1654,19 +1604,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                                     }
                                     s.dkey[base + q] = key;
 #endif
-                                }, req + 1u - has + kMarchSlack);
-#ifndef GF_NO_LOOKAHEAD_CACHE
-            if (mcnt > req) {   // a look-ahead sample exists: the clock is rewound to its start (what phase 1 / a survivor resumes from), the sample kept
-                mcnt = req; r_t = t_next;
-                s.c_x[tid] = la_x; s.c_y[tid] = la_y; s.c_z[tid] = la_z; s.c_dt[tid] = la_dt; s.c_t[tid] = la_t;
-            } else {
-                r_t = t_loc;
-                s.c_dt[tid] = 0.0f;
-            }
-#else
-            r_t = t_loc;
+                                }, req + 1u + kMarchSlack);
             if (mcnt > req) { mcnt = req; r_t = t_next; }
-#endif
         }
         GF_STAMP(3);
         if (owner) s.rcnt[tid] = (uint8_t)mcnt;
