@@ -246,3 +246,38 @@ def test_grid_encoder_seam_accepts_half_tables_like_the_reference_under_autocast
         GE.grid_encode_forward(x, eh, off, r16, B, 3, 2, 16, S, 16, None, 1, False, 0)
         torch.cuda.synchronize()
         assert (o16.float() - r16.float()).abs().max() < 4e-3          # the reference rounds every corner product to half
+
+
+@pytest.mark.parametrize("D", [2, 3, 4])
+@pytest.mark.parametrize("C", [2, 4, 8])
+@pytest.mark.parametrize("gridtype", [0, 1])
+def test_half_table_forward_is_the_fp32_forward_on_the_widened_table(D, C, gridtype):
+    """gf_grid_encode_forward_f16 (the branch the reference reaches through AT_DISPATCH_FLOATING_TYPES_AND_HALF, gridencoder.cu:375-398, when
+    its wrapper casts the table to half under autocast, grid.py:41-44) widens each row on load and computes in fp32: outputs and dy_dx must
+    equal gf_grid_encode_forward on `table.half().float()` BIT FOR BIT, for every channel count the half branch serves and both index rules."""
+    from geneface_amd.encoders.gridencoder import grid_offsets, per_level_scale_for
+    from geneface_amd.lib import check, current_stream, lib, ptr
+    L, Hres, log2, desired = 8, 16, 14, 256
+    off = grid_offsets(D, L, Hres, log2, desired)          # row offsets (independent of the channel count)
+    S = float(np.log2(per_level_scale_for(desired, Hres, L)))
+    g = torch.Generator().manual_seed(100 * D + 10 * C + gridtype)
+    table = (torch.rand(int(off[-1]), C, generator=g) * 2 - 1).to(DEV)
+    th = table.half()
+    offsets = torch.from_numpy(np.asarray(off, dtype=np.int32)).to(DEV)
+    B = 50_000
+    x = torch.rand(B, D, generator=g).to(DEV)
+    x[:5] = 1.5       # out of range: zeros
+    o32, d32 = torch.empty(L, B, C, device=DEV), torch.empty(B, L * D * C, device=DEV)
+    o16, d16 = torch.empty(L, B, C, device=DEV), torch.empty(B, L * D * C, device=DEV)
+    check(lib().gf_grid_encode_forward(ptr(x), ptr(th.float().contiguous()), ptr(offsets, torch.int32), ptr(o32), B, D, C, L, S, Hres, ptr(d32), gridtype, 0, 0,
+                                       current_stream(x.device)))
+    check(lib().gf_grid_encode_forward_f16(ptr(x), ptr(th, torch.float16), ptr(offsets, torch.int32), ptr(o16), B, D, C, L, S, Hres, ptr(d16), gridtype, 0, 0,
+                                           current_stream(x.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o32) and torch.equal(d16, d32)
+    assert float(o16[:, :5].abs().max()) == 0.0 and float(o16.abs().max()) > 0.1
+    # and it is the half table that was read, not something wider: against the fp32 table the outputs differ by the table's rounding
+    o_full = torch.empty(L, B, C, device=DEV)
+    check(lib().gf_grid_encode_forward(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(o_full), B, D, C, L, S, Hres, None, gridtype, 0, 0, current_stream(x.device)))
+    err = float((o16 - o_full).abs().max())
+    assert 0 < err < 2e-3
