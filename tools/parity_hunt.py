@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_hunt.json"))
     ap.add_argument("--frames", default="1,4,8,11,14,17,21,24")
     ap.add_argument("--T", type=int, default=25)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "split", "fast"], help="render_precision of the product side")
     args = ap.parse_args()
     from geneface_amd.infer import FramePipeline
     from geneface_amd.radnerf_torso import RADNeRFTorso
@@ -63,7 +64,7 @@ def main():
     m = RADNeRFTorso(hp)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
-    m.render_impl = "fused"
+    m.render_impl, m.render_precision = "fused", args.precision
     pipe = FramePipeline(m, hp, seq, DEV, impl="fused")
     have_ref = ref_kernels.available("fast")
     sd_g = {k: v.to(DEV) for k, v in sd.items()}
@@ -72,7 +73,7 @@ def main():
         with R.kernel_backend(ref_kernels.load("fast")):
             return R.render(sd_g, hp, smp["rays_o"], smp["rays_d"], smp["cond_wins"], smp["bg_coords"], smp["pose"], smp["bg_img"], True)["rgb_map"].reshape(-1, 3).cpu()
 
-    report = {"command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
+    report = {"precision": args.precision, "command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
               "frames": {}, "sweep_vs_reference_kernels": []}
     t0 = time.time()
     for i in [int(x) for x in args.frames.split(",") if x.strip()]:
