@@ -59,7 +59,8 @@ def frame_streams(device, n):
     later ones streams that share hardware queues with each other, and two frames "in flight" on one queue are not concurrent -- measured:
     the split tier's sub-block ran at 1 480-1 510 fps as the thirteenth pipeline of the process against 1 664 fps as the first.  Pipelines
     are used one after the other, so sharing costs nothing; two used concurrently would merely be ordered more strictly than necessary."""
-    key = torch.device(device).index or 0
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _STREAMS.setdefault(key, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device))
@@ -171,17 +172,20 @@ class FramePipeline:
         k = i - pre["first"]
         return pre["amb"][k], (pre["torso"][k] if pre["torso"] is not None else None)
 
-    def sample(self, i: int) -> dict:
+    def sample(self, i: int, rays: bool = True) -> dict:
         """The `sample` dict tasks/radnerfs/radnerf.py:119-126 reads (rays materialised, like the reference's dataset)."""
-        rays = utils.get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
-        return {"cond_wins": self.cond_wins[i], "rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "bg_coords": self.bg_coords,
-                "pose": self.pose6[i:i + 1], "idx": int(self.frame_ids[i]), "bg_img": self.bg, "H": self.H, "W": self.W}
+        s = {"cond_wins": self.cond_wins[i], "bg_coords": self.bg_coords, "pose": self.pose6[i:i + 1], "idx": int(self.frame_ids[i]),
+             "bg_img": self.bg, "H": self.H, "W": self.W}
+        if rays:
+            r = utils.get_rays(self.poses[i:i + 1], self.intrinsics, self.H, self.W, -1)
+            s["rays_o"], s["rays_d"] = r["rays_o"], r["rays_d"]
+        return s
 
     def kernel_sample(self, i: int) -> dict:
         """`sample(i)` with the rays the frame loop generates for itself (fused.pinhole_rays: the device function k_frame_init runs), as
         tensors: run_model(kernel_sample(i)) and render_frame(i) see the same ray bits."""
         from .fused import pinhole_rays
-        s = self.sample(i)
+        s = self.sample(i, rays=False)
         s["rays_o"], s["rays_d"] = pinhole_rays(self.poses[i], self.intrinsics, self.H, self.W, self.device)
         return s
 
