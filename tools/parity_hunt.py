@@ -55,12 +55,14 @@ def main():
     ap.add_argument("--frames", default="1,4,8,11,14,17,21,24")
     ap.add_argument("--T", type=int, default=25)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "split", "fast"], help="render_precision of the product side")
+    ap.add_argument("--identity", type=int, default=0, help="fixture seed: 0 = the bench identity, 1000 = the second identity of BASELINE.json configs[4] "
+                                                            "(other weights, another occupancy shape, another pose / landmark sequence)")
     args = ap.parse_args()
     from geneface_amd.infer import FramePipeline
     from geneface_amd.radnerf_torso import RADNeRFTorso
     threads = oracle_threads(16)
-    hp, sd = model_fixture(True)
-    seq = sequence(args.T, 512, 512)
+    hp, sd = model_fixture(True, args.identity)
+    seq = sequence(args.T, 512, 512, seed=5 if args.identity else 0)
     m = RADNeRFTorso(hp)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
@@ -73,7 +75,7 @@ def main():
         with R.kernel_backend(ref_kernels.load("fast")):
             return R.render(sd_g, hp, smp["rays_o"], smp["rays_d"], smp["cond_wins"], smp["bg_coords"], smp["pose"], smp["bg_img"], True)["rgb_map"].reshape(-1, 3).cpu()
 
-    report = {"precision": args.precision, "command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
+    report = {"precision": args.precision, "identity": args.identity, "command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
               "frames": {}, "sweep_vs_reference_kernels": []}
     t0 = time.time()
     for i in [int(x) for x in args.frames.split(",") if x.strip()]:
