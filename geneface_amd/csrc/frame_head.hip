@@ -388,13 +388,13 @@ __device__ __forceinline__ void skinny_partials(const floatx16 (&acc)[4], const 
         for (int c = 0; c < NOUT; c++) part[t][c] += __shfl_xor(part[t][c], 32);
 }
 // dst = &H[lane & 31][col0 + 4 * wave]: tile t is 32 rows further; one 16-byte (NOUT > 1) or 4-byte write per tile, lane half 0 only
-template <int NT, int NOUT>
+template <int NT, int NOUT, int RS = kHS /* floats per activation row */>
 __device__ __forceinline__ void skinny_publish(float* dst, int half, const float (&part)[NT][NOUT]) {
     if (half == 0) {
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            if constexpr (NOUT == 1) dst[t * 32 * kHS] = part[t][0];
-            else *reinterpret_cast<float4*>(dst + t * 32 * kHS) = float4{part[t][0], part[t][1], NOUT > 2 ? part[t][NOUT > 2 ? 2 : 0] : 0.0f, 0.0f};
+            if constexpr (NOUT == 1) dst[t * 32 * RS] = part[t][0];
+            else *reinterpret_cast<float4*>(dst + t * 32 * RS) = float4{part[t][0], part[t][1], NOUT > 2 ? part[t][NOUT > 2 ? 2 : 0] : 0.0f, 0.0f};
         }
     }
 }
@@ -888,16 +888,34 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     obw_zero<4>(A);
     obw16_mfma<gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(13);
+#ifndef GF_SKINNY_FROM_LDS
+    // the three skinny layers from the fp32 accumulators, as in the other two tiers (skinny_partials): relu(ambient L2) and relu(colour L1)
+    // are never rounded to f16 nor written to LDS; the rows are 68 floats here
+    constexpr int kHF16 = kHS16 / 2;
+    float* Hf = reinterpret_cast<float*>(s.H);
+    {
+        float part[4][2];
+        skinny_partials<4, 2>(A, s.P + P_SMALL + gf::HS_AMB3, wave, half, part);
+        __syncthreads();
+        GF_STAMP(14);
+        skinny_publish<4, 2, kHF16>(Hf + j * kHF16 + 16 + 4 * wave, half, part);   // floats 16..31 = halves 32..63: behind the 2-D features (halves 0..31)
+    }
+#else
     __syncthreads();
     GF_STAMP(14);
     obw16_store<true>(Hw, A, nt);
+#endif
     GF_STAMP(15);
     __syncthreads();
     GF_STAMP(16);
     // ---- ambient L3 + tanh -> 2-D grid features -> H[:, 0:32]
     if (tile_on) {
         float ambient[2];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<2>(Hf + sI * kHF16 + 16, ambient);
+#else
         rows_from_lds16<2>(Hrow, s.P + P_SMALL + gf::HS_AMB3, half, ambient);
+#endif
         // (tanh(v) + 1) / 2 = 1 / (1 + exp(-2 v))
         const float e2[2] = {__expf(-2.0f * ambient[0]), __expf(-2.0f * ambient[1])};
         const float x2[2] = {1.0f / (1.0f + e2[0]), 1.0f / (1.0f + e2[1])};
@@ -942,6 +960,13 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(24);
     obw16_store<true>(Hw, A, nt);
+#ifndef GF_SKINNY_FROM_LDS
+    {
+        float part[4][1];
+        skinny_partials<4, 1>(A, s.P + P_SMALL + gf::HS_SIGROW, wave, half, part);
+        skinny_publish<4, 1, kHF16>(Hf + j * kHF16 + 64 + wave, half, part);       // the row's 16 pad bytes (halves 128..135)
+    }
+#endif
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -949,7 +974,11 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     float sigma = 0.0f;
     if (tile_on) {
         float h0[1];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<1>(Hf + sI * kHF16 + 64, h0);
+#else
         rows_from_lds16<1>(Hrow, s.P + P_SMALL + gf::HS_SIGROW, half, h0);
+#endif
         sigma = expf(h0[0]);
 #ifdef GF_DIAG
         if (a.diag && dkey != 0xFFFFFFFFu && half == 0) a.diag[(size_t)dkey * kDiagWords + 14] = h0[0];
@@ -984,16 +1013,30 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     }
     obw16_mfma<gf::H16_COL1G, 8>(wp, Ws, lane16, Hb, A, nt);
     GF_STAMP(31);
+#ifndef GF_SKINNY_FROM_LDS
+    {
+        float part[4][3];
+        skinny_partials<4, 3>(A, s.P + P_SMALL + gf::HS_COL2, wave, half, part);
+        __syncthreads();
+        GF_STAMP(32);
+        skinny_publish<4, 3, kHF16>(Hf + j * kHF16 + 4 * wave, half, part);
+    }
+#else
     __syncthreads();
     GF_STAMP(32);
     obw16_store<true>(Hw, A, nt);
+#endif
     GF_STAMP(33);
     __syncthreads();
     GF_STAMP(34);
     // ---- colour L2 + sigmoid
     if (tile_on) {
         float c[3];
+#ifndef GF_SKINNY_FROM_LDS
+        skinny_collect<3>(Hf + sI * kHF16, c);
+#else
         rows_from_lds16<3>(Hrow, s.P + P_SMALL + gf::HS_COL2, half, c);
+#endif
         if (valid && half == 0) {
             s.sx[raw] = sigma;
             s.sy[raw] = 1.0f / (1.0f + __expf(-c[0]));
