@@ -234,7 +234,12 @@ __device__ __forceinline__ bool encode8_tiled(const float* __restrict__ table, c
     constexpr int LB = D == 3 ? GF_TILED_LB3 : GF_TILED_LB2, NP = 1 << (D - 1), NC = 1 << D;
     bool oob = false;
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    for (uint32_t d = 0; d < D; d++) oob |= !(x[d] >= 0.0f && x[d] <= 1.0f);      // (a NaN coordinate is out of range too)
+    // An out-of-range point gets zeros (gridencoder.cu:117-131) -- and must not form table addresses from its coordinates: on a dense level
+    // nothing wraps the index, and a far-away point (the module API accepts any position) would read far outside the table
+    float xs[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) xs[d] = oob ? 0.0f : x[d];
     const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
     bool wrapped = false;      // some pair of this lane sits on the last row of a wrapped level: the caller redoes the lookup corner by corner
 #pragma unroll
@@ -251,7 +256,7 @@ __device__ __forceinline__ bool encode8_tiled(const float* __restrict__ table, c
             uint32_t g[D];
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
-                float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
+                float p = __builtin_fmaf(xs[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
                 const float fl = floorf(p);
                 g[d] = (uint32_t)fl;
                 p -= fl;
@@ -317,7 +322,12 @@ __device__ __forceinline__ void encode8(const float* __restrict__ table, const L
 #endif
     bool oob = false;
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    for (uint32_t d = 0; d < D; d++) oob |= !(x[d] >= 0.0f && x[d] <= 1.0f);      // (a NaN coordinate is out of range too)
+    // An out-of-range point gets zeros (gridencoder.cu:117-131) -- and must not form table addresses from its coordinates: on a dense level
+    // nothing wraps the index, and a far-away point (the module API accepts any position) would read far outside the table
+    float xs[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) xs[d] = oob ? 0.0f : x[d];
     const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
     (void)gridtype;
 #pragma unroll
@@ -334,7 +344,7 @@ __device__ __forceinline__ void encode8(const float* __restrict__ table, const L
             uint32_t g[D];
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
-                float p = __builtin_fmaf(x[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
+                float p = __builtin_fmaf(xs[d], scale, 0.5f);  // fused on purpose: see oracle/radnerf_kernels.c
                 const float fl = floorf(p);
                 g[d] = (uint32_t)fl;
                 p -= fl;
@@ -395,7 +405,7 @@ __device__ __forceinline__ void encode8_grad2(const float* __restrict__ table, c
                                               uint32_t interp, const float (&x)[2], const float (&gf)[16], float (&dx)[2]) {
     constexpr uint32_t P1 = 2654435761u;
     dx[0] = dx[1] = 0.0f;
-    if (x[0] < 0.0f || x[0] > 1.0f || x[1] < 0.0f || x[1] > 1.0f) return;
+    if (!(x[0] >= 0.0f && x[0] <= 1.0f && x[1] >= 0.0f && x[1] <= 1.0f)) return;      // out of range, or NaN
     const float2* __restrict__ rows = reinterpret_cast<const float2*>(table);
 #pragma unroll
     for (int l = 0; l < 8; l++) {

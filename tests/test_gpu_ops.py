@@ -281,3 +281,55 @@ def test_half_table_forward_is_the_fp32_forward_on_the_widened_table(D, C, gridt
     check(lib().gf_grid_encode_forward(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(o_full), B, D, C, L, S, Hres, None, gridtype, 0, 0, current_stream(x.device)))
     err = float((o16 - o_full).abs().max())
     assert 0 < err < 2e-3
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_fused_lookup_far_out_of_range_points_read_nothing_and_give_zeros(D):
+    """The specialised lookup of the fused kernels on points far outside [0,1] (and NaN / inf): zeros like the generic operator and the
+    reference (gridencoder.cu:117-131), and -- the point of the test -- no table address is formed from such coordinates (on a dense level
+    nothing wraps the index: x = 1e6 used to index ~1e18 rows past the table).  The module API accepts any position (RADNeRF.forward)."""
+    from geneface_amd.encoders.gridencoder import grid_offsets, per_level_scale_for
+    from geneface_amd.lib import check, current_stream, lib, ptr
+    L, Hres, log2, desired = 16, 16, 16, 2048
+    off = grid_offsets(D, L, Hres, log2, desired)
+    S = float(np.log2(per_level_scale_for(desired, Hres, L)))
+    g = torch.Generator().manual_seed(77 + D)
+    table = (torch.rand(int(off[-1]), 2, generator=g) * 2 - 1).to(DEV)
+    offsets = torch.from_numpy(off).to(DEV)
+    x = torch.rand(4096, D, generator=g)
+    bad = torch.tensor([1e6, -1e6, 3.4e38, -3.4e38, float("inf"), float("-inf"), float("nan"), 1.0000001, -1e-7, 65536.5])
+    for k, v in enumerate(bad):
+        x[k * 3:(k * 3) + 3] = torch.rand(3, D, generator=g)
+        x[k * 3, 0] = v
+        x[k * 3 + 1, D - 1] = v
+        x[k * 3 + 2, :] = v
+    x = x.to(DEV)
+    for gridtype in (1, 0):
+        ref, out = torch.empty(4096, 32, device=DEV), torch.full((4096, 32), 7.0, device=DEV)
+        check(lib().gf_grid_encode_forward_blc(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(ref), 4096, D, 2, L, S, Hres, None, gridtype, 0, 0, current_stream(x.device)))
+        check(lib().gf_grid_encode_fused_lookup(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(out), 4096, D, S, Hres, gridtype, 0, current_stream(x.device)))
+        torch.cuda.synchronize()
+        rows = torch.arange(30, device=DEV)
+        assert float(out[rows].abs().max()) == 0.0                       # every planted row is out of range (or NaN): zeros
+        nan_rows = torch.isnan(x).any(dim=1)
+        assert torch.equal(out[~nan_rows], ref[~nan_rows].clone()) or (out[~nan_rows] - ref[~nan_rows]).abs().max().item() <= 1e-6
+        assert float(out[30:].abs().max()) > 0.1
+
+
+def test_field_forward_accepts_any_position():
+    """RADNeRF.forward on positions far outside the bound: the one-launch field must not fault, and returns what the oracle returns (zero
+    grid features -> the field of the biases)."""
+    from test_gpu_render import build
+    hp, sd, model = build(False, "fused")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(2000, 3, generator=g) * 2 - 1) * 0.4
+    x[:8] = torch.tensor([[1e6, 0, 0], [0, -1e6, 0], [0, 0, 3e38], [50, 50, 50], [-50, 0.1, 0.2], [1.0001, 0, 0], [0, -1.0001, 0], [7, -7, 7]])
+    d = torch.nn.functional.normalize(torch.randn(2000, 3, generator=g), dim=-1)
+    cond = torch.randn(5, 1, 204, generator=g)
+    cf = R.cal_cond_feat(sd, hp, cond)
+    s_ref, c_ref, a_ref = R.head_field(sd, hp, x, d, cf, sd["individual_embeddings"][0])
+    with torch.no_grad():
+        s, c, a = model(x.to(DEV), d.to(DEV), cf.to(DEV), model.individual_embeddings[0])
+    torch.cuda.synchronize()
+    assert torch.isfinite(s).all() and torch.isfinite(c).all()
+    assert ((s.cpu() - s_ref).abs() / s_ref.abs().clamp(min=1e-3)).max() < 2e-3 and (c.cpu() - c_ref).abs().max() < 1e-4 and (a.cpu() - a_ref).abs().max() < 1e-5
