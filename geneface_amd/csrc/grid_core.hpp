@@ -225,6 +225,8 @@ template <uint32_t D>
 __device__ __forceinline__ bool encode8_tiled(const float* __restrict__ table, const LevelMeta* __restrict__ meta8, uint32_t interp,
                                               const float (&x)[D], float (&f)[16]) {
     static_assert(D == 2 || D == 3, "head grids are 2-D or 3-D");
+    // levels whose reads are in flight together (A/B knobs: smaller batches did not relieve the register pressure that decided this function's
+    // shape -- NOTES 8.2 -- so the per-corner form's batch sizes stay)
 #ifndef GF_TILED_LB3
 #define GF_TILED_LB3 4
 #endif
