@@ -49,11 +49,6 @@ using gf::floatx16;
 constexpr int kThreads = 256;
 constexpr int kPass = 128;            // sample slots per round (four 32-column MFMA tiles)
 constexpr int kPool = 128;            // live rays per workgroup
-#ifndef GF_OWNER_WAVES
-#define GF_OWNER_WAVES 4
-#endif
-constexpr int kOwnerWaves = GF_OWNER_WAVES;   // waves whose low lanes own the pool's rays (2 or 4)
-static_assert(kOwnerWaves == 2 || kOwnerWaves == 4, "owner waves");
 constexpr int kHS = 132;              // floats per activation row (128 + 4: rows 16 B apart in bank space -> conflict-free b128)
 constexpr int kPFloats = gf::HS_TOTAL + 128 /*amb bias*/ + 2 * 16 * 8 /*level meta*/;
 constexpr int kHistBins = gf::kHistLds;   // LDS bins of the terminal-index histogram (d < kHistBins; larger d: global atomics, rare)
@@ -130,7 +125,7 @@ struct Smem {
     float *sx, *sy, *sz, *sdt, *st, *ob;
     uint8_t *d2r, *rcnt, *rbase, *rrank;
     uint32_t* hist;  // [kHistBins]
-    uint32_t* misc;  // [24]: 0..15 scalars of the round / workgroup, 16..19 alive rays per owner wave, 20..23 "saw the end of the queue" per owner wave
+    uint32_t* misc;  // [16]
 #ifdef GF_TRACE
     uint32_t* tr;    // [kTraceSlots]
 #endif
@@ -138,7 +133,7 @@ struct Smem {
     uint32_t* dkey;  // [kPass] record index of the sample in raw slot r (0xFFFFFFFF: none)
 #endif
 };
-constexpr int kSmemBase = (kPass * kHS + kPFloats + 3 * kPool + 6 * kPass + kHistBins + 24) * 4 + 4 * kPass;
+constexpr int kSmemBase = (kPass * kHS + kPFloats + 3 * kPool + 6 * kPass + kHistBins + 16) * 4 + 4 * kPass;
 #if defined(GF_TRACE)
 constexpr int kSmemBytes = kSmemBase + 4 * kTraceSlots;
 #elif defined(GF_DIAG)
@@ -156,7 +151,7 @@ __device__ __forceinline__ Smem carve(char* base) {
     s.p_dx = f; f += kPool; s.p_dy = f; f += kPool; s.p_dz = f; f += kPool;
     s.sx = f; f += kPass; s.sy = f; f += kPass; s.sz = f; f += kPass; s.sdt = f; f += kPass; s.st = f; f += kPass; s.ob = f; f += kPass;
     s.hist = reinterpret_cast<uint32_t*>(f); f += kHistBins;
-    s.misc = reinterpret_cast<uint32_t*>(f); f += 24;
+    s.misc = reinterpret_cast<uint32_t*>(f); f += 16;
     uint8_t* b = reinterpret_cast<uint8_t*>(f);
     s.d2r = b; s.rcnt = b + kPass; s.rbase = b + 2 * kPass; s.rrank = b + 3 * kPass;
 #ifdef GF_TRACE
@@ -1470,13 +1465,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     const Smem s = carve(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: per-wave weight-stream bases stay in SGPRs
-    // Pool slot of this lane: the 128 rays of a pool are OWNED by the first 128 / kOwnerWaves lanes of kOwnerWaves waves.  Four waves x 32 lanes
-    // (round 4; two x 64 before): the march, the compositor and the refill are per-ray VALU code that runs beside a neighbour workgroup's MFMA
-    // stream, where the issue port is what it waits for -- on four SIMDs instead of two it gets twice the issue slots, and a wave waits for
-    // the slowest of 32 rays instead of 64.  Which lane owns a ray cannot change the ray's result (tools/frame_digests.py: byte-identical).
-    constexpr int kOwnLanes = kPool / kOwnerWaves;
-    const bool owner = wave < kOwnerWaves && lane < kOwnLanes;
-    const int slot = owner ? wave * kOwnLanes + lane : 0;
+    const bool owner = tid < kPool;
 #ifdef GF_TRACE
     const unsigned long long span_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long span_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1572,8 +1561,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         dg_round++;
 #endif
         // ------------------------------------------------------------------ refill empty pool slots from the queue
-        if (queue_open && wave < kOwnerWaves) {  // wave-uniform branch
-            const bool want = owner && ray < 0 && (uint32_t)slot < s.misc[15];
+        if (queue_open && wave < 2) {  // wave-uniform branch
+            const bool want = ray < 0 && (uint32_t)tid < s.misc[15];
             const unsigned long long m = __ballot(want);
             const uint32_t nw = (uint32_t)__popcll(m);
             uint32_t base = 0;
@@ -1593,30 +1582,23 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                         acc.r = a.image[(size_t)ray * 3]; acc.g = a.image[(size_t)ray * 3 + 1]; acc.b = a.image[(size_t)ray * 3 + 2];
                     }
                     r_done = 0;
-                    s.p_dx[slot] = d[0]; s.p_dy[slot] = d[1]; s.p_dz[slot] = d[2];
+                    s.p_dx[tid] = d[0]; s.p_dy[tid] = d[1]; s.p_dz[tid] = d[2];
                 }
             }
-            if (lane == 0) s.misc[20 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
+            if (lane == 0) s.misc[4 + wave] = (nw && base + nw >= s.misc[14]) ? 1u : 0u;  // this wave saw the end of the queue
         }
         GF_STAMP(1);
         // ------------------------------------------------------------------ pool census
         const bool alive = ray >= 0;
         unsigned long long amask = 0;
-        if (wave < kOwnerWaves) {
+        if (wave < 2) {
             amask = __ballot(alive);
-            if (lane == 0) s.misc[16 + wave] = (uint32_t)__popcll(amask);
+            if (lane == 0) s.misc[wave] = (uint32_t)__popcll(amask);
         }
         __syncthreads();
         GF_STAMP(2);
-        uint32_t n_pool = 0, below = 0, saw_end = 0;      // alive rays of the pool / of the owner waves below this one
-#pragma unroll
-        for (int w = 0; w < kOwnerWaves; w++) {
-            const uint32_t c = s.misc[16 + w];
-            n_pool += c;
-            below += w < wave ? c : 0u;
-            saw_end |= s.misc[20 + w];
-        }
-        if (queue_open && saw_end) queue_open = false;
+        const uint32_t n_pool = s.misc[0] + s.misc[1];
+        if (queue_open && (s.misc[4] | s.misc[5])) queue_open = false;
         if (n_pool == 0) {
             if (!queue_open) break;   // nothing alive, nothing left to fetch
             continue;                 // the queue still has entries: fetch again
@@ -1633,7 +1615,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         // ------------------------------------------------------------------ A. march
         uint32_t mcnt = 0, req = 0, rank = 0;
         if (alive) {
-            rank = below + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+            rank = (wave ? s.misc[0] : 0u) + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
             const uint32_t left = s.misc[13] - r_done;
             const uint32_t mine = n + (rank < extra ? 1u : 0u);
             req = mine < left ? mine : left;
@@ -1648,7 +1630,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 const float* o = a.rays_o + (size_t)ray * 3;
                 r_ox = o[0]; r_oy = o[1]; r_oz = o[2];
             }
-            const float r_dx = s.p_dx[slot], r_dy = s.p_dy[slot], r_dz = s.p_dz[slot];
+            const float r_dx = s.p_dx[tid], r_dy = s.p_dy[tid], r_dz = s.p_dz[tid];
             mcnt = gf::march_ray(a.mp, r_ox, r_oy, r_oz, r_dx, r_dy, r_dz, r_far, 0.0f, req + 1u, r_t,
                                 [&](uint32_t q, float x, float y, float z, float dt, float t_after, float t_at) {
                                     if (q >= req) { t_next = t_at; return; }
@@ -1669,7 +1651,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             if (mcnt > req) { mcnt = req; r_t = t_next; }
         }
         GF_STAMP(3);
-        if (owner) s.rcnt[slot] = (uint8_t)mcnt;
+        if (owner) s.rcnt[tid] = (uint8_t)mcnt;
         __syncthreads();
         GF_STAMP(4);
         if (wave == 0) {  // exclusive scan of 128 counts, two per lane
@@ -1688,9 +1670,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         __syncthreads();
         const uint32_t Mv = s.misc[2];
         if (alive) {
-            const uint32_t b = s.rbase[slot];
+            const uint32_t b = s.rbase[tid];
             const uint32_t base = rank * n + (rank < extra ? rank : extra);
-            for (uint32_t q = 0; q < mcnt; q++) { s.d2r[b + q] = (uint8_t)(base + q); s.rrank[b + q] = (uint8_t)slot; }
+            for (uint32_t q = 0; q < mcnt; q++) { s.d2r[b + q] = (uint8_t)(base + q); s.rrank[b + q] = (uint8_t)tid; }
         }
         if (tid == 0) { s.misc[10] += Mv; s.misc[11] += 1u; s.misc[12] += (Mv + 31) / 32; }
         GF_STAMP(5);
@@ -1720,8 +1702,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
         bool survivor = false;
         if (alive) {
             // this ray's sample count and first raw slot come back from LDS (the scan left them there): two registers less across the field
-            const uint32_t cnt = s.rcnt[slot];
-            const uint32_t base = cnt ? (uint32_t)s.d2r[s.rbase[slot]] : 0u;
+            const uint32_t cnt = s.rcnt[tid];
+            const uint32_t base = cnt ? (uint32_t)s.d2r[s.rbase[tid]] : 0u;
             bool died = false;
             uint32_t d = 0;
             for (uint32_t q = 0; q < cnt; q++) {
@@ -1731,7 +1713,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                     float* rec = a.diag + (size_t)s.dkey[base + q] * kDiagWords;
                     uint32_t* ru = reinterpret_cast<uint32_t*>(rec);
                     rec[0] = s.sx[base + q]; rec[1] = s.sy[base + q]; rec[2] = s.sz[base + q]; rec[3] = s.ob[base + q];
-                    ru[6] = a.diag_tag; ru[7] = blockIdx.x; ru[8] = dg_round; ru[9] = (uint32_t)s.rbase[slot] + q; ru[10] = Mv;
+                    ru[6] = a.diag_tag; ru[7] = blockIdx.x; ru[8] = dg_round; ru[9] = (uint32_t)s.rbase[tid] + q; ru[10] = Mv;
                     ru[11] = (n_pool << 8) | n;
                 }
 #endif
@@ -1762,7 +1744,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
                 if (!survivor) ray = -1;   // survivors keep the index until the list below has taken it
             }
         }
-        if (a.phase == 0 && wave < kOwnerWaves) {
+        if (a.phase == 0 && wave < 2) {
             const unsigned long long m = __ballot(survivor);
             const uint32_t ns = (uint32_t)__popcll(m);
             uint32_t base = 0;
