@@ -39,7 +39,7 @@ def sources():
 
 
 def headers():
-    return sorted(glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")))
+    return sorted(glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(HERE, "*.inc")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")))
 
 
 def _compile(src, force, extra=(), obj_dir=OBJ_DIR):

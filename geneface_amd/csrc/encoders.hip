@@ -1,6 +1,6 @@
 // Stand-alone encoder operators behind the `_gridencoder`, `_shencoder`, `_freqencoder` seams.
 //   grid : /root/reference/modules/radnerfs/encoders/gridencoder/src/gridencoder.cu:88-244, launch :370-400
-//   SH   : .../encoders/shencoder/src/shencoder.cu:28-68 (degree <= 4), launch :385-391
+//   SH   : .../encoders/shencoder/src/shencoder.cu:28-121 (degree <= 8; bands 4..7 table driven, sh_core.hpp::sh_high), launch :385-391
 //   freq : .../encoders/freqencoder/src/freqencoder.cu:30-58, launch :96-110
 #include <atomic>
 
@@ -122,15 +122,16 @@ __global__ void __launch_bounds__(kBlock) k_sh(const float* __restrict__ inputs,
     const float x = inputs[(size_t)b * 3], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
     float sh[16];
     gf::sh4(x, y, z, sh);
-    const uint32_t n = degree * degree;
+    const uint32_t n = degree * degree, n4 = n < 16u ? n : 16u;
     float* o = outputs + (size_t)b * n;
-    for (uint32_t i = 0; i < n; i++) o[i] = sh[i];
-    if (dy_dx) {   // [B, 3, degree^2]
+    for (uint32_t i = 0; i < n4; i++) o[i] = sh[i];
+    float* d = dy_dx ? dy_dx + (size_t)b * 3 * n : nullptr;   // [B, 3, degree^2]
+    if (d) {
         float gx[16], gy[16], gz[16];
         gf::sh4_grad(x, y, z, gx, gy, gz);
-        float* d = dy_dx + (size_t)b * 3 * n;
-        for (uint32_t i = 0; i < n; i++) { d[i] = gx[i]; d[n + i] = gy[i]; d[2 * n + i] = gz[i]; }
+        for (uint32_t i = 0; i < n4; i++) { d[i] = gx[i]; d[n + i] = gy[i]; d[2 * n + i] = gz[i]; }
     }
+    if (degree > 4) gf::sh_high(x, y, z, degree, o, d, d ? d + n : nullptr, d ? d + 2 * n : nullptr);   // bands 4..7, shencoder.cu:69-121,150-356
 }
 
 // shencoder.cu:359-383: grad_inputs[b][d] += sum_k grad[b][k] * dy_dx[b][d][k]
@@ -581,7 +582,7 @@ GF_EXPORT int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_o
 GF_EXPORT int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx, void* stream) {
     if (B == 0) return GF_OK;
     if (D != 3) return gf_set_error(GF_ERR_INVALID, "SH encoder only support input dim == 3");
-    if (degree < 1 || degree > 4) return gf_set_error(GF_ERR_UNSUPPORTED, "SH encoder: this build implements degree 1..4 (GeneFace uses 4)");
+    if (degree < 1 || degree > 8) return gf_set_error(GF_ERR_INVALID, "SH encoder only supports degree in [1, 8]");   // sphere_harmonics.py:70
     if (!inputs || !outputs) return gf_set_error(GF_ERR_INVALID, "sh_encode_forward: null pointer");
     hipLaunchKernelGGL(k_sh, dim3(gf_div_up(B, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), inputs, outputs, B, degree, dy_dx);
     return gf_check_launch("sh_encode_forward");
@@ -592,7 +593,7 @@ GF_EXPORT int gf_sh_encode_backward(const float* grad, const float* inputs, uint
                                     float* grad_inputs, void* stream) {
     (void)inputs;
     if (B == 0) return GF_OK;
-    if (D != 3 || degree < 1 || degree > 4) return gf_set_error(GF_ERR_INVALID, "sh_encode_backward: D must be 3, degree 1..4");
+    if (D != 3 || degree < 1 || degree > 8) return gf_set_error(GF_ERR_INVALID, "sh_encode_backward: D must be 3, degree 1..8");
     if (!grad || !dy_dx || !grad_inputs) return gf_set_error(GF_ERR_INVALID, "sh_encode_backward: null pointer");
     hipLaunchKernelGGL(k_sh_backward, dim3(gf_div_up(B * 3, (uint32_t)kBlock)), dim3(kBlock), 0, gf_stream(stream), grad, dy_dx, B, degree * degree, grad_inputs);
     return gf_check_launch("sh_encode_backward");

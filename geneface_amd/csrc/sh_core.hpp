@@ -1,6 +1,7 @@
 // Direction / frequency encodings shared by the op kernels and the fused field kernels.
 //   real spherical harmonics, bands 0..3 (16 values): contract = kernel_sh,
 //     /root/reference/modules/radnerfs/encoders/shencoder/src/shencoder.cu:50-68
+//   bands 4..7 (degrees 5..8 of the `_shencoder` seam; shencoder.cu:69-121 values, :150-356 derivatives): sh_high, table driven
 //   NeRF frequency encoding: contract = kernel_freq, .../freqencoder/src/freqencoder.cu:30-58
 #pragma once
 #include "common.hpp"
@@ -56,6 +57,60 @@ __device__ __forceinline__ void sh4_grad(float x, float y, float z, float (&gx)[
     gx[13] = k3b * (1 - 5 * z2); gz[13] = -10 * k3b * x * z;
     gx[14] = 2 * c14 * x * z; gy[14] = -2 * c14 * y * z; gz[14] = c14 * (x2 - y2);
     gx[15] = 3 * k3a * (y2 - x2); gy[15] = 6 * k3a * x * y;
+}
+
+// ---- bands 4..7 (basis functions 16..63): the op seam serves degree <= 8 like the reference's extension; GeneFace itself stops at 4.
+// The reference lists 48 polynomials and 144 partial derivatives term by term.  Here the basis is evaluated from its structure,
+//     Y_l^m = N_l^m Q_l^|m|(z) * { A_m (m > 0) | 1 | B_|m| (m < 0) },   A_m + i B_m = (x + i y)^m,   Q_l^m = d^m P_l / dz^m,
+// and because dQ_l^m/dz = Q_l^(m+1), dA_m/dx = m A_(m-1), dA_m/dy = -m B_(m-1), dB_m/dx = m B_(m-1), dB_m/dy = m A_(m-1), values
+// and all three partials come from one family of Horner polynomials in z and one (A, B) recurrence: ~26 Horner chains + 14 products
+// instead of 192 expressions.  Same polynomials (on R^3, x^2 + y^2 eliminated in favour of z: the representative the reference
+// differentiates), other association order: agrees with the reference's kernel to a few ulp of the output scale
+// (tests/test_gpu_vs_ref_kernels.py).  Tables: tools/gen_sh_tables.py (derived from the definition in exact rational arithmetic).
+#include "sh_high_tables.inc"
+
+__device__ __forceinline__ float sh_horner8(const float (&c)[8], float z) {
+    float acc = c[7];
+#pragma unroll
+    for (int k = 6; k >= 0; k--) acc = fmaf(acc, z, c[k]);
+    return acc;
+}
+
+// Writes out[16 .. degree^2) and, when gx != nullptr, the three derivative rows over the same index range.  degree in 5..8.
+__device__ __forceinline__ void sh_high(float x, float y, float z, uint32_t degree, float* __restrict__ out, float* __restrict__ gx,
+                                        float* __restrict__ gy, float* __restrict__ gz) {
+    float A[8], B[8];
+    A[0] = 1.0f; B[0] = 0.0f;
+#pragma unroll
+    for (int m = 1; m < 8; m++) {
+        A[m] = x * A[m - 1] - y * B[m - 1];
+        B[m] = x * B[m - 1] + y * A[m - 1];
+    }
+#pragma unroll
+    for (int l = 4; l < 8; l++) {
+        if ((uint32_t)l >= degree) break;
+        const int c0 = l * l + l;
+#pragma unroll
+        for (int m = 0; m <= l; m++) {
+            const float q = sh_horner8(kShHighQ[kShHighRow[l - 4] + m], z);
+            if (m == 0) {
+                out[c0] = q;
+            } else {
+                out[c0 + m] = q * A[m];
+                out[c0 - m] = q * B[m];
+            }
+            if (gx) {
+                const float dq = sh_horner8(kShHighDQ[kShHighRow[l - 4] + m], z);
+                if (m == 0) {
+                    gx[c0] = 0.0f; gy[c0] = 0.0f; gz[c0] = dq;
+                } else {
+                    const float qm = q * (float)m;
+                    gx[c0 + m] = qm * A[m - 1];  gy[c0 + m] = -qm * B[m - 1];  gz[c0 + m] = dq * A[m];
+                    gx[c0 - m] = qm * B[m - 1];  gy[c0 - m] = qm * A[m - 1];   gz[c0 - m] = dq * B[m];
+                }
+            }
+        }
+    }
 }
 
 // element c of the [D + 2*D*deg] frequency encoding of in[0..D):

@@ -122,7 +122,8 @@ int gf_grid_level_meta(uint32_t L, float S, uint32_t H, float* scale_out_host, u
  * `_freqencoder` modules/radnerfs/encoders/freqencoder/src/bindings.cpp, freqencoder.h:7
  * ---------------------------------------------------------------------------------------------- */
 
-/* sh_encode_forward (kernel shencoder.cu:28-356).  inputs [B,3], outputs [B,degree^2]; degree 1..4; dy_dx NULL or [B,3,degree^2]. */
+/* sh_encode_forward (kernel shencoder.cu:28-356).  inputs [B,3], outputs [B,degree^2]; degree 1..8 like the reference (bands 4..7: table driven,
+ * csrc/sh_core.hpp::sh_high); dy_dx NULL or [B,3,degree^2]. */
 int gf_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx, void* stream);
 /* sh_encode_backward (shencoder.h:10, kernel shencoder.cu:359-383).  grad_inputs [B,3] accumulates. */
 int gf_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t degree, const float* dy_dx,

@@ -20,7 +20,8 @@ CFLAGS = ["-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off"
 
 def build(force: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(SRC):
+    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(HERE, "sh_high_monomials.inc")))
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     cmd = ["gcc", *CFLAGS, SRC, "-o", OUT, "-lm"]
     subprocess.run(cmd, check=True)

@@ -160,7 +160,7 @@ class shencoder:
     def sh_encode_forward(inputs, outputs, B, D, Cc, dy_dx):
         rc = lib().orc_sh_encode_forward(_p(inputs, torch.float32), _p(outputs, torch.float32), _u(B), _u(D), _u(Cc))
         if rc != 0:
-            raise RuntimeError("SH oracle: D must be 3 and degree in [1,4]")
+            raise RuntimeError("SH oracle: D must be 3 and degree in [1,8]")
         if dy_dx is not None:
             lib().orc_sh_encode_dy_dx(_p(inputs, torch.float32), _p(dy_dx, torch.float32), _u(B), _u(Cc))
 

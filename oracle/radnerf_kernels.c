@@ -445,17 +445,42 @@ ORC_EXPORT void orc_grid_level_meta(uint32_t L, float S, uint32_t H, float* scal
     }
 }
 
-/* ---- encoders/shencoder/src/shencoder.cu:28-68 kernel_sh (forward), degree C in [1,4] ----
- * (degrees 5..8 exist in the reference, shencoder.cu:69-121; GeneFace only instantiates degree 4,
- *  radnerf.py:58 via encoding.py:8,22) */
+/* ---- encoders/shencoder/src/shencoder.cu:28-121 kernel_sh (forward), degree C in [1,8] ----
+ * Bands 0..3 (C <= 4, the only degree GeneFace instantiates: radnerf.py:58 via encoding.py:8,22) restate shencoder.cu:50-68 line by line.
+ * Bands 4..7 (shencoder.cu:69-121, derivatives :150-356) are NOT transcribed: the 48 polynomials are derived from the definition of the
+ * basis in exact rational arithmetic (tools/gen_sh_tables.py, which also checks orthonormality and the addition theorem) and evaluated here
+ * monomial by monomial in DOUBLE -- the value of the polynomial the reference's fp32 expression approximates, and a different algorithm
+ * from the product's factorised Horner form.  Pinned by tests/golden/sh_deg8.npz (the reference's own source expressions evaluated by
+ * tests/golden/make_golden.py in this container) and by the reference's running kernel on the MI355X (tests/test_gpu_vs_ref_kernels.py). */
+#include "sh_high_monomials.inc"
+
+static double orc_ipow(double v, unsigned e) { double r = 1.0; while (e--) r *= v; return r; }
+
+/* basis function k (16 <= k < 64) at (x, y, z): value and, when g != NULL, its three partial derivatives */
+static double orc_sh_high_eval(uint32_t k, double x, double y, double z, double* g) {
+    double v = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    for (int t = orc_sh_high_start[k - 16]; t < orc_sh_high_start[k - 15]; t++) {
+        const orc_sh_mono_t m = orc_sh_high_mono[t];
+        v += m.c * orc_ipow(x, m.ex) * orc_ipow(y, m.ey) * orc_ipow(z, m.ez);
+        if (g) {
+            if (m.ex) gx += m.c * m.ex * orc_ipow(x, m.ex - 1) * orc_ipow(y, m.ey) * orc_ipow(z, m.ez);
+            if (m.ey) gy += m.c * m.ey * orc_ipow(x, m.ex) * orc_ipow(y, m.ey - 1) * orc_ipow(z, m.ez);
+            if (m.ez) gz += m.c * m.ez * orc_ipow(x, m.ex) * orc_ipow(y, m.ey) * orc_ipow(z, m.ez - 1);
+        }
+    }
+    if (g) { g[0] = gx; g[1] = gy; g[2] = gz; }
+    return v;
+}
+
 ORC_EXPORT int orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C) {
     if (D != 3) return -1;
-    if (C < 1 || C > 4) return -2;
+    if (C < 1 || C > 8) return -2;
     const uint32_t C2 = C * C;
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < (int64_t)B; b++) {
         const float x = inputs[b * 3], y = inputs[b * 3 + 1], z = inputs[b * 3 + 2];
         float* o = outputs + (size_t)b * C2;
+        for (uint32_t k = 16; k < C2; k++) o[k] = (float)orc_sh_high_eval(k, x, y, z, NULL);
         const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
         o[0] = 0.28209479177387814f;
         if (C <= 1) continue;
@@ -475,7 +500,7 @@ ORC_EXPORT int orc_sh_encode_forward(const float* inputs, float* outputs, uint32
         o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
         o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
         o[14] = 1.4453057213202769f * z * (x2 - y2);
-        o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+        o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);   /* C >= 5: bands 4..7 were written above */
     }
     return 0;
 }
@@ -742,10 +767,10 @@ ORC_EXPORT int orc_grid_encode_backward(const float* grad_, const float* inputs_
     return 0;
 }
 
-/* d/dx, d/dy, d/dz of the 16 real SH polynomials of orc_sh_encode_forward (degree <= 4): dy_dx [B, 3, degree^2]. */
+/* d/dx, d/dy, d/dz of the real SH polynomials of orc_sh_encode_forward: dy_dx [B, 3, degree^2] (bands 4..7 from the monomial lists). */
 ORC_EXPORT int orc_sh_encode_dy_dx(const float* inputs, float* dy_dx, uint32_t B, uint32_t degree) {
-    if (degree < 1 || degree > 4) return -1;
-    const uint32_t C2 = degree * degree;
+    if (degree < 1 || degree > 8) return -1;
+    const uint32_t C2 = degree * degree, C4 = C2 < 16u ? C2 : 16u;
     const float k1 = 0.48860251190291987f, k2 = 1.0925484305920792f, k3a = 0.59004358992664352f, k3b = 0.45704579946446572f;
     const float a6 = 0.94617469575755997f, c8 = 0.54627421529603959f, c10 = 2.8906114426405538f, c12 = 0.3731763325901154f,
                 c14 = 1.4453057213202769f;
@@ -770,7 +795,12 @@ ORC_EXPORT int orc_sh_encode_dy_dx(const float* inputs, float* dy_dx, uint32_t B
         g[0][15] = 3 * k3a * (y2 - x2); g[1][15] = 6 * k3a * x * y;
         float* o = dy_dx + (size_t)b * 3 * C2;
         for (uint32_t d = 0; d < 3; d++)
-            for (uint32_t k = 0; k < C2; k++) o[d * C2 + k] = g[d][k];
+            for (uint32_t k = 0; k < C4; k++) o[d * C2 + k] = g[d][k];
+        for (uint32_t k = 16; k < C2; k++) {
+            double gh[3];
+            orc_sh_high_eval(k, x, y, z, gh);
+            for (uint32_t d = 0; d < 3; d++) o[d * C2 + k] = (float)gh[d];
+        }
     }
     return 0;
 }

@@ -110,13 +110,23 @@ def cases():
     d = d / d.norm(dim=-1, keepdim=True)
     gsh = torch.randn(B, 16, generator=g)
 
-    def sh(m, dev):
-        SH = m[2]
-        out, dy = torch.empty(B, 16, device=dev), torch.empty(B, 48, device=dev)
-        SH.sh_encode_forward(d.to(dev), out, B, 3, 4, dy)
-        gi = torch.zeros(B, 3, device=dev)
-        SH.sh_encode_backward(gsh.to(dev), d.to(dev), B, 3, 4, dy, gi)
-        return {"out": out, "dy_dx": dy, "g_in": gi}
+    def sh_case(degree):
+        """degree 4 is GeneFace's; 5..8 are the rest of the extension's range (shencoder.cu:69-121,150-356), on unit directions and on free
+        points of R^3 (the polynomials are differentiated there, not on the sphere)."""
+        n = degree * degree
+        pts = d if degree == 4 else torch.cat([d[:B // 2], torch.rand(B // 2, 3, generator=torch.Generator().manual_seed(degree)) * 2 - 1])
+        gk = gsh if degree == 4 else torch.randn(B, n, generator=torch.Generator().manual_seed(100 + degree))
+
+        def run(m, dev):
+            SH = m[2]
+            out, dy = torch.empty(B, n, device=dev), torch.empty(B, 3 * n, device=dev)
+            SH.sh_encode_forward(pts.to(dev), out, B, 3, degree, dy)
+            gi = torch.zeros(B, 3, device=dev)
+            SH.sh_encode_backward(gk.to(dev), pts.to(dev), B, 3, degree, dy, gi)
+            return {"out": out, "dy_dx": dy, "g_in": gi}
+        return run
+
+    sh = sh_case(4)
 
     xf = torch.rand(B, 2, generator=g) * 2 - 1
     gfq = torch.randn(B, 42, generator=g)
@@ -192,7 +202,8 @@ def cases():
             "grad_tv3_hash": grad_tv(3, 0, he, hm.offsets),
             "near_far": near_far, "march1": march(1), "march2": march(2), "march8": march(8), "maintenance": maintenance,
             "grid3_tiled_lin": grid_fwd(3, 1, 0, pe, po), "grid2_tiled_lin": grid_fwd(2, 1, 0, ae, ao),
-            "grid3_hash_smooth": grid_fwd(3, 0, 1, he, hm.offsets), "sh": sh, "freq": freq, "train": train}
+            "grid3_hash_smooth": grid_fwd(3, 0, 1, he, hm.offsets), "sh": sh, "sh5": sh_case(5), "sh6": sh_case(6), "sh7": sh_case(7), "sh8": sh_case(8),
+            "freq": freq, "train": train}
 
 
 def diff(a, b, name):

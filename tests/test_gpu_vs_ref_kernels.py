@@ -51,7 +51,7 @@ def report():
 
 
 def _tol(case, name, contract):
-    fam = "grid" if case.startswith("grid") else ("grad" if case.startswith("grad_tv") else case)
+    fam = "grid" if case.startswith("grid") else ("grad" if case.startswith("grad_tv") else ("sh" if case.startswith("sh") else case))
     t = REL_TOL.get((fam, name), 2e-6)
     return t * (OFF_FACTOR if contract == "off" else 1.0)
 
@@ -75,7 +75,20 @@ def test_every_op_vs_running_reference_kernels(report, who, contract):
             else:
                 assert d["max"] <= _tol(case, name, contract) * max(d["scale"], 1.0), (key, name, d)
             checked += 1
-    assert checked >= 60
+    assert checked >= 72
+
+
+def test_sh_every_degree_of_the_extension(report):
+    """Seam 1 serves the whole range of the reference's `_shencoder` (sphere_harmonics.py:70 asserts 1..8): degrees 5..8 -- values, dy_dx,
+    backward -- against the reference's own kernel running beside them.  The product evaluates bands 4..7 from the structure of the basis
+    (Horner polynomials in z x the (x + iy)^m recurrence, sh_core.hpp::sh_high), the oracle from expanded monomials in double, the reference
+    from 192 spelled-out expressions: three algorithms, one polynomial each -- a few ulp of the output scale."""
+    for deg in (5, 6, 7, 8):
+        for who in ("oracle", "product"):
+            d = report[f"sh{deg}:{who}_vs_ref_fast"]
+            for name in ("out", "dy_dx", "g_in"):
+                assert "shape" not in d[name] and d[name]["n"] > 0, (deg, who, name, d[name])
+                assert d[name]["max"] <= 2e-6 * max(d[name]["scale"], 1.0), (deg, who, name, d[name])
 
 
 def test_marcher_is_bit_identical_to_the_reference_build(report):
