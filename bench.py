@@ -64,7 +64,11 @@ def parse(argv=None):
     ap.add_argument("--head-only", action="store_true", help="BASELINE.json configs[1]: May lm3d_radnerf head-only (default: configs[2], head+torso)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed loop until this much time has been measured; the line reports the median repetition")
     ap.add_argument("--repeats", type=int, default=0, help="fixed number of repetitions of the K-step loop (0 = from --min-seconds)")
-    ap.add_argument("--no-stress", action="store_true", help="skip the sensitivity legs (thin-density and heavy fixtures, head-only sub-block)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the sensitivity legs (thin-density and heavy fixtures, head-only sub-block, variants, latency)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (the other RAD-NeRF configurations the reference ships)")
+    ap.add_argument("--details", default=None, help="where the full record (per-frame lists, notes) is written; the stdout line is its compact form "
+                                                    "(default: gpurun_out/bench_details[_<precision>].json beside this file)")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact line (round 4's format, ~20 KB)")
     ap.add_argument("--selftest", action="store_true", help="control-flow self-test of the N-rank launch on a box without N GPUs: gloo instead of RCCL and a "
                                                             "pipeline stand-in that renders nothing; the line says so (data = 'selftest: no rendering') and is not a measurement")
     args = ap.parse_args(argv)
@@ -94,11 +98,24 @@ def host_inputs(sample):
     return {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in sample.items()}
 
 
-def oracle_render(hp, sd, inp, torso, rays_d=None):
-    """oracle/radnerf_ref.render (CPU restatement of the reference's render path: torch-fp32 layers over the C kernels) on host inputs."""
+def oracle_render(hp, sd, inp, torso, rays_d=None, branch=False):
+    """oracle/radnerf_ref.render (CPU restatement of the reference's render path: torch-fp32 layers over the C kernels) on host inputs.
+    `branch`: the outcome of the per-frame coin of a torso_head_aware model (radnerf_torso.py:175-179)."""
     from oracle import radnerf_ref as R
     return R.render(sd, hp, inp["rays_o"], inp["rays_d"] if rays_d is None else rays_d, inp["cond_wins"], inp["bg_coords"], inp["pose"],
-                    inp["bg_img"], torso=torso)
+                    inp["bg_img"], torso=torso, head_aware_branch=branch)
+
+
+def coin(hp, seed):
+    """torso_head_aware models draw random.random() < 0.5 once per rendered frame.  Seed the stream, look at the draw the next render will
+    make, re-seed: the product then makes that very draw, and the oracle is told its outcome.  False (and no seeding) for other models."""
+    if not hp.get("torso_head_aware", False):
+        return False
+    import random
+    random.seed(seed)
+    c = random.random() < 0.5
+    random.seed(seed)
+    return c
 
 
 def set_cpu_threads(t):
@@ -175,16 +192,19 @@ def parity_vs_oracle(pipe, hp, sd, torso, frames=PARITY_FRAMES, clock=None, graz
         with torch.no_grad():
             smp = pipe.sample(i)
             inp = host_inputs(smp)
+            br = coin(hp, 7000 + i)      # head-aware variants: every render of frame i below makes this draw, the oracle is told its outcome
             hit = cache.get(i) if cache is not None else None
             if hit is not None and all(torch.equal(hit["inp"][k], inp[k]) for k in ("rays_o", "rays_d", "cond_wins", "pose", "bg_coords")):
                 ref = hit["ref"]          # another tier of the same model on the same fixture frame: the same input bits, the same oracle frame
             else:
-                run = (lambda: oracle_render(hp, sd, inp, torso))
+                run = (lambda: oracle_render(hp, sd, inp, torso, branch=br))
                 ref = clock.run(run) if clock is not None else run()
                 if cache is not None:
                     cache[i] = {"inp": inp, "ref": ref}
             rgb_ref = ref["rgb_map"].reshape(-1, 3)
+            coin(hp, 7000 + i)
             out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+            coin(hp, 7000 + i)
             u8 = pipe.render_frame(i)
             pipe.wait()
             u8 = u8.clone().reshape(-1, 3).int()
@@ -206,7 +226,7 @@ def parity_vs_oracle(pipe, hp, sd, torso, frames=PARITY_FRAMES, clock=None, graz
         if n_off:
             with torch.no_grad():
                 kin = host_inputs(pipe.kernel_sample(i))
-            kref = oracle_render(hp, sd, kin, torso)
+            kref = oracle_render(hp, sd, kin, torso, branch=br)
             k8 = (kref["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8).int()
             still = int(((u8 - k8).abs() > 1).any(dim=1).sum())      # over the WHOLE frame, not just the flagged pixels
             rec["pose_mode_unexplained_on_kernel_rays"] = still
@@ -216,7 +236,7 @@ def parity_vs_oracle(pipe, hp, sd, torso, frames=PARITY_FRAMES, clock=None, graz
             rd = inp["rays_d"]
             moved = torch.zeros(rgb_ref.shape[0])
             for toward in (float("inf"), float("-inf")):
-                pr = oracle_render(hp, sd, inp, torso, rays_d=torch.nextafter(rd, torch.full_like(rd, toward)))
+                pr = oracle_render(hp, sd, inp, torso, rays_d=torch.nextafter(rd, torch.full_like(rd, toward)), branch=br)
                 moved = torch.maximum(moved, (pr["rgb_map"].reshape(-1, 3) - rgb_ref).abs().max(dim=1).values)
             g = moved > GRAZE_MOVE
             rec["grazing_pixels"] = int(g.sum())
@@ -475,6 +495,7 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
         parity = parity_vs_oracle(ppipe, hp, sd, torso, pframes, clock, grazing=not args.no_grazing, cache=cache)
         cpu = clock.result(f"{'head+torso' if torso else 'head-only'} {args.size}x{args.size}")
         cpu["legacy_nerf"] = legacy_nerf_baseline(seq)
+        set_cpu_threads(cpu["cores"])      # the secondary legs' oracle frames run at the count the sweep found best (128 threads: 3x slower)
         del ppipe
     rank_parity = None
     if real and ((world > 1 and not args.no_cpu_baseline) or args.rank_parity):
@@ -520,7 +541,10 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
                             "parity_first_frame": rank_parity,
                             "note": "fps: each rank's own clock over its K frames (median pass); `value` uses the max over ranks of every pass.  "
                                     "replica_checksum: int64 sum of the bit patterns of every parameter and buffer after the RCCL broadcast"}
-        if roofline and roofline.get("samples_per_frame"):
+        apply_rank_parity_guard(line, rank_parity)
+        if line["per_rank"]["replica_checksum_equal"] is False and line["value"] is not None:      # the broadcast did not deliver rank 0's weights everywhere
+            line["value_withheld"], line["value"], line["error"] = line["value"], None, "replica checksums differ across ranks after the weight broadcast"
+        if roofline and roofline.get("samples_per_frame") and line["value"] is not None:
             # fixtures differ in samples per frame (0.86 M here, 1.6 M on the heavy one): this rate is what compares across them
             line["msamples_per_s"] = roofline["samples_per_frame"] * (K / dt) * world / 1e6
         if roofline and args.precision == "fp32" and roofline.get("samples_per_frame") and world == 1:
@@ -552,6 +576,9 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
                     line["head_only"] = leg(head_only_leg, args, job, two)
                 if args.precision == "fp32":
                     line["split_tier"] = leg(split_tier_leg, args, job, hp, torso, seq, sd, pframes if parity else [], cache)
+                    if torso and not args.no_variants:
+                        line["variants"] = leg(variants_leg, args, job, bool(parity), line["value"])
+                    line["latency"] = leg(latency_leg, args, job, hp, torso, seq, sd)
                 if not args.no_train:
                     torch.cuda.synchronize()
                     line["train_step"] = leg(train_step_leg, args, job)
@@ -559,12 +586,273 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
         if emit is not None:
             emit(line)
         else:
+            out_line = line
+            if not args.full_line:
+                path = write_details(args, line)
+                out_line = compact_line(line, path)
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
+            os.write(json_fd, (json.dumps(out_line) + "\n").encode())
     job.close()
 
 
+# ------------------------------------------------------------------------------------------------ the stdout line
+def write_details(args, line):
+    """The FULL record -- per-frame parity lists, the example frame's schedule, every note -- goes to a side file and to stderr; stdout
+    carries its compact form (the driver keeps `config`, `roofline`, `cpu_baseline` and a 4 KB tail of a line that had grown to
+    15 KB, so the headline parity number survived only as a key name)."""
+    path = args.details
+    if path is None:
+        d = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+        except OSError:
+            d = "/tmp"
+        path = os.path.join(d, "bench_details.json" if args.precision == "fp32" else f"bench_details_{args.precision}.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+    except OSError as e:
+        path = f"(not written: {e})"
+    sys.stderr.write("bench.py full record:\n" + json.dumps(line) + "\n")
+    return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def _sig(v, n=3):
+    return float(f"{v:.{n}g}") if isinstance(v, float) else v
+
+
+def parity_row(p):
+    """[max_abs_rgb, frames, pose-mode pixels flagged, pose-mode pixels unexplained] of a parity block (config.parity.legs_columns)."""
+    if not p:
+        return None
+    if "error" in p:
+        return {"error": p["error"][:100]}
+    return [_sig(p["max_abs_rgb"]), p["frames"], p["pose_mode"]["pixels_off_by_more_than_1_lsb"], p["pose_mode"]["unexplained_after_oracle_on_kernel_rays"]]
+
+
+def parity_summary(p):
+    """The five numbers of a parity block (parity_vs_oracle): enough to judge it without the per-frame list."""
+    if not p:
+        return None
+    if "error" in p:
+        return {"error": p["error"][:120]}
+    out = {"max_abs_rgb": p["max_abs_rgb"], "frames": p["frames"], "tolerance": 1e-4,
+           "pose_mode_flagged": p["pose_mode"]["pixels_off_by_more_than_1_lsb"], "pose_mode_unexplained": p["pose_mode"]["unexplained_after_oracle_on_kernel_rays"]}
+    if "grazing" in p:
+        out["grazing_pixels"] = p["grazing"]["pixels"]
+    return out
+
+
+def compact_line(full, details_path):
+    """The stdout line: every number the contract, DESIGN.md section 5 and the judge read, none of the per-frame lists or prose (< 4 KB).
+    `config.parity` carries the headline parity summary AND one row per sub-leg, because `config` is what the driver's record keeps whole."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "repeats", "timed_region_s", "msamples_per_s", "host_enqueue_ms_per_step", "error", "value_withheld")
+    line = {k: _r(full[k]) for k in keep if k in full}
+    cfg = {k: v for k, v in full["config"].items() if k not in ("timing", "cond_encoder", "repeats")}
+    legs = {}
+    for name in ("split_tier", "stress_fixture", "heavy_fixture", "head_only"):
+        blk = full.get(name)
+        if isinstance(blk, dict) and blk.get("parity"):
+            legs[name] = parity_row(blk["parity"])
+    var = full.get("variants")
+    if isinstance(var, dict) and "error" not in var:
+        for name, rec in var.items():
+            if isinstance(rec, dict) and rec.get("parity"):
+                legs["variant:" + name] = parity_row(rec["parity"])
+                if rec.get("parity_split_tier"):
+                    legs["variant:" + name + ":split"] = parity_row(rec["parity_split_tier"])
+    tr = full.get("train_step")
+    head = parity_summary(full.get("parity"))
+    if head is not None:
+        head["max_abs_rgb"] = _sig(head["max_abs_rgb"])
+        head["psnr_db"] = _r(full["parity"]["psnr_db"], 2)
+        w = full["parity"].get("worst") or {}
+        head["worst_frame_pixel"] = [w.get("frame")] + list(w.get("pixel") or [])
+        head["frame_indices"] = full["parity"].get("frame_indices")
+        if legs:
+            rows = [v for v in legs.values() if isinstance(v, list)]
+            head["legs_columns"] = ["max_abs_rgb", "frames", "pose_mode_flagged", "pose_mode_unexplained"]
+            head["legs"] = legs
+            head["all_legs_max_abs_rgb"] = max([head["max_abs_rgb"]] + [v[0] for v in rows])
+            head["all_legs_unexplained"] = head["pose_mode_unexplained"] + sum(v[3] for v in rows)
+        if isinstance(tr, dict) and isinstance(tr.get("gradient_parity"), dict):
+            head["train_step_gradients_worst_relative_l2"] = _sig(tr["gradient_parity"].get("worst_relative_l2"))
+    cfg["parity"] = head
+    line["config"] = cfg
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        rk = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_stale", "kernel", "launches", "avg_launch_ms",
+              "kernel_ms_per_frame", "samples_per_frame", "samples_composited_per_frame", "tile_fill", "flop_per_sample", "algorithmic_bytes_per_launch",
+              "frac_composited", "mfma_executed_frac", "frames_profiled", "mfma_tflops_f32_equivalent", "note")
+        rr = {k: _r(r[k]) for k in rk if k in r}
+        if isinstance(r.get("pipelined"), dict):
+            rr["pipelined"] = {"achieved": _r(r["pipelined"]["achieved"]), "frac": _r(r["pipelined"]["frac"])}
+        if isinstance(r.get("mfma"), dict):
+            rr["mfma"] = {k: _r(v) for k, v in r["mfma"].items() if k != "note"}
+        m = r.get("marcher")
+        if isinstance(m, dict):
+            rr["marcher"] = {"kernel": "k_frame_init", "ms": _r(m.get("ms")), "achieved": _r(m.get("achieved")), "peak": m.get("peak"), "unit": m.get("unit"),
+                             "frac": _r(m.get("frac")), "bound": "instruction issue"}
+        line["roofline"] = rr
+    else:
+        line["roofline"] = r
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        line["cpu_baseline"] = {"value": _r(c["value"]), "unit": c["unit"], "cores": c["cores"], "host_cores": c.get("host_cores"), "kind": c["kind"],
+                                "sample": c["sample"][:160], "s_per_frame_by_threads": c.get("s_per_frame_by_threads"),
+                                "legacy_nerf_fps": _r(c["legacy_nerf"]["value"], 5) if isinstance(c.get("legacy_nerf"), dict) and "value" in c["legacy_nerf"] else None}
+    else:
+        line["cpu_baseline"] = c
+    if isinstance(var, dict):
+        line["variants"] = {name: ({"fps": _r(rec.get("value"), 1), "vs_default": _r(rec.get("vs_default"), 3), "frac": _r(rec.get("roofline_frac")),
+                                    "samples_per_frame": _r(rec.get("samples_per_frame"), 0), "split_fps": _r(rec.get("split_tier_value"), 1),
+                                    "max_abs_rgb": _sig((rec.get("parity") or {}).get("max_abs_rgb"))} if isinstance(rec, dict) and "error" not in rec
+                                   else {"error": str(rec.get("error") if isinstance(rec, dict) else rec)[:160]}) for name, rec in var.items()} \
+            if "error" not in var else {"error": var["error"][:200]}
+
+    def small(name, keys):
+        blk = full.get(name)
+        if isinstance(blk, dict):
+            line[name] = {"error": blk["error"][:200]} if "error" in blk and blk.get("value") is None and blk.get("ms_per_step") is None \
+                else {k: _r(blk[k]) for k in keys if k in blk and not isinstance(blk[k], (dict, list))}
+    small("split_tier", ("value", "unit", "ms_per_step", "frames_in_flight", "kernel_ms_per_frame"))
+    if isinstance(full.get("split_tier"), dict) and isinstance(full["split_tier"].get("mfma"), dict):
+        line["split_tier"]["mfma_frac"] = _r(full["split_tier"]["mfma"]["frac"])
+    small("stress_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
+    small("heavy_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
+    small("head_only", ("value", "ms_per_step"))
+    small("with_png", ("value", "frames", "png_workers", "png_MB_per_frame"))
+    lat = full.get("latency")
+    if isinstance(lat, dict):
+        line["latency"] = {"error": lat["error"][:200]} if "error" in lat else \
+            {p: {m: {k: _r(v, 3) for k, v in lat[p][m].items() if k != "unit"} for m in ("one_in_flight", "pipelined") if m in lat[p]} for p in ("fp32", "split") if p in lat}
+    if isinstance(tr, dict):
+        line["train_step"] = {"ms_per_step": _r(tr.get("ms_per_step"), 3), "steps_per_s": _r(tr.get("steps_per_s"), 2),
+                              "reference_kernels_ms_per_step": _r((tr.get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2),
+                              "speedup_vs_reference_kernels": _r(tr.get("speedup_vs_reference_kernels"), 2), "error": tr.get("error")}
+    pr = full.get("per_rank")
+    if isinstance(pr, dict):
+        pf = pr.get("parity_first_frame")
+        line["per_rank"] = {"fps": [_r(v, 1) for v in pr["fps"]], "fps_min": _r(pr["fps_min"], 1), "fps_max": _r(pr["fps_max"], 1), "frames": pr["frames"],
+                            "replica_checksum_equal": pr["replica_checksum_equal"],
+                            "parity_first_frame": ({k: pf[k] for k in ("frame", "max_abs_rgb", "max_abs_rgb_by_rank", "identical_across_ranks", "tolerance", "error") if k in pf}
+                                                   if isinstance(pf, dict) else pf)}
+    line["details"] = details_path
+    return line
+
+
 HEAVY_RADIUS, HEAVY_SIGMA_SCALE = 2.75, 0.3
+VARIANT_NAMES = ("hash", "hash_smoothstep", "smoothstep", "head_aware", "audio")
+VARIANT_PARITY_FRAMES = (14, 24)
+
+
+def variants_leg(args, job, parity_on, headline_fps):
+    """Every RAD-NeRF configuration the reference ships besides the May default (geneface_amd.hparams.VARIANTS: hashed grids
+    lm3d_radnerf_hash.yaml:8, + smoothstep lm3d_radnerf_hash_smoothstep.yaml:8-9, smoothstep on tiled grids lm3d_radnerf_smoothstep.yaml:8,
+    lm3d_radnerf_torso_head_aware.yaml:9, and the audio-driven egs_bases/radnerf/radnerf.yaml:4-7 -- 44 x 16 windows, smo_win 8, the Obama
+    identity): the same workload (512x512 head+torso, K frames) on each -- fps on the exact-fp32 tier, the head kernel's roofline fraction,
+    samples per frame, fps on the split tier, and parity against the oracle on two frames of the parity fixture (identical device bits)."""
+    import torch
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    n = args.steps + args.warmup
+    out = {}
+    for name in VARIANT_NAMES:
+        try:
+            hp = HP.variant_hparams(name, True)
+            seed = 1000 if name == "audio" else 0
+            sd = S.make_state_dict(hp, True, seed=seed)
+            seq = S.make_sequence(n, args.size, args.size, hp, seed=seed)
+            rec = {"config": HP.VARIANTS[name][1][0]}
+            for prec in ("fp32", "split"):
+                pipe = build_pipe(args, job, hp, True, seq, sd, (0, n), precision=prec)
+                with torch.no_grad():
+                    for i in range(args.warmup):
+                        pipe.render_frame(i)
+                    dt, dts = timed_loop(job, pipe, args.warmup, args.steps, args)
+                    if prec == "fp32":
+                        r = measure_roofline(pipe, args.impl, args.warmup, min(4, args.steps), PEAK_F32_MFMA_TFLOPS, precision="fp32")
+                        rec.update({"value": args.steps / dt, "unit": "frames/s", "vs_default": args.steps / dt / headline_fps if headline_fps else None,
+                                    "roofline_frac": r.get("frac"), "kernel_ms_per_frame": r.get("kernel_ms_per_frame"),
+                                    "samples_per_frame": r.get("samples_per_frame"), "tile_fill": r.get("tile_fill"),
+                                    "frames_in_flight": pipe.in_flight, "cond_encoder_batched": getattr(pipe, "_pre", None) is not None})
+                    else:
+                        rec["split_tier_value"] = args.steps / dt
+                del pipe
+            if parity_on:
+                pseq = S.make_sequence(PARITY_T, args.size, args.size, hp, seed=seed)
+                par, cache = {}, {}      # the split tier is compared with the oracle frames the fp32 tier was (same input bits)
+                for prec in ("fp32", "split"):
+                    pp = build_pipe(args, job, hp, True, pseq, sd, (0, PARITY_T), precision=prec)
+                    par[prec] = parity_vs_oracle(pp, hp, sd, True, VARIANT_PARITY_FRAMES, grazing=False, cache=cache)
+                    del pp
+                rec["parity"] = par["fp32"]
+                rec["parity_split_tier"] = par["split"]
+            out[name] = rec
+        except Exception as e:      # noqa: BLE001  (one variant must not cost the others)
+            import traceback
+            out[name] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc(limit=3)[-500:]}
+    return out
+
+
+def latency_leg(args, job, hp, torso, seq, sd):
+    """The viewer's shape (inference/nerfs/radnerf_gui.py: one frame, wait for it, show it) and the cost of pipelining in frame latency.
+      one_in_flight   render_frame(i); wait() -- host clock per frame: enqueue + every kernel of the frame alone on the GPU + the 768 KB D2H;
+      pipelined       the headline configuration (3-4 frames in flight): per frame the DEVICE time between its stream reaching the frame and
+                      its D2H copy finishing (HIP events on the frame's stream) -- the small kernels of a frame wait for CU slots behind the
+                      other frames' persistent head grids, so a frame takes longer to cross the GPU than it does alone."""
+    import torch
+    n = min(args.steps, 60)
+    out = {}
+
+    def pct(v, q):
+        v = sorted(v)
+        return v[min(len(v) - 1, int(q * len(v)))]
+    for prec in ("fp32", "split"):
+        from geneface_amd.infer import FramePipeline
+        model = build_pipe(args, job, hp, torso, seq, sd, (0, args.warmup + n), precision=prec).model
+        pipe = FramePipeline(model, hp, seq, job.dev, frames=(0, args.warmup + n), impl=args.impl, in_flight=1)
+        lat = []
+        with torch.no_grad():
+            for i in range(args.warmup):
+                pipe.render_frame(i)
+            pipe.wait()
+            for rep in range(3):
+                for i in range(args.warmup, args.warmup + n):
+                    t0 = time.perf_counter()
+                    pipe.render_frame(i)
+                    pipe.wait()
+                    lat.append((time.perf_counter() - t0) * 1e3)
+        rec = {"one_in_flight": {"value": 1e3 * len(lat) / sum(lat), "unit": "frames/s", "latency_ms_p50": pct(lat, 0.5), "latency_ms_p99": pct(lat, 0.99),
+                                 "frames": len(lat)}}
+        pipe2 = FramePipeline(model, hp, seq, job.dev, frames=(0, args.warmup + n), impl=args.impl)
+        with torch.no_grad():
+            for i in range(args.warmup):
+                pipe2.render_frame(i)
+            pipe2.wait()
+            pipe2.frame_timing = []
+            t0 = time.perf_counter()
+            for rep in range(3):
+                pipe2.prepare(args.warmup, args.warmup + n)
+                for i in range(args.warmup, args.warmup + n):
+                    pipe2.render_frame(i)
+            pipe2.wait()
+            wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dev = [a.elapsed_time(b) for _, a, b in pipe2.frame_timing]
+            pipe2.frame_timing = None
+        rec["pipelined"] = {"value": len(dev) / wall, "unit": "frames/s", "frames_in_flight": pipe2.in_flight, "device_ms_per_frame_p50": pct(dev, 0.5),
+                            "device_ms_per_frame_p99": pct(dev, 0.99), "frames": len(dev)}
+        out[prec] = rec
+    out["note"] = ("one_in_flight = the viewer path (render, wait, show); pipelined = throughput mode: a frame's small kernels queue behind the other "
+                   "frames' persistent head grids (every VGPR and 156 of 160 KB of LDS per CU are theirs), so stream priorities cannot lift them -- "
+                   "a wave cannot be placed on a CU that has no free registers, whatever its queue's priority")
+    return out
 
 
 def fixture_leg(args, job, hp, torso, seq, sd_kw, parity_frames, what, radius=None):
@@ -756,13 +1044,41 @@ def every_rank_parity(args, job, hp, torso, sd_rank0):
         try:
             set_cpu_threads(max(1, min(16, (os.cpu_count() or 8) // job.world)))      # torchrun exports OMP_NUM_THREADS=1 for N > 1
             ref = oracle_render(hp, sd_rank0, host_inputs(smp), torso)["rgb_map"].reshape(-1)
-            errs = [float((r.cpu() - ref).abs().max()) for r in rows]
-            out = {"frame": int(i), "max_abs_rgb_by_rank": errs, "max_abs_rgb": max(errs), "identical_across_ranks": all(torch.equal(rows[0], r) for r in rows),
-                   "tolerance": 1e-4}
+            out = judge_rank_frames([r.cpu() for r in rows], ref, int(i))
         except Exception as e:      # noqa: BLE001  (the other ranks wait in the barrier below: never leave them there)
             out = {"error": f"{type(e).__name__}: {e}"}
     job.barrier()
     return out
+
+
+RANK_PARITY_TOL = 1e-4
+
+
+def judge_rank_frames(rows, ref, frame):
+    """rows[r] = rank r's fp32 frame of the common fixture frame (flattened), ref = the oracle's: per-rank error, and whether the replicas
+    produced the SAME BYTES (same weights after the broadcast, same library, same inputs: they must)."""
+    import torch
+    errs = [float((r - ref).abs().max()) for r in rows]
+    differing = [k for k, r in enumerate(rows) if not torch.equal(rows[0], r)]
+    return {"frame": frame, "max_abs_rgb_by_rank": errs, "max_abs_rgb": max(errs), "identical_across_ranks": not differing,
+            "ranks_differing_from_rank0": differing, "tolerance": RANK_PARITY_TOL}
+
+
+def apply_rank_parity_guard(line, rank_parity):
+    """A line whose ranks disagree, or whose common frame is not the oracle's picture, is not a measurement: `value` becomes null (the
+    number is kept beside it as `value_withheld`) and `error` says why."""
+    if rank_parity is None:
+        return line
+    why = None
+    if "error" in rank_parity:
+        why = f"every-rank parity check failed to run: {rank_parity['error']}"
+    elif not rank_parity.get("identical_across_ranks", False):
+        why = f"the ranks' frames of fixture frame {rank_parity.get('frame')} are not byte-identical (ranks {rank_parity.get('ranks_differing_from_rank0')} differ from rank 0)"
+    elif not (rank_parity.get("max_abs_rgb", 1.0) <= rank_parity.get("tolerance", RANK_PARITY_TOL)):
+        why = f"fixture frame {rank_parity.get('frame')}: max|d rgb| {rank_parity.get('max_abs_rgb'):.3g} against the oracle exceeds the tolerance {rank_parity.get('tolerance')}"
+    if why:
+        line["value_withheld"], line["value"], line["error"] = line.get("value"), None, why
+    return line
 
 
 def png_leg(pipe, first, n):
@@ -798,17 +1114,31 @@ def png_leg(pipe, first, n):
 def pmc_traffic():
     """HBM bytes per k_head_phase launch from the newest committed PMC summary (separate `rocprofv3 --pmc FETCH_SIZE` /
     `--pmc WRITE_SIZE` passes of this same command, tools/gpu_round.sh + tools/pmc_summary.py; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside the timed run."""
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside the timed run, so the figure is read from a file --
+    and says so: `stale` is True unless the summary carries the digest of the kernel sources this process was built from
+    (geneface_amd/csrc/build.py::source_digest, stamped by tools/pmc_summary.py at collection time)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")))
+    try:
+        from geneface_amd.csrc.build import source_digest
+        now = source_digest()
+    except Exception:      # noqa: BLE001
+        now = None
+
+    def round_no(path):
+        import re
+        m = re.search(r"round(\d+)", path)
+        return int(m.group(1)) if m else -1
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")), key=lambda q: (round_no(q), os.path.basename(q)))
     for path in reversed(files):
         try:
-            d = json.load(open(path)).get("k_head_phase")
+            doc = json.load(open(path))
+            d = doc.get("k_head_phase")
             if d and "fetch_MB_x2" in d and "write_MB_raw" in d:
-                return (d["fetch_MB_x2"] + d["write_MB_raw"]) * 1e6, os.path.relpath(path, ROOT)
+                stamp = doc.get("_source_digest")
+                return (d["fetch_MB_x2"] + d["write_MB_raw"]) * 1e6, os.path.relpath(path, ROOT), not (stamp is not None and stamp == now)
         except (OSError, ValueError):
             continue
-    return None, None
+    return None, None, None
 
 
 def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
@@ -851,7 +1181,7 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
                              "note": "fp32-equivalent algorithmic FLOPs / (f16 dense peak / 3): the matrix pipe is a third busy; the round is gathers, "
                                      "f32 <-> split conversions, march / composite and barriers (profiles/round4/r4e_head_timeline_split.txt)"}
             return r
-        r["traffic"], r["traffic_source"] = pmc_traffic()
+        r["traffic"], r["traffic_source"], r["traffic_stale"] = pmc_traffic()
         return r
     # impl == "ops": the dominant kernel is whichever rocBLAS SGEMM torch dispatches; it is not ours to time per launch.
     return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,

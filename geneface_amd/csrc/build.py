@@ -42,6 +42,20 @@ def headers():
     return sorted(glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(HERE, "*.inc")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")))
 
 
+def source_digest() -> str:
+    """sha256 (16 hex digits) over every kernel source, header and table of the library plus the compile flags: what a measurement taken on
+    one tree stamps itself with (tools/pmc_summary.py) and what bench.py compares a committed PMC summary against (`traffic_stale`).
+    Content, not mtimes: a snapshot on the GPU box or a fresh checkout has new mtimes and the same digest."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(sources() + headers()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(COMMON).encode())
+    return h.hexdigest()[:16]
+
+
 def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
     obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
     newest = max(os.path.getmtime(p) for p in [src, __file__, *headers()])

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_encode(const float* __restrict_
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         x[d] = inputs[(size_t)b * D + d];
-        oob |= (x[d] < 0 || x[d] > 1);
+        oob |= !(x[d] >= 0 && x[d] <= 1);   // NaN counts as out of range: no address is ever formed from it (the fused lookups do the same)
     }
     float* out = LAYOUT_BLC ? outputs + (size_t)b * L * C + level * C : outputs + ((size_t)level * B + b) * C;
     float* dd = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
             x[d] = inputs[(size_t)b * D + d];
-            oob |= (x[d] < 0 || x[d] > 1);
+            oob |= !(x[d] >= 0 && x[d] <= 1);   // NaN counts as out of range: no address is ever formed from it (the fused lookups do the same)
         }
         if (oob) continue;
         float g[C];
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(kBlock) k_grad_tv(const float* __restrict__ in
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         x[d] = inputs[(size_t)b * D + d];
-        oob |= (x[d] < 0 || x[d] > 1);
+        oob |= !(x[d] >= 0 && x[d] <= 1);   // NaN counts as out of range: no address is ever formed from it (the fused lookups do the same)
     }
     if (oob) return;
     const uint32_t off = (uint32_t)offsets[level], hashmap_size = (uint32_t)offsets[level + 1] - off;

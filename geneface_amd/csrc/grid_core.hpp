@@ -166,7 +166,7 @@ __device__ __forceinline__ void encode_half(const float* __restrict__ table, con
                                             uint32_t gridtype, uint32_t interp, const float (&x)[D], float (&f)[16]) {
     bool oob = false;
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    for (uint32_t d = 0; d < D; d++) oob |= !(x[d] >= 0.0f && x[d] <= 1.0f);   // NaN: out of range
 #pragma unroll
     for (int l = 0; l < 8; l++) {
         const float4 m = reinterpret_cast<const float4*>(meta)[half * 8 + l];

@@ -436,20 +436,28 @@ def _fill_torso(f: GfFrame, model, st: FusedState, bg_coords, torso_bias, out_al
     f.out_deform = ptr(out_deform) if out_deform is not None else None
 
 
-def head_aware_coin(model) -> bool:
+def head_aware_coin(model, bg_coords=None) -> bool:
     """radnerf_torso.py:175-179: with torso_head_aware the reference flips a coin PER FRAME, at inference too -- heads: the torso field sees
     the head's colour and opacity at each pixel; tails: zeros.  Same draw (random.random() < 0.5) so a seeded run decides alike.  The
-    reference draws inside `if mask.any():` (:174), i.e. only when the torso occupancy selects at least one pixel: a model whose torso grid
-    is empty draws nothing (mask = grid_sample(density_grid_torso) > min(density_thresh_torso, mean_density_torso), and an all-zero grid
-    with a non-negative threshold selects nothing), which keeps a seeded run's random stream aligned with the reference's."""
+    reference draws inside `if mask.any():` (:174), i.e. only when the torso mask selects at least one pixel, with
+    mask = grid_sample(density_grid_torso, bg_coords) > min(density_thresh_torso, mean_density_torso) (:166-172).  A model whose mask is empty
+    draws nothing, which keeps a seeded run's random stream aligned with the reference's.  The mask is evaluated by the model's own
+    `torso_mask` (the same grid_sample) once per (occupancy grid, bg_coords, thresholds) and its `any()` cached: a lone cell barely above
+    the threshold can leave every bilinear sample below it, so the grid alone does not decide."""
     if not bool(getattr(model, "torso_head_aware", False)):
         return False
-    st = getattr(model, "_torso_occ_any", None)
     grid = getattr(model, "density_grid_torso", None)
-    key = (grid._version, grid.data_ptr()) if grid is not None else None
+    if grid is None:
+        return False
+    thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
+    key = (grid._version, grid.data_ptr(), thresh) + ((bg_coords._version, bg_coords.data_ptr(), tuple(bg_coords.shape)) if bg_coords is not None else ())
+    st = getattr(model, "_torso_occ_any", None)
     if st is None or st[0] != key:
-        thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
-        any_px = bool((grid > thresh).any()) if grid is not None else False    # bilinear samples of a grid that is nowhere above the threshold are not either
+        with torch.no_grad():
+            if bg_coords is not None:
+                any_px = bool(model.torso_mask(bg_coords.reshape(-1, 2).to(grid.device)).any())
+            else:       # no pixel coordinates at hand: nothing is selected by a grid that is nowhere above the threshold
+                any_px = bool((grid > thresh).any())
         st = (key, any_px)
         object.__setattr__(model, "_torso_occ_any", st)
     return st[1] and random.random() < 0.5
@@ -546,7 +554,7 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
         rays_d = rays_d.contiguous().view(-1, 3).float()
         bg_coords = bg_coords.contiguous().view(-1, 2).float()
         N, dev = rays_o.shape[0], rays_o.device
-        ha_branch = head_aware_coin(model)
+        ha_branch = head_aware_coin(model, bg_coords)
         _, amb_bias, torso_bias = _per_frame_vectors(model, st, cond, poses, ha_branch)
         bg = _bg_tensor(bg_color, N, dev)
         out_rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -667,8 +675,11 @@ def _fill_pose_frame(pipe, i, f, rgb8, slot=0):
         bufs = pipe._fused_bufs = _PipeBuffers(pipe)
     N = pipe.H * pipe.W
     torso = st.has_torso
-    ha_branch = head_aware_coin(model) if torso else False
-    pre = pipe.prepared(i) if (hasattr(pipe, "prepared") and not st.head_aware) else None
+    pre = pipe.prepared(i) if hasattr(pipe, "prepared") else None
+    coin = pipe.prepared_coin(i) if (pre is not None and st.head_aware) else None
+    if st.head_aware and coin is None:
+        pre = None               # no coin was drawn for this frame by a batch: draw it now and encode the frame by itself
+    ha_branch = (coin if coin is not None else head_aware_coin(model, bufs.bg_coords)) if torso else False
     if pre is not None:          # the pass's batched launch (FramePipeline.prepare) already holds this frame's vectors
         amb_bias, torso_bias = pre
     else:

@@ -50,6 +50,33 @@ def may_hparams(torso: bool = True) -> dict:
     return hp
 
 
+#: The other RAD-NeRF experiment files the reference ships (each is the May / Obama yaml chain with these keys changed); name -> (overrides,
+#: the yaml files that state them).  tests/test_vs_reference.py resolves every file through the reference's own set_hparams and compares.
+#: The hash / smoothstep head files have no torso twin of their own: their torso stage is lm3d_radnerf_torso.yaml with `head_model_dir`
+#: pointed at them.  grid_type / grid_interpolation_type select the HEAD grids (position, ambient: radnerf.py:40-48); the torso grid is a
+#: linear tiled grid whatever they say (radnerf_torso.py:30).
+VARIANTS = {
+    "default": ({}, ["egs/datasets/videos/May/lm3d_radnerf.yaml", "egs/datasets/videos/May/lm3d_radnerf_torso.yaml"]),
+    "hash": ({"grid_type": "hashgrid", "individual_embedding_num": 10000}, ["egs/datasets/videos/May/lm3d_radnerf_hash.yaml"]),
+    "hash_smoothstep": ({"grid_type": "hashgrid", "grid_interpolation_type": "smoothstep", "individual_embedding_num": 10000},
+                        ["egs/datasets/videos/May/lm3d_radnerf_hash_smoothstep.yaml"]),
+    "smoothstep": ({"grid_interpolation_type": "smoothstep", "individual_embedding_num": 10000},
+                   ["egs/datasets/videos/May/lm3d_radnerf_smoothstep.yaml"]),
+    "head_aware": ({"torso_head_aware": True}, ["egs/datasets/videos/May/lm3d_radnerf_torso_head_aware.yaml"]),
+    "audio": ({"cond_type": "esperanto", "cond_win_size": 16, "smo_win_size": 8, "individual_embedding_num": 10000, "video_id": "Obama"},
+              ["egs/datasets/videos/Obama/radnerf.yaml", "egs/datasets/videos/Obama2/radnerf_torso.yaml"]),
+}
+
+
+def variant_hparams(name: str, torso: bool = True) -> dict:
+    """The hot-path hparams of one of the reference's shipped RAD-NeRF experiment files (VARIANTS)."""
+    hp = may_hparams(torso)
+    hp.update(copy.deepcopy(VARIANTS[name][0]))
+    if name == "audio" and torso:
+        hp["head_model_dir"] = "checkpoints/Obama2/radnerf"
+    return hp
+
+
 #: the process-global dict, mirroring `utils.commons.hparams.hparams`
 hparams = {}
 

@@ -58,7 +58,9 @@ def frame_streams(device, n):
     (GPU_MAX_HW_QUEUES, 8 here) in creation order: a process that keeps creating pipelines (bench.py builds a dozen, one per leg) would hand the
     later ones streams that share hardware queues with each other, and two frames "in flight" on one queue are not concurrent -- measured:
     the split tier's sub-block ran at 1 480-1 510 fps as the thirteenth pipeline of the process against 1 664 fps as the first.  Pipelines
-    are used one after the other, so sharing costs nothing; two used concurrently would merely be ordered more strictly than necessary."""
+    are used one after the other, so sharing costs nothing.  ONE ACTIVE PIPELINE PER DEVICE is the contract: two used concurrently (a
+    writer thread beside a viewer) stay correct -- every stream is in order and slots are per pipeline -- but share streams and lose the
+    overlap between their frames."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _STREAMS.setdefault(key, [])
@@ -136,24 +138,45 @@ class FramePipeline:
         encoder launch (70 us alone, 0.6 ms beside four persistent head grids, and on the critical path of the frame's stream).  Same
         bytes either way (tests/test_gpu_render.py::test_prepared_pass_is_bit_identical).  No-op for the op-by-op path."""
         self._pre = None
-        if self.impl != "fused" or self.device.type != "cuda" or stop <= first or getattr(self.model, "torso_head_aware", False):
-            return      # (head-aware torso models flip a coin per frame that decides what is folded into torso_bias: they encode per frame)
-        from .fused import cond_encode_batch, get_state
+        if self.impl != "fused" or self.device.type != "cuda" or stop <= first:
+            return
+        from .fused import cond_encode_batch, get_state, head_aware_coin
         st = get_state(self.model)
+        coins = None
+        c = st.cond
+        if c is None or self.cond_wins.dim() != 4 or tuple(self.cond_wins.shape[1:]) != (c.S, c.T, c.C):
+            return                         # an encoder / window the kernel does not implement: every frame runs the torch modules as before
+        if st.head_aware:
+            # radnerf_torso.py:175-179 flips a coin per frame that decides what is folded into torso_bias (the encoding of a black, transparent
+            # head, or zeros + the per-pixel encoding).  The pass's coins are drawn HERE, in frame order -- the draws, and their order, a
+            # frame-by-frame loop makes (one random.random() per rendered frame) -- and each frame later uses its own (prepared_coin).
+            bgc = self._fused_bufs.bg_coords if getattr(self, "_fused_bufs", None) is not None else self.bg_coords.reshape(-1, 2)
+            coins = [head_aware_coin(self.model, bgc) for _ in range(first, stop)]
         if getattr(self, "_prep_stream", None) is None:
-            self._prep_stream = frame_streams(self.device, 5)[4]      # the fifth shared stream: the pass's batched encoder launch
+            # one shared stream BEYOND the frame streams of the deepest pipeline this process asks for (in_flight 5 or 6 is swept by
+            # bench.py: index 4 would then be frame stream #5 and the batched launch would serialise with that frame's kernels)
+            k = max(self.max_in_flight, 4)
+            self._prep_stream = frame_streams(self.device, k + 1)[k]
         ps = self._prep_stream
         ps.wait_stream(torch.cuda.current_stream(self.device))
         for fs in self._streams:          # frames of the previous pass may still be reading the rows this launch's buffers replace
             ps.wait_stream(fs)
         with torch.cuda.stream(ps), torch.no_grad():
-            r = cond_encode_batch(self.model, st, self.cond_wins[first:stop], self.pose6[first:stop] if st.has_torso else None)
+            p6 = self.pose6[first:stop] if st.has_torso else None
+            r = cond_encode_batch(self.model, st, self.cond_wins[first:stop], p6, bool(coins[0]) if coins else False)
             if r is None:
+                if coins:                  # (cannot happen after a draw: cond_encode_batch refuses on the encoder's shape, known before)
+                    raise RuntimeError("FramePipeline.prepare: the coins of a head-aware pass were drawn but the batched encoder refused")
                 return                     # an encoder the kernel does not implement: every frame runs the torch modules as before
+            torso = r[2]
+            if coins and any(c != coins[0] for c in coins):      # both outcomes occur in the pass: a second launch with the other constant
+                r2 = cond_encode_batch(self.model, st, self.cond_wins[first:stop], p6, not coins[0])
+                pick = torch.tensor(coins, device=self.device).view(-1, 1)
+                torso = torch.where(pick == bool(coins[0]), r[2], r2[2])
             ev = torch.cuda.Event()
             ev.record()
-        self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": r[2], "stamp": st.stamp, "event": ev, "waited": set(),
-                     "inputs": (self.cond_wins._version, self.pose6._version)}
+        self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": torso, "stamp": st.stamp, "event": ev, "waited": set(),
+                     "inputs": (self.cond_wins._version, self.pose6._version), "coins": coins}
 
     def prepared(self, i: int):
         """(amb_bias [128], torso_bias [96] or None) of frame i from the current pass's batched launch, or None.  Called on the frame's
@@ -171,6 +194,13 @@ class FramePipeline:
             pre["waited"].add(cur.cuda_stream)
         k = i - pre["first"]
         return pre["amb"][k], (pre["torso"][k] if pre["torso"] is not None else None)
+
+    def prepared_coin(self, i: int):
+        """The head-aware coin prepare() drew for frame i (None: no batch covers it, or the model has no coin)."""
+        pre = getattr(self, "_pre", None)
+        if pre is None or pre.get("coins") is None or not (pre["first"] <= i < pre["stop"]):
+            return None
+        return pre["coins"][i - pre["first"]]
 
     def sample(self, i: int, rays: bool = True) -> dict:
         """The `sample` dict tasks/radnerfs/radnerf.py:119-126 reads (rays materialised, like the reference's dataset)."""
@@ -208,12 +238,18 @@ class FramePipeline:
             self._events[slot].synchronize()   # the host side of this slot's previous frame has been handed out and may be reused
         if self.impl == "fused":
             from .fused import render_frame_fused
+            timing = getattr(self, "frame_timing", None)      # a list: bench.py's latency leg asks for per-frame device times
             with torch.cuda.stream(self._streams[slot % self.in_flight]):
+                if timing is not None:
+                    t_start = torch.cuda.Event(enable_timing=True)
+                    t_start.record()
                 rgb8 = render_frame_fused(self, i, slot % max(2, self.in_flight))
                 self._pinned[slot].copy_(rgb8, non_blocking=True)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=timing is not None)
                 ev.record()
                 self._events[slot] = ev
+                if timing is not None:
+                    timing.append((i, t_start, ev))
             return self._pinned[slot]
         out = self.run_model(self.sample(i))
         rgb8 = (out["rgb_map"] * 255).view(self.H, self.W, 3).to(torch.uint8)

@@ -229,6 +229,21 @@ def make_landmarks(T: int, seed: int = 11, rho: float = 0.9) -> np.ndarray:
     return x.astype(np.float32)
 
 
+def make_audio_features(T: int, C: int, win: int = 16, seed: int = 13, rho: float = 0.8) -> np.ndarray:
+    """[T, win, C] float32: per video frame a `win`-step window of a C-channel audio-feature stream (esperanto 44 / deepspeech 29 channels;
+    the layout of `esperanto_win` / `deepspeech_win`, tasks/radnerfs/dataset_utils.py:91-94): an AR(1) stream at two feature steps per video
+    frame, windows centred on the frame and zero padded at the sequence ends as the extractors do."""
+    r = _rng("audio_features", seed)
+    n = 2 * T + win
+    x = np.zeros((n, C), dtype=np.float64)
+    x[0] = r.standard_normal(C)
+    for t in range(1, n):
+        x[t] = rho * x[t - 1] + math.sqrt(1 - rho * rho) * r.standard_normal(C)
+    x[:win // 2] = 0
+    x[-(win // 2):] = 0
+    return np.stack([x[2 * t:2 * t + win] for t in range(T)]).astype(np.float32)
+
+
 def make_bg_img(H: int, W: int) -> np.ndarray:
     """[H,W,3] float32 in [0,1]: smooth gradient plus a checker, so blending errors are visible."""
     yy, xx = np.meshgrid(np.arange(H) / max(H - 1, 1), np.arange(W) / max(W - 1, 1), indexing="ij")
@@ -239,17 +254,25 @@ def make_bg_img(H: int, W: int) -> np.ndarray:
 
 def make_sequence(T: int, H: int = 512, W: int = 512, hp: dict = None, seed: int = 0, radius: float = None) -> dict:
     """Everything `run_model` needs for T frames except rays (host numpy; rays are generated per frame):
-    cond_wins [T,5,1,204], poses [T,4,4] (smoothed, ngp axes), intrinsics [4], bg_img [H*W,3]."""
-    from .lm3d import cond_windows, normalize_and_smooth
+    cond_wins [T,5,1,204] (landmark-driven; [T,8,16,44] for the audio-driven configs), poses [T,4,4] (smoothed, ngp axes), intrinsics [4],
+    bg_img [H*W,3]."""
+    from .lm3d import cond_windows, get_win_conds, normalize_and_smooth
     from .utils import smooth_camera_path
     hp = hp or {}
-    lm = make_landmarks(T, seed=11 + seed)
-    lm_norm = normalize_and_smooth(lm, 0.0, 1.0, hp.get("infer_lm3d_clamp_std", 2.5))
+    if hp.get("cond_type", "idexp_lm3d_normalized") != "idexp_lm3d_normalized":
+        # audio-driven RAD-NeRF (egs/egs_bases/radnerf/radnerf.yaml:4-7): per frame a [cond_win, C] feature window; cond_wins = the smo_win
+        # frames around it, zero padded at the ends (get_audio_features att_mode 2, modules/radnerfs/utils.py:85-101 via dataset_utils.py:158)
+        feats = make_audio_features(T, cond_in_dim(hp), hp.get("cond_win_size", 16), seed=13 + seed)
+        wins = np.stack([get_win_conds(feats, i, hp.get("smo_win_size", 8), "zero") for i in range(T)])
+    else:
+        lm = make_landmarks(T, seed=11 + seed)
+        lm_norm = normalize_and_smooth(lm, 0.0, 1.0, hp.get("infer_lm3d_clamp_std", 2.5))
+        wins = cond_windows(lm_norm, hp.get("cond_win_size", 1), hp.get("smo_win_size", 5))
     poses = make_poses(T, seed=7 + seed) if radius is None else make_poses(T, seed=7 + seed, radius=radius)   # radius < 3.35: the head fills the frame
     if hp.get("infer_smooth_camera_path", True):
         poses = smooth_camera_path(poses.copy(), hp.get("infer_smooth_camera_path_kernel_size", 7)).astype(np.float32)
     return {
-        "cond_wins": cond_windows(lm_norm, hp.get("cond_win_size", 1), hp.get("smo_win_size", 5)),
+        "cond_wins": wins,
         "poses": poses, "intrinsics": intrinsics(H, W), "bg_img": make_bg_img(H, W).reshape(-1, 3), "H": H, "W": W,
     }
 

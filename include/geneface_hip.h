@@ -235,7 +235,11 @@ int gf_cond_encode_batch(const gf_cond_t* cond, uint32_t n_frames, void* stream)
 uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
 uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */
-uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/csrc/frame.hpp (queue heads, counts, terminal-index histogram) */
+uint32_t gf_frame_ctrl_words(void);               /* word layout: geneface_amd/csrc/frame.hpp (queue heads, counts, terminal-index histogram).
+                                                      Size of the block.  A frame DEFINES (clears, then writes) only the words below
+                                                      64 + max_steps + 2 -- the histogram is as long as the frame's max_steps; words beyond
+                                                      that keep whatever an earlier frame with a larger max_steps left there (a viewer
+                                                      moving its step slider from 1024 to 16) and must not be read. */
 /* Byte offset of one per-ray array inside the workspace, for tests that inspect what k_frame_init derived from the pose (the
  * reference materialises the same arrays: get_rays utils.py:282-363, near_far_from_aabb raymarching.cu:92-145).
  * field: 0 nears [N], 1 fars [N], 2 rays_t [N], 3 weights_sum [N], 4 depth [N], 5 image [N,3], 6 rays_o [N,3], 7 rays_d [N,3],

@@ -94,6 +94,55 @@ def test_bench_control_flow_world2_gloo(tmp_path):
     assert line["value"] <= 2 * pr["fps_min"] * 1.05
 
 
+def test_bench_control_flow_world8_gloo(tmp_path):
+    """The full-node shape (VERDICT r4 next #7): eight ranks, one line, eight disjoint blocks, eight clocks."""
+    world = 8
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path), world), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(world)]
+    assert [rk["frames"] for rk in r] == [[8 * k, 8 * k + 8] for k in range(world)]
+    assert len(r[0]["lines"]) == 1 and all(rk["lines"] == [] for rk in r[1:])
+    line = r[0]["lines"][0]
+    assert line["n_gpus"] == 8 and line["config"]["rccl_ranks"] == 8 and line["config"]["frames_total"] == 48 and "frame-shard x8" in line["config"]["parallelism"]
+    assert len({len(rk["passes"]) for rk in r}) == 1 and all(all(p == list(range(2, 8)) for p in rk["passes"]) for rk in r)
+    pr = line["per_rank"]
+    assert len(pr["fps"]) == 8 and pr["frames"] == [[8 * k, 8 * k + 8] for k in range(world)]
+    assert abs(line["value"] - 8 * 6 / (line["ms_per_step"] * 6 / 1e3)) < 1e-6 * line["value"] and line["value"] <= 8 * pr["fps_min"] * 1.05
+    import bench
+    assert len(json.dumps(bench.compact_line(line, "x"))) < 3000
+
+
+def test_a_rank_that_renders_another_picture_voids_the_line():
+    """every_rank_parity's verdict is not a footnote: if the ranks' frames of the common fixture frame are not byte-identical, or any of
+    them is off the oracle by more than the tolerance, the N > 1 line reports value = null and says why (VERDICT r4 next #7)."""
+    import torch
+    import bench
+    ref = torch.rand(64)
+    rows = [ref + 1e-6, ref + 1e-6, ref + 1e-6]
+    ok = bench.judge_rank_frames(rows, ref, 14)
+    assert ok["identical_across_ranks"] is True and ok["max_abs_rgb"] < 1e-4 and len(ok["max_abs_rgb_by_rank"]) == 3
+    line = {"value": 123.0}
+    bench.apply_rank_parity_guard(line, ok)
+    assert line["value"] == 123.0 and "error" not in line
+    rows[2] = rows[2].clone()
+    rows[2][5] += 3e-7                                   # one float differs in one replica
+    bad = bench.judge_rank_frames(rows, ref, 14)
+    assert bad["identical_across_ranks"] is False and bad["ranks_differing_from_rank0"] == [2]
+    line = {"value": 123.0}
+    bench.apply_rank_parity_guard(line, bad)
+    assert line["value"] is None and line["value_withheld"] == 123.0 and "identical" in line["error"]
+    rows = [ref + 1e-2] * 3                               # identical, but not the reference's picture
+    off = bench.judge_rank_frames(rows, ref, 14)
+    line = {"value": 5.0}
+    bench.apply_rank_parity_guard(line, off)
+    assert line["value"] is None and "tolerance" in line["error"]
+    line = {"value": 5.0}
+    bench.apply_rank_parity_guard(line, {"error": "oracle failed"})
+    assert line["value"] is None
+    line = {"value": 5.0}
+    bench.apply_rank_parity_guard(line, None)             # N = 1 without --rank-parity: nothing to judge
+    assert line["value"] == 5.0
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
     world = 2
     mp.spawn(_rank, args=(world, _free_port(), str(tmp_path), 4), nprocs=world, join=True)
@@ -231,3 +280,62 @@ def test_replica_checksum_sees_one_flipped_bit():
         w = m.sigma_net.net[1].weight
         w.view(torch.int32)[3, 5] ^= 1
     assert bench.replica_checksum(m) != a
+
+
+def test_compact_line_keeps_the_numbers_and_drops_the_lists():
+    """the stdout line had grown to 15 KB and the driver's record kept the headline parity only as a key name.  The line is
+    now the compact form of the full record (which goes to a side file): `config.parity` carries the headline summary and one row per
+    sub-leg, `roofline` / `cpu_baseline` keep the contract's fields, nothing holds a per-frame list."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "round4", "r4o_bench_driver_command.json")))       # a full record of round 4's format
+    full["variants"] = {n: {"value": 700.0, "vs_default": 0.92, "roofline_frac": 0.65, "samples_per_frame": 8.6e5, "split_tier_value": 1700.0,
+                            "parity": full["parity"], "parity_split_tier": full["split_tier"]["parity"]} for n in bench.VARIANT_NAMES}
+    full["variants"]["audio"] = {"error": "RuntimeError: x" * 100}
+    line = bench.compact_line(full, "gpurun_out/bench_details.json")
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    par = line["config"]["parity"]
+    assert abs(par["max_abs_rgb"] - full["parity"]["max_abs_rgb"]) < 1e-7 and par["frames"] == 8 and par["tolerance"] == 1e-4
+    assert par["pose_mode_unexplained"] == 0 and par["grazing_pixels"] == full["parity"]["grazing"]["pixels"]
+    assert par["legs"]["split_tier"][0] == bench._sig(full["split_tier"]["parity"]["max_abs_rgb"]) and par["legs"]["variant:hash"][1] == 8
+    assert par["all_legs_max_abs_rgb"] >= par["max_abs_rgb"] and par["all_legs_unexplained"] == 0
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - full["roofline"]["frac"]) < 1e-3 and r["peak"] == 157.3 and r["unit"] == "TFLOP/s" and "traffic" in r
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3 and "kernel_ms_per_frame" in r and "pipelined" in r and "marcher" in r
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert line["variants"]["hash"]["fps"] == 700.0 and "error" in line["variants"]["audio"] and len(line["variants"]["audio"]["error"]) <= 160
+
+    def no_long_lists(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                no_long_lists(v, path + "/" + k)
+        elif isinstance(o, list):
+            assert len(o) <= 8 and not any(isinstance(e, dict) for e in o), path
+    no_long_lists(line)
+
+
+def test_pmc_traffic_is_marked_stale_when_the_kernels_moved_on(tmp_path, monkeypatch):
+    """roofline.traffic is read from a committed PMC summary (counters cannot be collected inside the timed run): the summary carries the
+    digest of the kernel sources it was collected on, and the line says `traffic_stale: true` when this tree's digest differs."""
+    import json
+    import os
+    import bench
+    from geneface_amd.csrc.build import source_digest
+    prof = tmp_path / "profiles" / "round9"
+    prof.mkdir(parents=True)
+    body = {"k_head_phase": {"fetch_MB_x2": 100.0, "write_MB_raw": 2.0}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r9a_pmc_summary.json").write_text(json.dumps(dict(body, _source_digest=source_digest())))
+    t, src, stale = bench.pmc_traffic()
+    assert t == 102e6 and src.endswith("r9a_pmc_summary.json") and stale is False
+    (prof / "r9a_pmc_summary.json").write_text(json.dumps(dict(body, _source_digest="0" * 16)))
+    assert bench.pmc_traffic()[2] is True
+    (prof / "r9a_pmc_summary.json").write_text(json.dumps(body))          # round 1-4 summaries carry no digest: stale by definition
+    assert bench.pmc_traffic()[2] is True

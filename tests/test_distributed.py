@@ -148,20 +148,23 @@ def _torchrun_style_rank(rank, world, port, out_dir, cond_path, T, H, W):
     dist.destroy_process_group()
 
 
-def test_forward_system_under_an_existing_process_group_gathers_on_rank0(tmp_path):
+@pytest.mark.parametrize("T,world", [(11, 2), (272, 8)])
+def test_forward_system_under_an_existing_process_group_gathers_on_rank0(tmp_path, T, world):
     """under torchrun rank 0 used to write ITS block to out_video_name as if it were the sequence.  Now both multi-GPU entry
-    paths return the same thing on rank 0: every frame, in order, rendered from rank 0's weights."""
+    paths return the same thing on rank 0: every frame, in order, rendered from rank 0's weights.  (272, 8): the length of the reference's
+    demo audio (zozo.wav) on a full node -- 34 frames per rank, none left over; the uneven case is (11, 2); VERDICT r4 next #7."""
     import numpy as np
     from geneface_amd import synthetic as S
-    T, H, W, world = 11, 16, 16, 2
+    H, W = (16, 16) if world == 2 else (8, 8)
     cond_path = str(tmp_path / "lm.npy")
     np.save(cond_path, S.make_landmarks(T).astype(np.float32)[None])
     mp.spawn(_torchrun_style_rank, args=(world, _free_port(), str(tmp_path), cond_path, T, H, W), nprocs=world, join=True)
     full = np.load(tmp_path / "out.npy")
     assert full.shape == (T, H, W, 3)
-    assert [int(full[i, 0, 0, 0]) for i in range(T)] == list(range(T))           # StubPipeline encodes the global frame index in channel 0
+    assert [int(full[i, 0, 0, 0]) for i in range(T)] == [i % 256 for i in range(T)]   # StubPipeline encodes the global frame index in channel 0
     assert len({int(full[i, 0, 0, 1]) for i in range(T)}) == 1                     # one weight checksum: rank 0's, on both ranks' frames
     np.testing.assert_array_equal(np.load(tmp_path / "ret_0.npy"), full)           # rank 0 returns the whole sequence
-    r1 = np.load(tmp_path / "ret_1.npy")
-    np.testing.assert_array_equal(r1, full[T // world:])                           # the other rank its own block
+    for r in range(1, world):                                                       # the other ranks their own blocks
+        a, b = shard_range(T, r, world)
+        np.testing.assert_array_equal(np.load(tmp_path / f"ret_{r}.npy"), full[a:b])
     assert sorted(os.listdir(tmp_path / "imgs")) == [f"{i:05d}.png" for i in range(T)]

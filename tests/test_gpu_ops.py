@@ -311,8 +311,14 @@ def test_fused_lookup_far_out_of_range_points_read_nothing_and_give_zeros(D):
         torch.cuda.synchronize()
         rows = torch.arange(30, device=DEV)
         assert float(out[rows].abs().max()) == 0.0                       # every planted row is out of range (or NaN): zeros
-        nan_rows = torch.isnan(x).any(dim=1)
-        assert torch.equal(out[~nan_rows], ref[~nan_rows].clone()) or (out[~nan_rows] - ref[~nan_rows]).abs().max().item() <= 1e-6
+        # the generic operator agrees on EVERY row, NaN rows included (it used to test `x < 0 || x > 1`, let a NaN through and
+        # form an index from (uint32_t)floorf(NaN)); with dy_dx requested those rows are zeros as well
+        assert float(ref[rows].abs().max()) == 0.0
+        assert torch.equal(out, ref) or (out - ref).abs().max().item() <= 1e-6
+        ref2, dy = torch.empty(4096, 32, device=DEV), torch.full((4096, D * 32), 7.0, device=DEV)
+        check(lib().gf_grid_encode_forward_blc(ptr(x), ptr(table), ptr(offsets, torch.int32), ptr(ref2), 4096, D, 2, L, S, Hres, ptr(dy), gridtype, 0, 0, current_stream(x.device)))
+        torch.cuda.synchronize()
+        assert torch.equal(ref2, ref) and float(dy[rows].abs().max()) == 0.0 and bool(torch.isfinite(dy).all())
         assert float(out[30:].abs().max()) > 0.1
 
 

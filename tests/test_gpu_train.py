@@ -263,7 +263,13 @@ def test_fused_training_field_vs_op_graph():
         # the single-element attention bias sits on a cancelling sum (the same constant added to all five window logits in front of a
         # softmax): its gradient is rounding residue of the forward's summation order -- 3e-3 with the row sums of rounds 2-3, 6.5e-3 with
         # round 4's per-wave partial sums -- so it gets the "worst element" bar; every real tensor keeps 5e-3
-        assert l2 < (2e-2 if go[n].numel() == 1 else 5e-3) and worst < 2e-2, (n, l2, worst)
+        if n == "cond_att_net.attentionConvNet.8.bias":
+            # mathematically zero (a constant in front of a softmax): what both sides hold is rounding residue, so the statement is "tiny
+            # against the gradients that matter", not a relative error between two residues
+            scale = max(float(go[k].abs().max()) for k in go if k.startswith("cond_att_net.attentionConvNet.8"))
+            assert float(gf[n].abs().max()) <= 1e-3 * max(scale, 1e-12) or l2 < 2e-2, (n, float(gf[n].abs().max()), scale, l2)
+            continue
+        assert l2 < 5e-3 and worst < 2e-2, (n, l2, worst)
 
 
 def test_training_branch_under_fp16_autocast():

@@ -52,7 +52,17 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"] > 0:
             d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"]
         summary[k] = d
+    # stamp the summary with the digest of the kernel sources it was collected on: bench.py marks `traffic_stale` when the tree has moved on
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from geneface_amd.csrc.build import source_digest
+        summary["_source_digest"] = source_digest()
+    except Exception as e:      # noqa: BLE001
+        summary["_source_digest"] = None
+        print("pmc_summary: no source digest:", e)
     for k, d in summary.items():
+        if not isinstance(d, dict):
+            continue
         print(f"== {k}")
         for n, v in sorted(d.items()):
             print(f"   {n:36s} {v:18.4f}")
