@@ -1,0 +1,215 @@
+"""-m gpu: SURVEY 8 f-1 + f-2 as ONE loop (VERDICT r4 missing #4) -- what tasks/radnerfs/radnerf.py:185-216 does around the model, end to end:
+
+    teacher renders target frames -> a student from another seed trains for a few hundred steps with the product's training branch
+    (update_extra_state every 16 steps: :188-192; render in training mode; MSE + the ambient regulariser; Adam with the task's three
+    parameter groups: :55-76) -> the checkpoint is written in the Trainer's layout (utils/commons/trainer.py:454-473: per-child state
+    dicts, optimizer states, legacy non-zip pickle) -> reloaded through the entry point (LM3d_RADNeRFInfer.build_model) -> rendered on
+    the fused path -> held to the strict 1e-4 against the oracle on the TRAINED weights and the bitfield the training loop regenerated.
+
+Beside it the same host loop runs over the reference's own kernels (oracle/_ref: its four .cu files compiled for gfx950) at the product's
+seams -- the field as a torch op graph over the reference's encoders, its marcher / compositor, block-wise density-grid refresh -- and both
+loss curves must fall by the same factor.  The Trainer itself (schedulers, LPIPS, logging) is out of scope; this is the loop's arithmetic.
+Test infrastructure only: nothing here is product code."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_threads
+from oracle import radnerf_ref as R
+from oracle import ref_kernels
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SIZE, T, STEPS = 128, 8, 304
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _teacher_targets(hp, seq):
+    """8 frames of the synthetic identity (seed 0) on the fused inference path: the 'video' the student learns."""
+    from geneface_amd import synthetic as S
+    from geneface_amd import utils
+    from geneface_amd.radnerf import RADNeRF
+    teacher = RADNeRF(hp)
+    teacher.load_state_dict(S.make_state_dict(hp, False, seed=0), strict=True)
+    teacher = teacher.to(DEV).eval()
+    poses = torch.from_numpy(seq["poses"]).to(DEV)
+    cond = torch.from_numpy(seq["cond_wins"]).to(DEV)
+    bg = torch.from_numpy(seq["bg_img"]).to(DEV).view(1, -1, 3)
+    bgc = utils.get_bg_coords(SIZE, SIZE, DEV)
+    tg = []
+    with torch.no_grad():
+        for f in range(T):
+            rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], SIZE, SIZE, -1)
+            out = teacher.render(rays["rays_o"], rays["rays_d"], cond[f], bgc, None, index=0, bg_color=bg, perturb=False, force_all_rays=True, **hp)
+            tg.append(out["rgb_map"].reshape(1, -1, 3).clone())
+    return poses, cond, bg, bgc, torch.cat(tg)
+
+
+def _student(hp):
+    """Another identity's weights (seed 5), density grid empty as at the start of training (renderer.py:78-99)."""
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf import RADNeRF
+    sd = S.make_state_dict(hp, False, seed=5)
+    m = RADNeRF(hp)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    m.reset_extra_state()
+    m.density_bitfield.zero_()
+    return m
+
+
+def _optimizer(model, lr=5e-4):
+    """RADNeRFTask.build_optimizer (tasks/radnerfs/radnerf.py:45-76): networks at lr, embedders (grids, identity codes) at 10 lr, the attention
+    net at 5 lr, Adam(0.9, 0.99, eps 1e-15)."""
+    emb = [p for n, p in model.named_parameters() if "embedder" in n or n == "individual_embeddings"]
+    att = [p for n, p in model.named_parameters() if n.startswith("cond_att_net")]
+    ids = {id(p) for p in emb + att}
+    net = [p for p in model.parameters() if id(p) not in ids]
+    opt = torch.optim.Adam(net, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+    opt.add_param_group({"params": emb, "lr": lr * 10, "betas": (0.9, 0.99), "eps": 1e-15})
+    opt.add_param_group({"params": att, "lr": lr * 5, "betas": (0.9, 0.99), "eps": 1e-15})
+    return opt
+
+
+def _train(model, hp, seq, poses, cond, bg, bgc, targets, steps, n_rays=8192):
+    """The task's step (radnerf.py:185-216) `steps` times; every random draw (pixel choice, march jitter, grid jitter, the window
+    update_extra_state picks) comes from generators seeded here, so two runs over different kernels see the same draws."""
+    import random
+    from geneface_amd import utils
+    torch.manual_seed(11)
+    random.seed(11)
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    model.conds = cond[:, cond.shape[1] // 2]
+    model.mark_untrained_grid(poses, seq["intrinsics"])
+    opt = _optimizer(model)
+    losses = []
+    for i in range(steps):
+        if i % hp["update_extra_interval"] == 0:
+            model.update_extra_state(generator=gen)
+        f = i % T
+        rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], SIZE, SIZE, n_rays)
+        sel = rays["inds"][0]
+        out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel], perturb=True,
+                           force_all_rays=False, **hp)
+        mse = ((out["rgb_map"] - targets[f:f + 1, sel]) ** 2).mean()
+        loss = mse + 1e-3 * out["ambient"].abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(mse))
+    model.update_extra_state(generator=gen)      # the bitfield the checkpoint carries belongs to the final weights
+    return losses, opt
+
+
+def _save_trainer_checkpoint(path, model, opt, step):
+    """utils/commons/trainer.py:454-473 (dump_checkpoint + save): {'epoch', 'global_step', 'checkpoint_callback_best', 'optimizer_states',
+    'state_dict': {child name: state dict}} through torch.save's LEGACY container."""
+    ck = {"epoch": 0, "global_step": step, "checkpoint_callback_best": np.float64(0.5), "optimizer_states": [opt.state_dict()],
+          "state_dict": {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}}}
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(ck, path, _use_new_zipfile_serialization=False)
+
+
+def _dump(record):
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "closed_loop_loss_curves.json"), "w") as f:
+            json.dump(record, f)
+
+
+def _head_fall(losses, k=16):
+    return float(np.mean(losses[-k:]) / np.mean(losses[:k]))
+
+
+def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd.infer import FramePipeline
+    from geneface_amd.lm3d_radnerf_infer import LM3d_RADNeRFInfer, RADNeRFPoseSource
+    from geneface_amd.radnerf import RADNeRF
+    hp = HP.may_hparams(False)
+    seq = S.make_sequence(T, SIZE, SIZE, hp)
+    poses, cond, bg, bgc, targets = _teacher_targets(hp, seq)
+
+    # ---- the product's training branch (fused field node, hand-written backward, one-launch grid refresh)
+    student = _student(hp)
+    w0 = {k: v.detach().clone() for k, v in student.state_dict().items()}
+    losses, opt = _train(student, hp, seq, poses, cond, bg, bgc, targets, STEPS)
+    assert all(np.isfinite(losses)), "training diverged"
+    fall = _head_fall(losses)
+    assert fall < 0.2, f"the student did not learn: mse {np.mean(losses[:16]):.4g} -> {np.mean(losses[-16:]):.4g}"
+    moved = sum(int(not torch.equal(w0[k], v)) for k, v in student.state_dict().items() if v.is_floating_point() and not k.startswith("aabb"))
+    assert moved >= 20 and int(student.density_bitfield.count_nonzero()) > 0 and student.iter_density >= STEPS // 16
+
+    # ---- the same host loop over the reference's own kernels at the product's seams
+    record = {"steps": STEPS, "n_rays": 8192, "size": SIZE, "product": {"mse": losses, "fall": fall}}
+    if ref_kernels.available("fast"):
+        import geneface_amd.encoders.freqencoder as fe
+        import geneface_amd.encoders.gridencoder as ge
+        import geneface_amd.encoders.shencoder as she
+        import geneface_amd.raymarching as rmod
+        import geneface_amd.renderer as rr
+        from train_rate_reference import FQ, RM, SH, _RefGridEncode
+        with monkeypatch.context() as mp:
+            mp.setattr(rmod, "_backend", RM)
+            mp.setattr(she, "_backend", SH)
+            mp.setattr(fe, "_backend", FQ)
+            mp.setattr(ge, "_grid_encode", _RefGridEncode)
+            mp.setattr(RADNeRF, "field_impl", "ops")
+            mp.setattr(rr.NeRFRenderer, "_pick_impl", lambda self, impl, perturb, max_steps: "ops")
+            ref_student = _student(hp)
+            ref_losses, _ = _train(ref_student, hp, seq, poses, cond, bg, bgc, targets, STEPS)
+        ref_fall = _head_fall(ref_losses)
+        record["reference_kernels"] = {"mse": ref_losses, "fall": ref_fall}
+        _dump(record)
+        assert all(np.isfinite(ref_losses))
+        # "The same factor": the two runs share every draw but not their rounding, and 300 Adam steps amplify that -- the per-step losses
+        # decorrelate after ~50 steps while the curves stay on top of each other.  Measured on the MI355X: x0.0168 against x0.0147 (a 60-fold
+        # fall either way).  So the bar is on the curve, in the unit a loss curve is read in: the decades fallen agree to 10 %, the final
+        # plateaus to 30 %, and so does every 32-step window on the way down.
+        assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.10, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
+        assert abs(fall / ref_fall - 1.0) < 0.30, (fall, ref_fall)
+        for a in range(0, STEPS - 32, 32):
+            wa, wb = float(np.mean(losses[a:a + 32])), float(np.mean(ref_losses[a:a + 32]))
+            assert abs(wa / wb - 1.0) < 0.30, f"steps {a}..{a + 32}: mse {wa:.4g} (product) vs {wb:.4g} (reference kernels)"
+        assert abs(losses[0] / ref_losses[0] - 1.0) < 1e-3          # step 0: same weights, same draws, same picture
+        # the two occupancy fields agree on almost every cell (a cell whose density sits on the threshold may fall either way)
+        a, b = student.density_bitfield, ref_student.density_bitfield
+        diff_bits = int((a ^ b).to(torch.int32).cpu().apply_(lambda v: bin(v).count("1")).sum())
+        record["bitfield_bits_differing"] = diff_bits
+        record["bitfield_bits_set"] = int(a.to(torch.int32).cpu().apply_(lambda v: bin(v).count("1")).sum())
+        assert diff_bits <= 0.05 * max(record["bitfield_bits_set"], 1)
+    _dump(record)
+
+    # ---- checkpoint in the Trainer's layout -> the entry point's build_model -> fused render -> oracle on the trained weights
+    work_dir = str(tmp_path / "checkpoints" / "May" / "lm3d_radnerf")
+    _save_trainer_checkpoint(os.path.join(work_dir, f"model_ckpt_steps_{STEPS}.ckpt"), student, opt, STEPS)
+    import zipfile
+    assert not zipfile.is_zipfile(os.path.join(work_dir, f"model_ckpt_steps_{STEPS}.ckpt"))
+    dd, _ = S.make_dataset_dict(T=T + 2, H=SIZE, W=SIZE)
+    hp_inf = dict(hp, work_dir=work_dir)
+    inf = LM3d_RADNeRFInfer(hp_inf, dataset=RADNeRFPoseSource(dd, hp_inf), device=DEV)
+    assert inf.global_step == STEPS and isinstance(inf.model, RADNeRF)
+    loaded = inf.model.to(DEV).eval()
+    sd_trained = {k: v.detach().cpu() for k, v in student.state_dict().items()}
+    for k, v in loaded.state_dict().items():
+        assert torch.equal(v.cpu(), sd_trained[k]), k
+    assert loaded._pick_impl("auto", False, hp["max_steps"]) == "fused"
+    pipe = FramePipeline(loaded, hp, seq, DEV, impl="fused")
+    oracle_threads(16)
+    worst = 0.0
+    for i in (1, 5):
+        with torch.no_grad():
+            smp = pipe.sample(i)
+            out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
+            host = {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in smp.items()}
+            ref = R.render(sd_trained, hp, host["rays_o"], host["rays_d"], host["cond_wins"], host["bg_coords"], host["pose"], host["bg_img"], torso=False)
+        err = float((out - ref["rgb_map"].reshape(-1, 3)).abs().max())
+        worst = max(worst, err)
+        assert err < 1e-4, f"frame {i}: max|d rgb| {err:.3g} on the trained weights"
+        # and the trained student does look like the teacher now (it is a 300-step fit, not a converged one: a loose bar)
+        assert float(((out - targets[i].cpu()) ** 2).mean()) < 2.0 * np.mean(losses[-16:]) + 1e-3
+    print(f"closed loop: mse {np.mean(losses[:16]):.4g} -> {np.mean(losses[-16:]):.4g} (x{fall:.3f}); trained-weights parity {worst:.3g}")
