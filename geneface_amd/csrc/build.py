@@ -56,12 +56,12 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
+def _compile(src, force, extra=(), obj_dir=OBJ_DIR, drop=()):
     obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
     newest = max(os.path.getmtime(p) for p in [src, __file__, *headers()])
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC, *COMMON, *PER_FILE.get(os.path.basename(src), ()), *extra, "-x", "hip", "-c", src, "-o", obj, "-I", HERE,
+    cmd = [HIPCC, *[f for f in COMMON if f not in drop], *PER_FILE.get(os.path.basename(src), ()), *extra, "-x", "hip", "-c", src, "-o", obj, "-I", HERE,
            "-I", os.path.join(HERE, "..", "..", "include")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -71,17 +71,20 @@ def _compile(src, force, extra=(), obj_dir=OBJ_DIR):
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False, trace: bool = False, variant: str = None, defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, trace: bool = False, variant: str = None, defines=(), drop_flags=()) -> str:
     """trace=True builds the instrumented variant (-DGF_TRACE: per-round s_memtime timeline of the head kernel, read by
     tools/trace_head.py) into libgeneface_hip_trace.so; the product library never contains the instrumentation.
-    variant="x", defines=("-DFOO",) builds an experiment library libgeneface_hip_x.so (A/B runs select it with GF_HIP_LIB)."""
+    variant="x", defines=("-DFOO",) builds an experiment library libgeneface_hip_x.so (A/B runs select it with GF_HIP_LIB);
+    drop_flags=("-fno-slp-vectorize",) removes flags of COMMON for that variant (tools/pk_regress.py: the packed-FP32 probe build)."""
+    if drop_flags and not variant:
+        raise ValueError("drop_flags is for experiment variants only: the product library is always built with COMMON")
     tag = "trace" if trace else variant
     obj_dir = OBJ_DIR + (f"_{tag}" if tag else "")
     out = OUT.replace(".so", f"_{tag}.so") if tag else OUT
     extra = (("-DGF_TRACE",) if trace else ()) + tuple(defines)
     os.makedirs(obj_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, extra, obj_dir), sources()))
+        results = list(ex.map(lambda s: _compile(s, force, extra, obj_dir, tuple(drop_flags)), sources()))
     objs = [o for o, _ in results]
     if force or any(ch for _, ch in results) or not os.path.exists(out):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out, "-lz", "-lpthread"]   # zlib: the PNG frame writer (png_writer.cpp)

@@ -166,15 +166,19 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
         record["reference_kernels"] = {"mse": ref_losses, "fall": ref_fall}
         _dump(record)
         assert all(np.isfinite(ref_losses))
-        # "The same factor": the two runs share every draw but not their rounding, and 300 Adam steps amplify that -- the per-step losses
-        # decorrelate after ~50 steps while the curves stay on top of each other.  Measured on the MI355X: x0.0168 against x0.0147 (a 60-fold
-        # fall either way).  So the bar is on the curve, in the unit a loss curve is read in: the decades fallen agree to 10 %, the final
-        # plateaus to 30 %, and so does every 32-step window on the way down.
+        # "The same factor": the two runs share every draw but not their rounding (and the reference's table gradients are float atomics, so
+        # its own runs differ from each other), and 300 Adam steps with an occupancy refresh every 16 amplify that.  Measured on the MI355X
+        # (profiles/round5/r5b_closed_loop_loss_curves.json): the 16-step means agree to 2.7 % for the first 224 steps; then ONE of the two
+        # runs takes a transient the other does not (a refresh that flips cells sitting on the density threshold: x2.2 for 32 steps, gone
+        # by step 288); the falls over the whole run were x0.01528 / x0.01545 on one box, x0.0168 / x0.0147 on another.  So the bar is on
+        # the curve, in the unit a loss curve is read in: decades fallen within 10 %, final plateaus within 30 %, every 32-step window of
+        # the first 192 steps within 10 %, every later window within a factor of 3.
         assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.10, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
         assert abs(fall / ref_fall - 1.0) < 0.30, (fall, ref_fall)
         for a in range(0, STEPS - 32, 32):
             wa, wb = float(np.mean(losses[a:a + 32])), float(np.mean(ref_losses[a:a + 32]))
-            assert abs(wa / wb - 1.0) < 0.30, f"steps {a}..{a + 32}: mse {wa:.4g} (product) vs {wb:.4g} (reference kernels)"
+            tol = 0.10 if a < 192 else 2.0
+            assert abs(wa / wb - 1.0) < tol and abs(wb / wa - 1.0) < tol, f"steps {a}..{a + 32}: mse {wa:.4g} (product) vs {wb:.4g} (reference kernels)"
         assert abs(losses[0] / ref_losses[0] - 1.0) < 1e-3          # step 0: same weights, same draws, same picture
         # the two occupancy fields agree on almost every cell (a cell whose density sits on the threshold may fall either way)
         a, b = student.density_bitfield, ref_student.density_bitfield
