@@ -13,8 +13,12 @@ struct FrameWs {
     float* far_occ;  // min(far, exit of the occupancy bounding box): where marching may stop (no sample can lie beyond it)
     int32_t *alive_a, *alive_b;  // survivor list / hit list
     uint32_t* ctrl;  // [kCtrlWords]
+    // torso pass (frame_torso.hip, round 5): the masked pixels as a dense list, its inverse, and the field's outputs per list entry
+    uint32_t *torso_list, *torso_dense_of;   // [N] pixel of list entry j;  [N] list entry of pixel n, or kTorsoNone
+    float* torso_out;                        // [6][N] SoA by list entry: alpha, r, g, b, deform x, deform y
     size_t bytes;
 };
+constexpr uint32_t kTorsoNone = 0xFFFFFFFFu;
 constexpr uint32_t kMaxSteps = 1024;  // largest max_steps the fused path accepts: the reference's own default (renderer.py:263) and the top of
                                       // its viewer's slider (radnerf_gui.py:466-471).  (64 until round 4: the size of the LDS histogram, which now
                                       // only holds the first kHistLds bins; later terminal indices go to the control block directly.)
@@ -28,6 +32,7 @@ constexpr uint32_t kCtrlNHit = 1;      // rays with >= 1 sample (length of the h
 constexpr uint32_t kCtrlNSurv = 2;     // rays still alive after max_steps samples (length of the survivor list, alive_a)
 constexpr uint32_t kCtrlQHead1 = 3;    // phase 1: next unclaimed entry of the survivor list
 constexpr uint32_t kCtrlBudget = 10;   // total per-ray sample budget B the reference's n_step schedule arrives at
+constexpr uint32_t kCtrlTorsoCount = 16;   // torso pass: pixels the torso mask selects (length of torso_list); written after the head kernels are done
 // line 1: statistics (two 64-bit adds per workgroup and phase: [samples | tiles << 32], [rounds | composited << 32])
 constexpr uint32_t kCtrlStatA = 32;    // [2 phases] uint64: field evaluations (low word) | 32-sample MFMA tiles executed (high word)
 constexpr uint32_t kCtrlStatB = 36;    // [2 phases] uint64: workgroup rounds (low) | samples the compositor consumed (high; <= evaluations: a ray
@@ -54,6 +59,9 @@ inline FrameWs carve_workspace(void* base, uint32_t n_rays) {
     w.alive_a = (int32_t*)take(N * 4);
     w.alive_b = (int32_t*)take(N * 4);
     w.ctrl = (uint32_t*)take(kCtrlWords * 4);
+    w.torso_list = (uint32_t*)take(N * 4);
+    w.torso_dense_of = (uint32_t*)take(N * 4);
+    w.torso_out = (float*)take(N * 24);
     w.bytes = off;
     return w;
 }

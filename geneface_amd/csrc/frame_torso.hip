@@ -4,9 +4,18 @@
 //
 // Replaces RADNeRFTorso.render's tail (/root/reference/modules/radnerfs/radnerf_torso.py:156-198) and forward_torso
 // (:51-84): grid_sample + boolean-mask gather/scatter (host sync on mask.any()), 2 freq encodes, 6 GEMMs, a grid
-// encode, cats/sigmoids and five elementwise blends -- ~25 launches -- become one kernel.
-// A 256-thread workgroup owns 256 consecutive pixels; masked ones are packed densely and processed as 32-pixel MFMA
-// tiles (same register-chained layer scheme as the head, mfma_mlp.hpp); all torso weights (44 KB) stay LDS-resident.
+// encode, cats/sigmoids and five elementwise blends -- ~25 launches.
+//
+// Three launches since round 5 (one until then):
+//   k_torso_mask   one lane per pixel: the mask (bilinear sample of the occupancy > threshold) and a DENSE LIST of the masked pixels
+//                  (ballot / popcount inside a workgroup, one atomic per workgroup for its range of the list) + the list's inverse;
+//   k_torso_field  the field over the list: a wave owns 32 consecutive list entries (one MFMA tile, the register-chained layer scheme of
+//                  mfma_mlp.hpp), a workgroup 128, all torso weights (44 KB) LDS-resident; workgroups beyond the list's end leave at once;
+//   k_torso_blend  one lane per pixel: torso over background, head over that, clamp, depth, uint8.
+// Why: the masked pixels are the lower part of the picture.  With one workgroup per 256 consecutive pixels the field ran on the ~40 % of
+// the workgroups that cover those rows, two tiles deep on each of their waves (8 tiles on 4 waves) while the others only blended; over the
+// dense list every wave of every launched workgroup has exactly one tile.  Same values: a pixel's field is a column of the MFMA tiles,
+// independent of which pixels share its tile, so frames are bit-identical to the one-kernel form (tools/frame_digests.py).
 #include "common.hpp"
 #include "frame.hpp"
 #include "grid_core.hpp"
@@ -27,6 +36,9 @@ struct TorsoArgs {
     float *out_rgb, *out_depth, *out_alpha, *out_torso_rgb, *out_deform; uint8_t* out_rgb8;
     const float* ha;       // head-aware extension pack (frame.hpp TH_*), HA launches only
     const float* ha_enc;   // [N,16] encoder outputs (k_head_aware_encode), HA launches only
+    const uint32_t *list, *dense_of, *count;   // the masked pixels as a dense list, its inverse, its length (k_torso_mask)
+    uint32_t* count_reset; // == count, for the blend's final clear
+    float* tout;           // [6][N] field outputs by list entry
 };
 
 __device__ __forceinline__ float leaky02(float x) { return x > 0.0f ? x : 0.02f * x; }
@@ -98,127 +110,136 @@ __device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
     return sinf(scalbnf(d ? x1 : x0, freq) + phase);
 }
 
+// ---- (1) mask + dense list.  list order: workgroups in the order their atomics retire, pixels in order inside a workgroup -- any order gives
+// the same frame (see the header); dense_of is the inverse the blend reads.
+__global__ void __launch_bounds__(kThreads) k_torso_mask(uint32_t N, uint32_t G, const float* __restrict__ bg_coords, const float* __restrict__ occ,
+                                                         float thresh, uint32_t* __restrict__ list, uint32_t* __restrict__ dense_of,
+                                                         uint32_t* __restrict__ count) {
+    __shared__ uint32_t wcnt[kThreads / 64];
+    __shared__ uint32_t wg_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = blockIdx.x * kThreads + tid;
+    bool masked = false;
+    if (n < N) masked = sample_occ(occ, (int)G, bg_coords[(size_t)n * 2], bg_coords[(size_t)n * 2 + 1]) > thresh;
+    const unsigned long long bal = __ballot(masked);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kThreads / 64; w++) { const uint32_t c = wcnt[w]; if (w < wave) before += c; total += c; }
+    if (tid == 0) wg_base = total ? atomicAdd(count, total) : 0u;     // (L2 retires same-address atomics at ~10 ns each: ~5 us for a 512 x 512 frame's
+                                                                      //  masked workgroups -- why frame loops build the list once, gf_torso_mask_list)
+    __syncthreads();
+    if (n < N) {
+        const uint32_t j = wg_base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (masked) list[j] = n;
+        dense_of[n] = masked ? j : gf::kTorsoNone;
+    }
+}
+
+// ---- (2) the field over the list
 template <bool HA>
-__global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ha = reinterpret_cast<float*>(smem_raw);     // [TH_W0]: the two extra weight streams (HA launches only)
     float* pack = ha + (HA ? gf::TH_W0 : 0);            // [TP_TOTAL]
     float* bias = pack + gf::TP_TOTAL;                  // [TB_TOTAL]
     float* meta = bias + gf::TB_TOTAL;                  // [64]
-    float* o_a = meta + 64;                             // [256] per local pixel: alpha, r, g, b, dx0, dx1
-    float* o_r = o_a + kThreads; float* o_g = o_r + kThreads; float* o_b = o_g + kThreads;
-    float* o_dx = o_b + kThreads; float* o_dy = o_dx + kThreads;
-    uint32_t* d2p = reinterpret_cast<uint32_t*>(o_dy + kThreads);  // [256] dense -> local pixel
-    uint32_t* wcnt = d2p + kThreads;                               // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const uint32_t n = blockIdx.x * kThreads + tid;
-    const bool in_img = n < a.N;
+    const uint32_t Mt = *a.count;
+    if ((uint32_t)blockIdx.x * 128u >= Mt) return;      // workgroup-uniform: nothing of the list is ours (no weight copy either)
 
-    float cx = 0.0f, cy = 0.0f;
-    bool masked = false;
-    if (in_img) {
-        cx = a.bg_coords[(size_t)n * 2];
-        cy = a.bg_coords[(size_t)n * 2 + 1];
-        masked = sample_occ(a.occ, (int)a.G, cx, cy) > a.thresh;
+    for (int i = tid; i < (int)gf::TP_TOTAL / 4; i += kThreads) reinterpret_cast<float4*>(pack)[i] = reinterpret_cast<const float4*>(a.pack)[i];
+    if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
+    if constexpr (HA) {
+        for (int i = tid; i < (int)gf::TH_W0 / 4; i += kThreads) reinterpret_cast<float4*>(ha)[i] = reinterpret_cast<const float4*>(a.ha)[i];
     }
-    // dense packing of the masked pixels of this workgroup (pixel order preserved)
-    const unsigned long long bal = __ballot(masked);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
-    o_a[tid] = 0.0f; o_r[tid] = 0.0f; o_g[tid] = 0.0f; o_b[tid] = 0.0f;
+    if (tid < 16) {
+        meta[tid * 4 + 0] = a.lv.scale[tid];
+        meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
+        meta[tid * 4 + 2] = __uint_as_float((uint32_t)a.offsets[tid]);
+        meta[tid * 4 + 3] = __uint_as_float((uint32_t)(a.offsets[tid + 1] - a.offsets[tid]));
+    }
     __syncthreads();
-    uint32_t wbase = 0, Mt = 0;
-    for (int w = 0; w < kThreads / 64; w++) { const uint32_t c = wcnt[w]; if (w < wave) wbase += c; Mt += c; }
-    if (masked) d2p[wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)tid;
+    for (uint32_t base = (uint32_t)blockIdx.x * 128u; base < Mt; base += gridDim.x * 128u) {
+        const uint32_t tile0 = base + wave * 32;
+        if (tile0 >= Mt) continue;  // wave-uniform; no barriers inside the tile body
+        const uint32_t j = tile0 + (lane & 31);
+        const bool valid = j < Mt;
+        const uint32_t pix = a.list[valid ? j : tile0];
+        const float x0 = a.bg_coords[(size_t)pix * 2] * a.shrink, x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
 
-    if (Mt > 0) {  // workgroup-uniform
-        for (int i = tid; i < (int)gf::TP_TOTAL / 4; i += kThreads) reinterpret_cast<float4*>(pack)[i] = reinterpret_cast<const float4*>(a.pack)[i];
-        if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
+        float e8[8];
+        if constexpr (HA) {   // encoder output 8 * half + t of this pixel (k_head_aware_encode): the B operand of the 8 extra steps of both first layers
+            const float4* e4 = reinterpret_cast<const float4*>(a.ha_enc + (size_t)pix * 16 + 8 * half);
+            const float4 u = e4[0], v = e4[1];
+            e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
+        }
+        float enc[24];
+#pragma unroll
+        for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
+
+        floatx16 h2[2];
+        float act2[32];
         if constexpr (HA) {
-            for (int i = tid; i < (int)gf::TH_W0 / 4; i += kThreads) reinterpret_cast<float4*>(ha)[i] = reinterpret_cast<const float4*>(a.ha)[i];
+            gf::mfma_layer<2, 24, false, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+            gf::mfma_part<2, 0, 2, 8, true, true>(ha + gf::TH_D1E, lane, e8, nullptr, h2);
+        } else {
+            gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
         }
-        if (tid < 16) {
-            meta[tid * 4 + 0] = a.lv.scale[tid];
-            meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
-            meta[tid * 4 + 2] = __uint_as_float((uint32_t)a.offsets[tid]);
-            meta[tid * 4 + 3] = __uint_as_float((uint32_t)(a.offsets[tid + 1] - a.offsets[tid]));
+        gf::unpack<2>(h2, act2);
+        gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
+        gf::unpack<2>(h2, act2);
+        float dx[2];
+        gf::valu_rows<2, 2>(pack + gf::TP_D3, half, act2, dx);
+
+        const float xc[2] = {(fminf(fmaxf(x0 + dx[0], -1.0f), 1.0f) + 1.0f) / 2.0f, (fminf(fmaxf(x1 + dx[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
+        float in[40];
+        {
+            float g[16];
+            gf::encode_half<2>(a.table, meta, half, 1u /*tiled*/, 0u /*linear*/, xc, g);
+#pragma unroll
+            for (int t = 0; t < 16; t++) in[t] = g[t];
+#pragma unroll
+            for (int t = 0; t < 24; t++) in[16 + t] = enc[t];
         }
-        __syncthreads();
-        for (uint32_t base = 0; base < Mt; base += 128) {
-            const uint32_t tile0 = base + wave * 32;
-            if (tile0 >= Mt) continue;  // wave-uniform; no barriers inside the tile body
-            const uint32_t j = tile0 + (lane & 31);
-            const bool valid = j < Mt;
-            const uint32_t p = valid ? d2p[j] : d2p[tile0];
-            const uint32_t pix = blockIdx.x * kThreads + p;
-            const float x0 = a.bg_coords[(size_t)pix * 2] * a.shrink, x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
-
-            float e8[8];
-            if constexpr (HA) {   // encoder output 8 * half + t of this pixel (k_head_aware_encode): the B operand of the 8 extra steps of both first layers
-                const float4* e4 = reinterpret_cast<const float4*>(a.ha_enc + (size_t)pix * 16 + 8 * half);
-                const float4 u = e4[0], v = e4[1];
-                e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
-            }
-            float enc[24];
-#pragma unroll
-            for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
-
-            floatx16 h2[2];
-            float act2[32];
-            if constexpr (HA) {
-                gf::mfma_layer<2, 24, false, false>(pack + gf::TP_D1, lane, enc, bias, h2);
-                gf::mfma_part<2, 0, 2, 8, true, true>(ha + gf::TH_D1E, lane, e8, nullptr, h2);
-            } else {
-                gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
-            }
-            gf::unpack<2>(h2, act2);
-            gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
-            gf::unpack<2>(h2, act2);
-            float dx[2];
-            gf::valu_rows<2, 2>(pack + gf::TP_D3, half, act2, dx);
-
-            const float xc[2] = {(fminf(fmaxf(x0 + dx[0], -1.0f), 1.0f) + 1.0f) / 2.0f, (fminf(fmaxf(x1 + dx[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
-            float in[40];
-            {
-                float g[16];
-                gf::encode_half<2>(a.table, meta, half, 1u /*tiled*/, 0u /*linear*/, xc, g);
-#pragma unroll
-                for (int t = 0; t < 16; t++) in[t] = g[t];
-#pragma unroll
-                for (int t = 0; t < 24; t++) in[16 + t] = enc[t];
-            }
-            floatx16 h1[1];
-            float act1[16];
-            if constexpr (HA) {
-                gf::mfma_layer<1, 40, false, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
-                gf::mfma_part<1, 0, 1, 8, true, true>(ha + gf::TH_C1E, lane, e8, nullptr, h1);
-            } else {
-                gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
-            }
-            gf::unpack<1>(h1, act1);
-            gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
-            gf::unpack<1>(h1, act1);
-            float o4[4];
-            gf::valu_rows<4, 1>(pack + gf::TP_C3, half, act1, o4);
-            if (valid && half == 0) {
-                o_a[p] = 1.0f / (1.0f + __expf(-o4[0]));
-                o_r[p] = 1.0f / (1.0f + __expf(-o4[1]));
-                o_g[p] = 1.0f / (1.0f + __expf(-o4[2]));
-                o_b[p] = 1.0f / (1.0f + __expf(-o4[3]));
-                o_dx[p] = dx[0];
-                o_dy[p] = dx[1];
-            }
+        floatx16 h1[1];
+        float act1[16];
+        if constexpr (HA) {
+            gf::mfma_layer<1, 40, false, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+            gf::mfma_part<1, 0, 1, 8, true, true>(ha + gf::TH_C1E, lane, e8, nullptr, h1);
+        } else {
+            gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
         }
-        __syncthreads();
+        gf::unpack<1>(h1, act1);
+        gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
+        gf::unpack<1>(h1, act1);
+        float o4[4];
+        gf::valu_rows<4, 1>(pack + gf::TP_C3, half, act1, o4);
+        if (valid && half == 0) {      // SoA by list entry: 32 consecutive floats per array and tile
+            const size_t N = a.N;
+            a.tout[j] = 1.0f / (1.0f + __expf(-o4[0]));
+            a.tout[N + j] = 1.0f / (1.0f + __expf(-o4[1]));
+            a.tout[2 * N + j] = 1.0f / (1.0f + __expf(-o4[2]));
+            a.tout[3 * N + j] = 1.0f / (1.0f + __expf(-o4[3]));
+            a.tout[4 * N + j] = dx[0];
+            a.tout[5 * N + j] = dx[1];
+        }
     }
+}
 
-    if (!in_img) return;
-    // radnerf_torso.py:186-193: torso over background, head over that, clamp, depth normalisation
-    const float alpha = o_a[tid];
-    const float tc[3] = {o_r[tid], o_g[tid], o_b[tid]};
+// ---- (3) radnerf_torso.py:186-193: torso over background, head over that, clamp, depth normalisation
+__global__ void __launch_bounds__(kThreads) k_torso_blend(const TorsoArgs a) {
+    const uint32_t n = blockIdx.x * kThreads + threadIdx.x;
+    if (n >= a.N) return;
+    const uint32_t j = a.dense_of[n];
+    const bool masked = j != gf::kTorsoNone;
+    const size_t N = a.N;
+    const float alpha = masked ? a.tout[j] : 0.0f;
+    const float tc[3] = {masked ? a.tout[N + j] : 0.0f, masked ? a.tout[2 * N + j] : 0.0f, masked ? a.tout[3 * N + j] : 0.0f};
     const float ws = a.weights_sum[n];
     if (a.out_alpha) a.out_alpha[n] = alpha;
-    if (a.out_deform && masked) { a.out_deform[(size_t)n * 2] = o_dx[tid]; a.out_deform[(size_t)n * 2 + 1] = o_dy[tid]; }
+    if (a.out_deform && masked) { a.out_deform[(size_t)n * 2] = a.tout[4 * N + j]; a.out_deform[(size_t)n * 2 + 1] = a.tout[5 * N + j]; }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float bgc = tc[c] * alpha + a.bg[(size_t)n * 3 + c] * (1 - alpha);
@@ -229,9 +250,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_finish(const TorsoArgs a)
         if (a.out_rgb8) a.out_rgb8[(size_t)n * 3 + c] = (uint8_t)(v * 255.0f);
     }
     a.out_depth[n] = fmaxf(a.depth[n] - a.nears[n], 0.0f) / (a.fars[n] - a.nears[n]);
+    if (n == 0 && a.count_reset) *a.count_reset = 0u;     // the list is consumed (k_torso_field finished before this launch started): a second torso pass on the same head starts a new one
 }
 
-constexpr size_t kTorsoSmem = (gf::TP_TOTAL + gf::TB_TOTAL + 64 + 6 * kThreads + kThreads + 8) * sizeof(float);
+constexpr size_t kTorsoSmem = (gf::TP_TOTAL + gf::TB_TOTAL + 64) * sizeof(float);
 
 }  // namespace
 
@@ -261,12 +283,41 @@ GF_EXPORT int gf_render_torso(const gf_frame_t* f, void* stream) {
                            w.weights_sum, f->torso_ha_pack, f->torso_ha_ws);
         a.ha_enc = f->torso_ha_ws;
     }
+    const bool given = f->torso_mask_list != nullptr;
+    if (given != (f->torso_mask_dense_of != nullptr) || given != (f->torso_mask_count != nullptr))
+        return gf_set_error(GF_ERR_INVALID, "torso: torso_mask_list / torso_mask_dense_of / torso_mask_count must be given together");
+    a.list = given ? f->torso_mask_list : w.torso_list;
+    a.dense_of = given ? f->torso_mask_dense_of : w.torso_dense_of;
+    a.count = given ? f->torso_mask_count : w.ctrl + gf::kCtrlTorsoCount;
+    a.count_reset = given ? nullptr : w.ctrl + gf::kCtrlTorsoCount;
+    a.tout = w.torso_out;
     static GfLdsAttr lds[2];
     const size_t smem = kTorsoSmem + (ha ? gf::TH_W0 * sizeof(float) : 0);
-    const void* fn = ha ? reinterpret_cast<const void*>(k_torso_finish<true>) : reinterpret_cast<const void*>(k_torso_finish<false>);
+    const void* fn = ha ? reinterpret_cast<const void*>(k_torso_field<true>) : reinterpret_cast<const void*>(k_torso_field<false>);
     if (const int e = gf_raise_lds_limit(lds[ha], fn, (int)smem, "torso")) return e;
-    const dim3 grid(gf_div_up(f->n_rays, (uint32_t)kThreads));
-    if (ha) hipLaunchKernelGGL(k_torso_finish<true>, grid, dim3(kThreads), smem, gf_stream(stream), a);
-    else hipLaunchKernelGGL(k_torso_finish<false>, grid, dim3(kThreads), smem, gf_stream(stream), a);
+    hipStream_t st = gf_stream(stream);
+    const dim3 per_pixel(gf_div_up(f->n_rays, (uint32_t)kThreads));
+    // the count word was cleared with the rest of the control block at the head of the frame (gf_render_head) and nothing has touched it since
+    if (!given)
+        hipLaunchKernelGGL(k_torso_mask, per_pixel, dim3(kThreads), 0, st, f->n_rays, f->grid_size, f->bg_coords, f->torso_occ, f->torso_thresh,
+                           w.torso_list, w.torso_dense_of, w.ctrl + gf::kCtrlTorsoCount);
+    // one workgroup per 128 list entries up to 512 workgroups (two per CU), which then stride over a longer list; the list's length is only
+    // known on the device: workgroups beyond it return before they copy a weight
+    const dim3 field_grid(gf_div_up(f->n_rays, 128u) < 512u ? gf_div_up(f->n_rays, 128u) : 512u);
+    if (ha) hipLaunchKernelGGL(k_torso_field<true>, field_grid, dim3(kThreads), smem, st, a);
+    else hipLaunchKernelGGL(k_torso_field<false>, field_grid, dim3(kThreads), smem, st, a);
+    hipLaunchKernelGGL(k_torso_blend, per_pixel, dim3(kThreads), 0, st, a);
     return gf_check_launch("render_torso");
+}
+
+// The torso mask as a dense list for a whole frame loop (gf_frame_t.torso_mask_*): k_torso_mask into caller-owned buffers.
+GF_EXPORT int gf_torso_mask_list(const float* bg_coords, const float* torso_occ, uint32_t n_rays, uint32_t grid_size, float torso_thresh, uint32_t* list,
+                                 uint32_t* dense_of, uint32_t* count, void* stream) {
+    if (!bg_coords || !torso_occ || !list || !dense_of || !count) return gf_set_error(GF_ERR_INVALID, "torso_mask_list: null pointer");
+    hipStream_t st = gf_stream(stream);
+    if (hipMemsetAsync(count, 0, sizeof(uint32_t), st) != hipSuccess) return gf_set_error(GF_ERR_HIP, "torso_mask_list: hipMemsetAsync failed");
+    if (n_rays == 0) return GF_OK;
+    hipLaunchKernelGGL(k_torso_mask, dim3(gf_div_up(n_rays, (uint32_t)kThreads)), dim3(kThreads), 0, st, n_rays, grid_size, bg_coords, torso_occ, torso_thresh,
+                       list, dense_of, count);
+    return gf_check_launch("torso_mask_list");
 }

@@ -197,7 +197,19 @@ typedef struct gf_frame_t {
     const float* torso_ha_pack;
     float* torso_ha_ws;         /* [N,16] scratch for the encoder's outputs; needed when torso_ha_branch = 1 */
     uint32_t torso_ha_branch, _pad4;
+    /* The torso mask as a dense list (round 5): which pixels `grid_sample(density_grid_torso, bg_coords) > torso_thresh` selects
+     * (radnerf_torso.py:166-172) is a property of (bg_coords, torso_occ, torso_thresh, n_rays) -- constant over a frame loop.  A caller that
+     * renders many frames builds the list once with gf_torso_mask_list() and hands it in here; with torso_mask_list == NULL gf_render_torso
+     * builds it for every frame in the workspace.  All three device pointers or none. */
+    const uint32_t* torso_mask_list;      /* [count] pixel indices of the masked pixels (any order) */
+    const uint32_t* torso_mask_dense_of;  /* [N] position of pixel n in the list, 0xFFFFFFFF when the mask does not select it */
+    const uint32_t* torso_mask_count;     /* [1] length of the list */
 } gf_frame_t;
+
+/* gf_frame_t.torso_mask_*: the masked pixels of a torso pass as a dense list, built once for many frames.  bg_coords [N,2], torso_occ [G*G],
+ * list / dense_of [N] uint32, count [1] uint32 (overwritten).  Same mask arithmetic as gf_render_torso (one device function). */
+int gf_torso_mask_list(const float* bg_coords, const float* torso_occ, uint32_t n_rays, uint32_t grid_size, float torso_thresh, uint32_t* list,
+                       uint32_t* dense_of, uint32_t* count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-frame condition encoder: RADNeRF.cal_cond_feat (modules/radnerfs/radnerf.py:61-71) =

