@@ -1208,6 +1208,6 @@ def test_torso_mask_list_is_rebuilt_when_its_inputs_change():
     b = both(1)
     assert get_state(model)._mask_list is not entry and int(get_state(model)._mask_list[1][2].item()) < n_masked
     assert not torch.equal(a, b)
-    model.density_thresh_torso = 0.5                                              # the threshold is part of the key as well
+    model.density_thresh_torso, model.mean_density_torso = 0.5, 1.0               # threshold = min of the two (radnerf_torso.py:170): part of the key as well
     c = both(1)
     assert not torch.equal(b, c)
