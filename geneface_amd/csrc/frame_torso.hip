@@ -20,6 +20,7 @@
 #include "frame.hpp"
 #include "grid_core.hpp"
 #include "mfma_mlp.hpp"
+#include "sh_core.hpp"
 
 namespace {
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
     if (e < 2) return e ? x1 : x0;
     const int col = e / 2 - 1, d = e & 1, freq = col >> 1;
     const float phase = (col & 1) ? (3.141592653589793f / 2) : 0.0f;
-    return sinf(scalbnf(d ? x1 : x0, freq) + phase);
+    return gf::sin_bounded(scalbnf(d ? x1 : x0, freq) + phase);
 }
 
 // ---- (1) mask + dense list.  list order: workgroups in the order their atomics retire, pixels in order inside a workgroup -- any order gives

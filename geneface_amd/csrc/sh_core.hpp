@@ -113,6 +113,34 @@ __device__ __forceinline__ void sh_high(float x, float y, float z, uint32_t degr
     }
 }
 
+// sin(x) for the frequency encodings (round 5).  The reference calls the hardware's fast sine (__sinf, freqencoder.cu:52: absolute error that
+// grows with |x|); oracle and product evaluate the function it approximates.  libm's sinf carries a Payne-Hanek reduction for arguments up to
+// 3e38 that the compiler must inline in full -- ~100 VALU operations per call, 2 400 of the 4 000 VALU instructions of a torso tile (24
+// encodings per lane), the largest single item of k_torso_field.  The encodings' arguments are 2^f x + {0, pi/2} with f <= 9 and |x| of order 1:
+// a three-term Cody-Waite reduction with fused multiply-adds (pi/2 = C1 + C2 + C3 to 2^-75) and the two degree-9 / degree-8 minimax
+// polynomials on [-pi/4, pi/4] do it in ~24 operations, absolute error <= 9.3e-8 against the exact sine over |x| <= 512 (measured on 12 M
+// arguments in fp32 emulation; glibc's sinf: 7.0e-8), <= 1.6 ulp wherever |sin| > 0.01.  Beyond |x| = 8192 (never reached by an encoding of a
+// bounded coordinate; the op seam accepts any float) and for NaN the call falls back to sinf.
+__device__ __forceinline__ float sin_bounded(float x) {
+    if (!(fabsf(x) <= 8192.0f)) return sinf(x);
+    const float n = rintf(x * 0.63661977236758134f);
+    float r = __builtin_fmaf(-n, 1.5707963705062866f, x);
+    r = __builtin_fmaf(-n, -4.371138828673793e-08f, r);
+    r = __builtin_fmaf(-n, -1.7763568394002505e-15f, r);
+    const float r2 = r * r;
+    float ps = __builtin_fmaf(r2, 2.7557314297e-06f, -1.9841270114e-04f);
+    ps = __builtin_fmaf(r2, ps, 8.3333337680e-03f);
+    ps = __builtin_fmaf(r2, ps, -1.6666667163e-01f);
+    const float s = __builtin_fmaf(r * r2, ps, r);
+    float pc = __builtin_fmaf(r2, -2.7557314297e-07f, 2.4801587642e-05f);
+    pc = __builtin_fmaf(r2, pc, -1.3888889225e-03f);
+    pc = __builtin_fmaf(r2, pc, 4.1666667908e-02f);
+    const float c = __builtin_fmaf(r2 * r2, pc, __builtin_fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)n;
+    const float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
 // element c of the [D + 2*D*deg] frequency encoding of in[0..D):
 //   [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...], cos evaluated as sin(. + pi/2) with pi/2 rounded to fp32
 __device__ __forceinline__ float freq_element(const float* __restrict__ in, uint32_t D, uint32_t c) {
@@ -120,8 +148,8 @@ __device__ __forceinline__ float freq_element(const float* __restrict__ in, uint
     const uint32_t col = c / D - 1, d = c - (col + 1) * D, freq = col >> 1;
     const float phase = (col & 1u) ? (3.141592653589793f / 2) : 0.0f;
     // the reference's __sinf is a hardware-specific fast sine (error grows with |x|, and the torso's
-    // 2^9 x reaches ~400 rad); the correctly-rounded-ish sinf is the centroid every fast sine approximates
-    return sinf(scalbnf(in[d], (int)freq) + phase);
+    // 2^9 x reaches ~400 rad); the accurate sine is the centroid every fast sine approximates
+    return sin_bounded(scalbnf(in[d], (int)freq) + phase);
 }
 
 }  // namespace gf
