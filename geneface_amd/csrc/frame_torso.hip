@@ -27,6 +27,20 @@ namespace {
 using gf::floatx16;
 constexpr int kThreads = 256;
 
+// Trace build only (-DGF_TRACE, tools/trace_torso.py): lane 0 of every wave of the first kTTraceWGs field workgroups stamps s_memtime at the
+// segment boundaries of its first tile.  The product library carries none of it.
+#ifdef GF_TRACE
+constexpr int kTTraceWGs = 64, kTTraceSlots = 16;
+static unsigned long long* g_ttrace_buf = nullptr;
+#define GF_TSTAMP(i)                                                                                                     \
+    do {                                                                                                                 \
+        if (a.ttrace && blockIdx.x < kTTraceWGs && lane == 0 && first_tile)                                              \
+            a.ttrace[((size_t)blockIdx.x * 4 + wave) * kTTraceSlots + (i)] = __builtin_amdgcn_s_memtime();              \
+    } while (0)
+#else
+#define GF_TSTAMP(i) do { } while (0)
+#endif
+
 struct TorsoArgs {
     uint32_t N, G;
     const float *image, *weights_sum, *depth, *nears, *fars;  // head accumulators (workspace)
@@ -39,6 +53,9 @@ struct TorsoArgs {
     const float* ha_enc;   // [N,16] encoder outputs (k_head_aware_encode), HA launches only
     const uint32_t *list, *dense_of, *count;   // the masked pixels as a dense list, its inverse, its length (k_torso_mask)
     uint32_t* count_reset; // == count, for the blend's final clear
+#ifdef GF_TRACE
+    unsigned long long* ttrace;
+#endif
     float* tout;           // [6][N] field outputs by list entry
 };
 
@@ -103,12 +120,15 @@ __device__ __forceinline__ float sample_occ(const float* __restrict__ occ, int G
 }
 
 // entry e (0..47) of the zero-padded frequency encoding of a 2-vector (42 real entries, freqencoder.cu:30-58 layout)
+// Branch-free: the sine is evaluated for every entry (on a harmless argument for the two pass-through and the six padding entries) and
+// selected afterwards, so the 24 entries of a lane are 24 independent chains the scheduler interleaves.  Arguments are 2^f x + {0, pi/2} with
+// f <= 9 and x = bg_coords * torso_shrink, |x| <= 1 for coordinates that are pixel coordinates: sin_reduced's domain (sh_core.hpp).
 __device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
-    if (e >= 42) return 0.0f;
-    if (e < 2) return e ? x1 : x0;
-    const int col = e / 2 - 1, d = e & 1, freq = col >> 1;
+    const int ee = e < 2 ? 2 : (e >= 42 ? 2 : e);
+    const int col = ee / 2 - 1, d = ee & 1, freq = col >> 1;
     const float phase = (col & 1) ? (3.141592653589793f / 2) : 0.0f;
-    return gf::sin_bounded(scalbnf(d ? x1 : x0, freq) + phase);
+    const float sv = gf::sin_reduced(scalbnf(d ? x1 : x0, freq) + phase);
+    return e >= 42 ? 0.0f : (e < 2 ? (e ? x1 : x0) : sv);
 }
 
 // ---- (1) mask + dense list.  list order: workgroups in the order their atomics retire, pixels in order inside a workgroup -- any order gives
@@ -147,38 +167,57 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
     float* meta = bias + gf::TB_TOTAL;                  // [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    [[maybe_unused]] bool first_tile = true;
+    GF_TSTAMP(0);
     const uint32_t Mt = *a.count;
     if ((uint32_t)blockIdx.x * 128u >= Mt) return;      // workgroup-uniform: nothing of the list is ours (no weight copy either)
+    GF_TSTAMP(1);
 
-    for (int i = tid; i < (int)gf::TP_TOTAL / 4; i += kThreads) reinterpret_cast<float4*>(pack)[i] = reinterpret_cast<const float4*>(a.pack)[i];
+    // The 44 KB of weights travel L2 -> LDS as asynchronous 1-KiB wave instructions that touch no register (global_load ... lds), and the
+    // first tile's list entry, coordinates and 24 frequency encodings -- which need none of them -- are computed while they fly; the barrier
+    // in front of the first MFMA waits for both.  (Through registers and with the barrier first, the copy was 8.7 K of a tile's 50.5 K
+    // cycles and the encodings another 11.4 K: tools/trace_torso.py, profiles/round5/r5e_torso_field_timeline_before.txt.)
+    static_assert(gf::TP_TOTAL % 256 == 0 && gf::TH_W0 % 256 == 0, "whole 1-KiB DMA instructions");
+    gf::dma_to_lds(pack, a.pack, (int)gf::TP_TOTAL, wave, lane);
+    if constexpr (HA) gf::dma_to_lds(ha, a.ha, (int)gf::TH_W0, wave, lane);
     if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
-    if constexpr (HA) {
-        for (int i = tid; i < (int)gf::TH_W0 / 4; i += kThreads) reinterpret_cast<float4*>(ha)[i] = reinterpret_cast<const float4*>(a.ha)[i];
-    }
     if (tid < 16) {
         meta[tid * 4 + 0] = a.lv.scale[tid];
         meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
         meta[tid * 4 + 2] = __uint_as_float((uint32_t)a.offsets[tid]);
         meta[tid * 4 + 3] = __uint_as_float((uint32_t)(a.offsets[tid + 1] - a.offsets[tid]));
     }
-    __syncthreads();
+    GF_TSTAMP(2);
+    bool weights_ready = false;
     for (uint32_t base = (uint32_t)blockIdx.x * 128u; base < Mt; base += gridDim.x * 128u) {
         const uint32_t tile0 = base + wave * 32;
-        if (tile0 >= Mt) continue;  // wave-uniform; no barriers inside the tile body
-        const uint32_t j = tile0 + (lane & 31);
-        const bool valid = j < Mt;
-        const uint32_t pix = a.list[valid ? j : tile0];
-        const float x0 = a.bg_coords[(size_t)pix * 2] * a.shrink, x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
-
+        const bool have_tile = tile0 < Mt;    // wave-uniform
+        uint32_t j = 0, pix = 0;
+        bool valid = false;
+        float x0 = 0.0f, x1 = 0.0f;
         float e8[8];
-        if constexpr (HA) {   // encoder output 8 * half + t of this pixel (k_head_aware_encode): the B operand of the 8 extra steps of both first layers
-            const float4* e4 = reinterpret_cast<const float4*>(a.ha_enc + (size_t)pix * 16 + 8 * half);
-            const float4 u = e4[0], v = e4[1];
-            e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
-        }
         float enc[24];
+        if (have_tile) {
+            j = tile0 + (lane & 31);
+            valid = j < Mt;
+            pix = a.list[valid ? j : tile0];
+            x0 = a.bg_coords[(size_t)pix * 2] * a.shrink; x1 = a.bg_coords[(size_t)pix * 2 + 1] * a.shrink;
+            GF_TSTAMP(3);
+            if constexpr (HA) {   // encoder output 8 * half + t of this pixel (k_head_aware_encode): the B operand of the 8 extra steps of both first layers
+                const float4* e4 = reinterpret_cast<const float4*>(a.ha_enc + (size_t)pix * 16 + 8 * half);
+                const float4 u = e4[0], v = e4[1];
+                e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
+            }
 #pragma unroll
-        for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
+            for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
+        }
+        if (!weights_ready) {     // workgroup-uniform (first trip of every wave, whether it has a tile or not): the DMA has landed for everybody
+            __builtin_amdgcn_s_waitcnt(0);     // this wave's asynchronous copies (vmcnt) and LDS stores
+            __syncthreads();
+            weights_ready = true;
+        }
+        if (!have_tile) continue;
+        GF_TSTAMP(4);
 
         floatx16 h2[2];
         float act2[32];
@@ -189,10 +228,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
             gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
         }
         gf::unpack<2>(h2, act2);
+        GF_TSTAMP(5);
         gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
         gf::unpack<2>(h2, act2);
+        GF_TSTAMP(6);
         float dx[2];
         gf::valu_rows<2, 2>(pack + gf::TP_D3, half, act2, dx);
+        GF_TSTAMP(7);
 
         const float xc[2] = {(fminf(fmaxf(x0 + dx[0], -1.0f), 1.0f) + 1.0f) / 2.0f, (fminf(fmaxf(x1 + dx[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
         float in[40];
@@ -204,6 +246,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
 #pragma unroll
             for (int t = 0; t < 24; t++) in[16 + t] = enc[t];
         }
+        GF_TSTAMP(8);
         floatx16 h1[1];
         float act1[16];
         if constexpr (HA) {
@@ -213,10 +256,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
             gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
         }
         gf::unpack<1>(h1, act1);
+        GF_TSTAMP(9);
         gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
         gf::unpack<1>(h1, act1);
+        GF_TSTAMP(10);
         float o4[4];
         gf::valu_rows<4, 1>(pack + gf::TP_C3, half, act1, o4);
+        GF_TSTAMP(11);
         if (valid && half == 0) {      // SoA by list entry: 32 consecutive floats per array and tile
             const size_t N = a.N;
             a.tout[j] = 1.0f / (1.0f + __expf(-o4[0]));
@@ -226,6 +272,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
             a.tout[4 * N + j] = dx[0];
             a.tout[5 * N + j] = dx[1];
         }
+        GF_TSTAMP(12);
+        first_tile = false;
     }
 }
 
@@ -292,6 +340,9 @@ GF_EXPORT int gf_render_torso(const gf_frame_t* f, void* stream) {
     a.count = given ? f->torso_mask_count : w.ctrl + gf::kCtrlTorsoCount;
     a.count_reset = given ? nullptr : w.ctrl + gf::kCtrlTorsoCount;
     a.tout = w.torso_out;
+#ifdef GF_TRACE
+    a.ttrace = g_ttrace_buf;
+#endif
     static GfLdsAttr lds[2];
     const size_t smem = kTorsoSmem + (ha ? gf::TH_W0 * sizeof(float) : 0);
     const void* fn = ha ? reinterpret_cast<const void*>(k_torso_field<true>) : reinterpret_cast<const void*>(k_torso_field<false>);
@@ -322,3 +373,8 @@ GF_EXPORT int gf_torso_mask_list(const float* bg_coords, const float* torso_occ,
                        list, dense_of, count);
     return gf_check_launch("torso_mask_list");
 }
+
+#ifdef GF_TRACE
+// trace build only: device buffer of 64 workgroups x 4 waves x 16 uint64 slots (tools/trace_torso.py)
+GF_EXPORT void gf_torso_trace_set(void* dev_buf) { g_ttrace_buf = reinterpret_cast<unsigned long long*>(dev_buf); }
+#endif

@@ -24,36 +24,46 @@ __device__ __forceinline__ void mfma_part(const float* __restrict__ Wl, int lane
     static_assert(OB0 + NOBP <= NOB, "block range");
     const float4* W4 = reinterpret_cast<const float4*>(Wl);
     const int half = lane >> 5;
+    floatx16 acc[NOBP];
 #pragma unroll
     for (int o = 0; o < NOBP; o++) {
         const int ob = OB0 + o;
-        floatx16 acc;
         if (ACCUM) {
-            acc = out[ob];
+            acc[o] = out[ob];
         } else if (bias) {
             const float4* b4 = reinterpret_cast<const float4*>(bias + ob * 32 + half * 16);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const float4 b = b4[q];
-                acc[q * 4 + 0] = b.x; acc[q * 4 + 1] = b.y; acc[q * 4 + 2] = b.z; acc[q * 4 + 3] = b.w;
+                acc[o][q * 4 + 0] = b.x; acc[o][q * 4 + 1] = b.y; acc[o][q * 4 + 2] = b.z; acc[o][q * 4 + 3] = b.w;
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+            for (int r = 0; r < 16; r++) acc[o][r] = 0.0f;
         }
+    }
+    // The out-blocks advance TOGETHER, one group of four steps each in turn (round 5; they used to run one after the other): consecutive MFMAs
+    // then belong to different accumulators wherever a layer has two blocks, so none waits for the result of the one issued just before it
+    // (tools/trace_torso.py: a 64-MFMA layer took 88 cycles per MFMA as one dependent chain per block).  Each accumulator still sees its own
+    // steps in the same order: same bits.
 #pragma unroll
-        for (int t4 = 0; t4 < NSTEPS / 4; t4++) {
+    for (int t4 = 0; t4 < NSTEPS / 4; t4++) {
+#pragma unroll
+        for (int o = 0; o < NOBP; o++) {
             const float4 w = W4[(o * (NSTEPS / 4) + t4) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, bin[t4 * 4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, bin[t4 * 4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, bin[t4 * 4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, bin[t4 * 4 + 3], acc, 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, bin[t4 * 4 + 0], acc[o], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, bin[t4 * 4 + 1], acc[o], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, bin[t4 * 4 + 2], acc[o], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, bin[t4 * 4 + 3], acc[o], 0, 0, 0);
         }
+    }
+#pragma unroll
+    for (int o = 0; o < NOBP; o++) {
         if (RELU) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = fmaxf(acc[r], 0.0f);
+            for (int r = 0; r < 16; r++) acc[o][r] = fmaxf(acc[o][r], 0.0f);
         }
-        out[ob] = acc;
+        out[OB0 + o] = acc[o];
     }
 }
 

@@ -121,8 +121,10 @@ __device__ __forceinline__ void sh_high(float x, float y, float z, uint32_t degr
 // polynomials on [-pi/4, pi/4] do it in ~24 operations, absolute error <= 9.3e-8 against the exact sine over |x| <= 512 (measured on 12 M
 // arguments in fp32 emulation; glibc's sinf: 7.0e-8), <= 1.6 ulp wherever |sin| > 0.01.  Beyond |x| = 8192 (never reached by an encoding of a
 // bounded coordinate; the op seam accepts any float) and for NaN the call falls back to sinf.
-__device__ __forceinline__ float sin_bounded(float x) {
-    if (!(fabsf(x) <= 8192.0f)) return sinf(x);
+// sin_reduced: the branch-free core, valid for |x| <= 8192 (anything else gives a finite, meaningless value).  Callers whose arguments are
+// bounded by construction use it directly: 24 of them in a row then interleave freely (the torso tile: with the fallback's branch between
+// them each was a serial chain, 480 cycles apiece where 24 operations need ~100; tools/trace_torso.py).
+__device__ __forceinline__ float sin_reduced(float x) {
     const float n = rintf(x * 0.63661977236758134f);
     float r = __builtin_fmaf(-n, 1.5707963705062866f, x);
     r = __builtin_fmaf(-n, -4.371138828673793e-08f, r);
@@ -139,6 +141,10 @@ __device__ __forceinline__ float sin_bounded(float x) {
     const int q = (int)n;
     const float v = (q & 1) ? c : s;
     return (q & 2) ? -v : v;
+}
+__device__ __forceinline__ float sin_bounded(float x) {
+    if (!(fabsf(x) <= 8192.0f)) return sinf(x);
+    return sin_reduced(x);
 }
 
 // element c of the [D + 2*D*deg] frequency encoding of in[0..D):

@@ -20,9 +20,10 @@ def main():
     from geneface_amd import synthetic as S
     from geneface_amd.infer import FramePipeline
     from geneface_amd.radnerf_torso import RADNeRFTorso
-    hp = HP.may_hparams(True)
-    seq = S.make_sequence(25, 512, 512, hp)
-    for name, kw in (("default", {}), ("thin", dict(sigma_row_scale=0.02))):
+    import random
+    seq = S.make_sequence(25, 512, 512, HP.may_hparams(True))
+    for name, kw in (("default", {}), ("thin", dict(sigma_row_scale=0.02)), ("head_aware", {})):
+        hp = HP.variant_hparams("head_aware", True) if name == "head_aware" else HP.may_hparams(True)     # head_aware: k_torso_field<true>, both coin outcomes
         sd = S.make_state_dict(hp, True, **kw)
         for precision in ("fp32", "split"):
             m = RADNeRFTorso(hp)
@@ -32,9 +33,11 @@ def main():
             pipe = FramePipeline(m, hp, seq, "cuda:0", impl="fused")
             for i in range(0, 25, 2 if name == "default" else 6):
                 with torch.no_grad():
+                    random.seed(100 + i)
                     u8 = pipe.render_frame(i)
                     pipe.wait()
                     d8 = hashlib.md5(u8.numpy().tobytes()).hexdigest()
+                    random.seed(100 + i)
                     out = pipe.run_model(pipe.sample(i))
                     df = hashlib.md5(out["rgb_map"].cpu().numpy().tobytes() + out["depth_map"].cpu().numpy().tobytes()).hexdigest()
                 print(name, precision, i, d8, df)
