@@ -1497,6 +1497,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
     // Rays per pool: a full pool (128 rays, 1 sample per ray and round) when there is plenty of work, but when the queue is short
     // (phase 1: a few thousand survivors that each need B - max_steps more samples) spread it over the whole grid and give
     // every ray up to 8 samples per round instead of walking 128 rays through B - max_steps rounds on a handful of CUs.
+    // (Round 5 tried a floor of 128 / budget rays when fewer than 8 samples remain of the budget -- phase 1 of the default scene has 7, so
+    // sixteen rays can never use the eighth slot each -- : byte-identical frames, 309 instead of 348 phase-1 workgroups, +0.1 % / +0.3 % fps
+    // (fp32 / split, noise level) and the kernel ALONE 1.5 % slower, because the fuller rounds are longer and phase 1 is one round deep
+    // whatever its width (profiles/round5/r5g_phase1_pool_floor_same_box_ab.txt).  Not kept.)
     uint32_t pool_cap = (limit + gridDim.x - 1) / gridDim.x;
     pool_cap = pool_cap < 16u ? 16u : (pool_cap > (uint32_t)kPool ? (uint32_t)kPool : pool_cap);
 #ifdef GF_DIAG
