@@ -198,3 +198,31 @@ def test_yaml_chain_loader_matches_reference_set_hparams(cfg):
     for k, v in HP.may_hparams(True).items():
         if k in may:
             assert may[k] == v, (k, may[k], v)
+
+
+@pytest.mark.parametrize("name", ["hash", "hash_smoothstep", "smoothstep", "head_aware", "audio"])
+def test_variant_hparams_match_the_reference_yaml_files(name):
+    """geneface_amd.hparams.VARIANTS (the other RAD-NeRF experiment files the reference ships: what tests/test_gpu_sweep.py sweeps and
+    bench.py's `variants` block times) against the reference's own set_hparams on the yaml files each entry names."""
+    import os
+    from geneface_amd import hparams as HP
+    refshim.install()
+    from utils.commons.hparams import set_hparams as ref_set
+    overrides, files = HP.VARIANTS[name]
+    cwd = os.getcwd()
+    os.chdir(refshim.REFERENCE_ROOT)
+    try:
+        resolved = [ref_set(config=f, hparams_str="", print_hparams=False, global_hparams=False) for f in files]
+    finally:
+        os.chdir(cwd)
+    head = resolved[0]
+    for k, v in overrides.items():
+        if k == "video_id":
+            continue
+        src = next((r for r in resolved if k in r and r[k] == v), None)
+        assert src is not None, (name, k, v, [r.get(k) for r in resolved])
+    ours = HP.variant_hparams(name, torso=len(files) > 1 or name == "head_aware")
+    ref = resolved[-1] if name in ("head_aware", "audio") else head
+    for k, v in ours.items():
+        if k in ref and k not in ("video_id", "head_model_dir", "task_cls", "torso_train_mode"):
+            assert ref[k] == v or (name not in ("head_aware",) and k in ("individual_embedding_num",) and any(r.get(k) == v for r in resolved)), (name, k, ref[k], v)
