@@ -730,7 +730,7 @@ def compact_line(full, details_path):
     lat = full.get("latency")
     if isinstance(lat, dict):
         line["latency"] = {"error": lat["error"][:200]} if "error" in lat else \
-            {p: {m: {k: _r(v, 3) for k, v in lat[p][m].items() if k != "unit"} for m in ("one_in_flight", "pipelined") if m in lat[p]} for p in ("fp32", "split") if p in lat}
+            {p: {m: {k: _r(v, 3) for k, v in lat[p][m].items() if k != "unit"} for m in ("one_in_flight", "two_in_flight", "pipelined") if m in lat[p]} for p in ("fp32", "split") if p in lat}
     if isinstance(tr, dict):
         line["train_step"] = {"ms_per_step": _r(tr.get("ms_per_step"), 3), "steps_per_s": _r(tr.get("steps_per_s"), 2),
                               "reference_kernels_ms_per_step": _r((tr.get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2),
@@ -803,6 +803,7 @@ def variants_leg(args, job, parity_on, headline_fps):
 def latency_leg(args, job, hp, torso, seq, sd):
     """The viewer's shape (inference/nerfs/radnerf_gui.py: one frame, wait for it, show it) and the cost of pipelining in frame latency.
       one_in_flight   render_frame(i); wait() -- host clock per frame: enqueue + every kernel of the frame alone on the GPU + the 768 KB D2H;
+      two_in_flight   the same loop one frame deep: frame i + 1 is enqueued before frame i is waited for (device time per frame as below);
       pipelined       the headline configuration (3-4 frames in flight): per frame the DEVICE time between its stream reaching the frame and
                       its D2H copy finishing (HIP events on the frame's stream) -- the small kernels of a frame wait for CU slots behind the
                       other frames' persistent head grids, so a frame takes longer to cross the GPU than it does alone."""
@@ -830,26 +831,29 @@ def latency_leg(args, job, hp, torso, seq, sd):
                     lat.append((time.perf_counter() - t0) * 1e3)
         rec = {"one_in_flight": {"value": 1e3 * len(lat) / sum(lat), "unit": "frames/s", "latency_ms_p50": pct(lat, 0.5), "latency_ms_p99": pct(lat, 0.99),
                                  "frames": len(lat)}}
-        pipe2 = FramePipeline(model, hp, seq, job.dev, frames=(0, args.warmup + n), impl=args.impl)
-        with torch.no_grad():
-            for i in range(args.warmup):
-                pipe2.render_frame(i)
-            pipe2.wait()
-            pipe2.frame_timing = []
-            t0 = time.perf_counter()
-            for rep in range(3):
-                pipe2.prepare(args.warmup, args.warmup + n)
-                for i in range(args.warmup, args.warmup + n):
+        for key, depth in (("two_in_flight", 2), ("pipelined", None)):
+            pipe2 = FramePipeline(model, hp, seq, job.dev, frames=(0, args.warmup + n), impl=args.impl, in_flight=depth)
+            with torch.no_grad():
+                for i in range(args.warmup):
                     pipe2.render_frame(i)
-            pipe2.wait()
-            wall = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            dev = [a.elapsed_time(b) for _, a, b in pipe2.frame_timing]
-            pipe2.frame_timing = None
-        rec["pipelined"] = {"value": len(dev) / wall, "unit": "frames/s", "frames_in_flight": pipe2.in_flight, "device_ms_per_frame_p50": pct(dev, 0.5),
-                            "device_ms_per_frame_p99": pct(dev, 0.99), "frames": len(dev)}
+                pipe2.wait()
+                pipe2.frame_timing = []
+                t0 = time.perf_counter()
+                for rep in range(3):
+                    pipe2.prepare(args.warmup, args.warmup + n)
+                    for i in range(args.warmup, args.warmup + n):
+                        pipe2.render_frame(i)
+                pipe2.wait()
+                wall = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                dev = [a.elapsed_time(b) for _, a, b in pipe2.frame_timing]
+                pipe2.frame_timing = None
+            rec[key] = {"value": len(dev) / wall, "unit": "frames/s", "frames_in_flight": pipe2.in_flight, "device_ms_per_frame_p50": pct(dev, 0.5),
+                        "device_ms_per_frame_p99": pct(dev, 0.99), "frames": len(dev)}
+            del pipe2
         out[prec] = rec
-    out["note"] = ("one_in_flight = the viewer path (render, wait, show); pipelined = throughput mode: a frame's small kernels queue behind the other "
+    out["note"] = ("one_in_flight = the viewer path (render, wait, show); two_in_flight = a viewer that shows frame i while frame i + 1 renders (one frame of "
+                   "extra latency); pipelined = throughput mode: a frame's small kernels queue behind the other "
                    "frames' persistent head grids (every VGPR and 156 of 160 KB of LDS per CU are theirs), so stream priorities cannot lift them -- "
                    "a wave cannot be placed on a CU that has no free registers, whatever its queue's priority")
     return out

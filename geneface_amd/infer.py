@@ -196,11 +196,15 @@ class FramePipeline:
         return pre["amb"][k], (pre["torso"][k] if pre["torso"] is not None else None)
 
     def prepared_coin(self, i: int):
-        """The head-aware coin prepare() drew for frame i (None: no batch covers it, or the model has no coin)."""
+        """The head-aware coin prepare() drew for frame i (None: no batch covers it, the model has no coin, or the coin has been used).  A
+        coin is good for ONE render -- the reference draws once per rendered frame -- so it is consumed here: rendering frame i a second
+        time inside the same pass draws a fresh coin and encodes that frame by itself."""
         pre = getattr(self, "_pre", None)
         if pre is None or pre.get("coins") is None or not (pre["first"] <= i < pre["stop"]):
             return None
-        return pre["coins"][i - pre["first"]]
+        c = pre["coins"][i - pre["first"]]
+        pre["coins"][i - pre["first"]] = None
+        return c
 
     def sample(self, i: int, rays: bool = True) -> dict:
         """The `sample` dict tasks/radnerfs/radnerf.py:119-126 reads (rays materialised, like the reference's dataset)."""
@@ -280,7 +284,8 @@ class FramePipeline:
         indices = list(indices)
         if indices and indices == list(range(indices[0], indices[-1] + 1)):
             pre = getattr(self, "_pre", None)
-            covered = pre is not None and pre["first"] <= indices[0] and indices[-1] < pre["stop"] and self.prepared(indices[0]) is not None
+            covered = pre is not None and pre["first"] <= indices[0] and indices[-1] < pre["stop"] and self.prepared(indices[0]) is not None \
+                and pre.get("coins") is None        # (a head-aware batch carries one-shot coins: every pass over the block draws its own)
             if not covered:      # no batch, a stale one, or one that covers only part of the block (the rest would fall back to per-frame launches)
                 self.prepare(indices[0], indices[-1] + 1)      # every window of the block is resident: one encoder launch for all of them
         for i in indices:

@@ -186,6 +186,13 @@ def test_head_aware_batched_pass_draws_the_coins_a_frame_loop_draws():
         assert torch.equal(plain[i], batched[i]), f"frame {i} (coin {coins[i]}): {int((plain[i] != batched[i]).sum())} bytes differ"
     a, b = next(i for i, c in enumerate(coins) if c), next(i for i, c in enumerate(coins) if not c)
     assert not torch.equal(batched[a], batched[b])
+    # a coin is good for one render: frame 0 a second time inside the same pass draws its own (the reference draws once per rendered frame)
+    random.seed(5)
+    first, second = random.random(), random.random()
+    random.seed(5)
+    pipe.render_frame(0)
+    pipe.wait()
+    assert random.random() == second and first != second
 
 
 def test_the_oracle_moves_under_a_last_ulp_ray_change():
