@@ -230,7 +230,7 @@ def torso_field(sd, hp, x, poses6, code, image=None, weights_sum=None):
         parts.append(code.reshape(1, -1).repeat(m, 1))
     if hp.get("torso_head_aware", False):
         if image is None:
-            image, weights_sum = torch.zeros(m, 3), torch.zeros(m, 1)
+            image, weights_sum = torch.zeros(m, 3, device=x.device), torch.zeros(m, 1, device=x.device)   # (on the GPU when the reference's kernels are the backend)
         e = torch.cat([image, weights_sum], dim=-1)
         for i in (0, 2, 4):
             e = F.linear(e, sd[f"head_color_weights_encoder.{i}.weight"], sd[f"head_color_weights_encoder.{i}.bias"])

@@ -57,12 +57,32 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "split", "fast"], help="render_precision of the product side")
     ap.add_argument("--identity", type=int, default=0, help="fixture seed: 0 = the bench identity, 1000 = the second identity of BASELINE.json configs[4] "
                                                             "(other weights, another occupancy shape, another pose / landmark sequence)")
+    ap.add_argument("--variant", default="default", help="one of geneface_amd.hparams.VARIANTS (round 5: the other RAD-NeRF configurations the reference "
+                                                          "ships -- hash, hash_smoothstep, smoothstep, head_aware, audio); the soak then runs on that model")
     args = ap.parse_args()
+    import random
     from geneface_amd.infer import FramePipeline
     from geneface_amd.radnerf_torso import RADNeRFTorso
     threads = oracle_threads(16)
-    hp, sd = model_fixture(True, args.identity)
-    seq = sequence(args.T, 512, 512, seed=5 if args.identity else 0)
+    if args.variant == "default":
+        hp, sd = model_fixture(True, args.identity)
+        seq = sequence(args.T, 512, 512, seed=5 if args.identity else 0)
+    else:
+        from geneface_amd import hparams as HP
+        from geneface_amd import synthetic as S
+        hp = HP.variant_hparams(args.variant, True)
+        ident = 1000 if args.variant == "audio" else args.identity
+        sd = S.make_state_dict(hp, True, seed=ident)
+        seq = S.make_sequence(args.T, 512, 512, hp, seed=ident)
+    head_aware = bool(hp.get("torso_head_aware", False))
+
+    def coin(i):      # head-aware models: seed the stream, look at the draw the next render makes, re-seed (bench.py::coin)
+        if not head_aware:
+            return False
+        random.seed(9000 + i)
+        c = random.random() < 0.5
+        random.seed(9000 + i)
+        return c
     m = RADNeRFTorso(hp)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
@@ -71,11 +91,12 @@ def main():
     have_ref = ref_kernels.available("fast")
     sd_g = {k: v.to(DEV) for k, v in sd.items()}
 
-    def ref_gpu(smp):
+    def ref_gpu(smp, branch=False):
         with R.kernel_backend(ref_kernels.load("fast")):
-            return R.render(sd_g, hp, smp["rays_o"], smp["rays_d"], smp["cond_wins"], smp["bg_coords"], smp["pose"], smp["bg_img"], True)["rgb_map"].reshape(-1, 3).cpu()
+            return R.render(sd_g, hp, smp["rays_o"], smp["rays_d"], smp["cond_wins"], smp["bg_coords"], smp["pose"], smp["bg_img"], True,
+                            head_aware_branch=branch)["rgb_map"].reshape(-1, 3).cpu()
 
-    report = {"precision": args.precision, "identity": args.identity, "command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
+    report = {"precision": args.precision, "identity": args.identity, "variant": args.variant, "command_reproduced": "python3 bench.py --gpus 1 --steps 20 --warmup 5 (BENCH_r03.json: parity.max_abs_rgb 0.0896)", "oracle_threads": threads,
               "frames": {}, "sweep_vs_reference_kernels": []}
     t0 = time.time()
     for i in [int(x) for x in args.frames.split(",") if x.strip()]:
@@ -101,9 +122,12 @@ def main():
         for i in range(args.T):
             with torch.no_grad():
                 smp = pipe.sample(i)
+                br = coin(i)
                 out = pipe.run_model(smp)["rgb_map"].reshape(-1, 3).cpu()
-                c = cmp(out, ref_gpu(smp))
+                c = cmp(out, ref_gpu(smp, br))
             c["frame"] = i
+            if head_aware:
+                c["coin"] = br
             report["sweep_vs_reference_kernels"].append(c)
         sw = report["sweep_vs_reference_kernels"]
         print(f"sweep vs reference kernels (identical device rays), {len(sw)} frames: worst", max(c["max"] for c in sw),
