@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--details", default=None, help="where the full record (per-frame lists, notes) is written; the stdout line is its compact form "
                                                     "(default: gpurun_out/bench_details[_<precision>].json beside this file)")
     ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact line (round 4's format, ~20 KB)")
+    ap.add_argument("--ranks-share-gpu", action="store_true", help="test mode for a box with ONE GPU: N real ranks (real replicas, real rendering, the every-rank "
+                    "parity check) that all use cuda:0, with gloo as the collective layer (RCCL refuses two ranks on one device); the line says so and its fps is "
+                    "N processes sharing a GPU -- not a scaling measurement")
     ap.add_argument("--selftest", action="store_true", help="control-flow self-test of the N-rank launch on a box without N GPUs: gloo instead of RCCL and a "
                                                             "pipeline stand-in that renders nothing; the line says so (data = 'selftest: no rendering') and is not a measurement")
     args = ap.parse_args(argv)
@@ -347,9 +350,14 @@ class Job:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.cuda = backend == "nccl"
+        self.share = bool(getattr(args, "ranks_share_gpu", False))
+        if self.share:
+            backend = self.backend = "gloo"
+        self.cuda = backend == "nccl" or self.share
         if self.cuda:
             assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+            if self.share:
+                self.local_rank = 0
             torch.cuda.set_device(self.local_rank)
             self.dev = torch.device("cuda", self.local_rank)
         else:
@@ -360,7 +368,7 @@ class Job:
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if self.cuda:
+            if self.cuda and not self.share:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
@@ -373,18 +381,18 @@ class Job:
 
     def barrier(self):
         if self.use_dist:
-            self.dist.barrier(device_ids=[self.local_rank]) if self.cuda else self.dist.barrier()
+            self.dist.barrier(device_ids=[self.local_rank]) if (self.cuda and not self.share) else self.dist.barrier()
         self.sync()
 
     def reduce(self, value, op="max"):
-        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([value], dtype=self.torch.float64, device="cpu" if self.share else self.dev)
         if self.use_dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
         return float(t.item())
 
     def gather(self, values, dtype=None):
         """[world][len(values)] on every rank (all_gather of one small tensor)."""
-        t = self.torch.tensor(list(values), dtype=dtype or self.torch.float64, device=self.dev)
+        t = self.torch.tensor(list(values), dtype=dtype or self.torch.float64, device="cpu" if self.share else self.dev)   # (gloo gathers host tensors)
         if not self.use_dist:
             return [t.cpu().tolist()]
         out = [self.torch.empty_like(t) for _ in range(self.world)]
@@ -521,14 +529,16 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "repeats": len(dts), "timed_region_s": sum(dts), "ms_per_step_min_max": [min(dts) / K * 1e3, max(dts) / K * 1e3],
             "host_enqueue_ms_per_step": host_ms,
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic" if real else "selftest: no rendering (launch-path check only)",
+            "vs_baseline": None, "dtype": dtype, "data": ("synthetic" + (f"; {world} ranks SHARING one GPU over gloo (--ranks-share-gpu): a check of the N-rank path, not a scaling measurement"
+                                                                      if getattr(job, "share", False) else "")) if real else "selftest: no rendering (launch-path check only)",
             "config": {"workload": (f"May lm3d_radnerf + lm3d_radnerf_torso head+torso {args.size}x{args.size}, {K} frames per GPU "
                                     f"(BASELINE.json configs[2])" if torso else
                                     f"May lm3d_radnerf head-only {args.size}x{args.size}, {K} frames per GPU (BASELINE.json configs[1])")
                                    + f"; frame-sharded over {world} GPU(s)",
                        "impl": args.impl, "frames_total": world * K, "rays_per_frame": args.size * args.size,
                        "max_steps": hp["max_steps"], "parallelism": f"frame-shard x{world}", "rccl_ranks": ranks_seen,
-                       "collective_backend": backend if job.use_dist else None,
+                       "collective_backend": job.backend if job.use_dist else None,
+                       **({"ranks_share_one_gpu": True} if getattr(job, "share", False) else {}),
                        "frames_in_flight": getattr(pipe, "in_flight", 1) if args.impl == "fused" else 1, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "cond_encoder": "per frame" if args.no_prepare else "one batched launch per pass, inside the timed region",
                        "repeats": len(dts), "timing": "median of `repeats` passes of exactly `steps` frames, each between barrier + synchronize pairs"},
@@ -1038,6 +1048,8 @@ def every_rank_parity(args, job, hp, torso, sd_rank0):
     with torch.no_grad():
         smp = ppipe.sample(i)
         rgb = ppipe.run_model(smp)["rgb_map"].reshape(-1).float().contiguous()
+    if getattr(job, "share", False):
+        rgb = rgb.cpu()                      # gloo gathers host tensors
     rows = [torch.empty_like(rgb) for _ in range(job.world)]
     if job.use_dist:
         job.dist.all_gather(rows, rgb)

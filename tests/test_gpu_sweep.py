@@ -257,3 +257,32 @@ def test_bench_one_rank_under_torchrun_uses_rccl():
     par = pr["parity_first_frame"]
     assert par["frame"] == 14 and par["max_abs_rgb"] < RGB_ATOL and par["identical_across_ranks"] is True
     assert line["value"] > 25 and line["roofline"]["frac"] > 0.4
+
+
+def test_bench_two_real_ranks_on_the_one_gpu():
+    """N = 2 with REAL replicas on the one GPU a test box has: `python bench.py --gpus 2 --ranks-share-gpu` fans out two ranks (torchrun on
+    127.0.0.1) that both render on cuda:0, gloo standing in for RCCL (which refuses two ranks on one device).  Everything the 2/4/8-GPU line
+    relies on runs with real data: rank 1 is built WITHOUT the weights and receives them through the one broadcast, each rank renders its own
+    block, the every-rank parity check gathers one common frame per rank (byte-identical across ranks, within 1e-4 of the oracle), the
+    replica checksums agree, per-rank clocks and blocks are reported.  The fps of two processes sharing a GPU is not a scaling number and
+    the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ranks-share-gpu", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--rank-parity", "--no-stress", "--png-frames", "0", "--min-seconds", "0.2", "--profile-frames", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["collective_backend"] == "gloo" and line["config"]["ranks_share_one_gpu"] is True
+    assert "not a scaling measurement" in line["data"] and line["config"]["frames_total"] == 12
+    pr = line["per_rank"]
+    assert pr["replica_checksum_equal"] is True and len(pr["fps"]) == 2 and min(pr["fps"]) > 0 and pr["frames"] == [[0, 8], [8, 16]]
+    par = pr["parity_first_frame"]
+    assert par["identical_across_ranks"] is True and len(par["max_abs_rgb_by_rank"]) == 2 and par["max_abs_rgb"] < RGB_ATOL
+    assert line["value"] is not None and line["value"] > 25 and "error" not in line
