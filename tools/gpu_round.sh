@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench line, head-kernel timeline, rocprofv3 kernel stats, PMC passes.
-# usage: tools/gpu_round.sh <tag> [steps...]   (steps: test bench benchfast trace prof pmc train clock ab:<variant> abm:<v1>,<v2>; default: test bench trace prof pmc)
+# usage: tools/gpu_round.sh <tag> [steps...]   (steps: test bench benchfast benchsplit trace ttrace prof pmc pmcsplit pk train clock ab:<variant> abm:<v1>,<v2>; default: test bench trace prof pmc)
 set -u
 TAG=${1:-r1}; shift || true
 STEPS=${*:-test bench trace prof pmc}
@@ -46,6 +46,11 @@ for s in $STEPS; do
     trace) [ -f geneface_amd/csrc/libgeneface_hip_trace.so ] || python -m geneface_amd.csrc.build --trace > /dev/null   # (the instrumented library is not shipped: .gpurunignore)
            timeout 300 python tools/trace_head.py --json $OUT/trace.json > $OUT/trace.txt 2>&1; cat $OUT/trace.txt ;;
     tracev:*) V=${s#tracev:}; GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_$V.so timeout 300 python tools/trace_head.py > $OUT/trace_$V.txt 2>&1; grep -E "phase ms|lifetime|round =" $OUT/trace_$V.txt ;;
+    ttrace) [ -f geneface_amd/csrc/libgeneface_hip_trace.so ] || python -m geneface_amd.csrc.build --trace > /dev/null
+           timeout 300 python tools/trace_torso.py > $OUT/trace_torso.txt 2>&1; tail -16 $OUT/trace_torso.txt ;;
+    pk)    # packed-FP32 regression (NOTES 9.5): the library built WITH the SLP vectoriser, rendered over and over; the product as control
+           python tools/pk_regress.py --build-only > $OUT/slp_census.json 2>/dev/null
+           GF_HIP_LIB=$REPO/geneface_amd/csrc/libgeneface_hip_slp.so timeout 600 python tools/pk_regress.py --frames 3000 > $OUT/pk_regress_slp.json 2>/dev/null; cut -c1-400 $OUT/pk_regress_slp.json ;;
     trace1) GF_HEAD_GRID=256 timeout 300 python tools/trace_head.py --json $OUT/trace_1wg.json > $OUT/trace_1wg.txt 2>&1; cat $OUT/trace_1wg.txt ;;
     prof)  # one frame in flight: per-kernel durations are those of the kernel alone (what bench.py's roofline leg times)
            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o k --output-format csv -- python $REPO/bench.py --steps 30 --warmup 5 --repeats 1 --no-stress --png-frames 0 --no-cpu-baseline --no-overlap > $OUT/prof.log 2>&1); head -8 $OUT/prof/k_kernel_stats.csv | cut -c1-160
