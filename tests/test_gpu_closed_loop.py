@@ -121,7 +121,10 @@ def _dump(record):
 
 
 def _head_fall(losses, k=16):
-    return float(np.mean(losses[-k:]) / np.mean(losses[:k]))
+    """The fall of the curve: the calmest 32-step stretch of the last 128 steps over the first 16 steps.  (Not the last steps' mean: either
+    run may be inside a transient -- an occupancy refresh that flips threshold cells, up to x2.2 for ~40 steps -- when the run ends.)"""
+    tail = min(float(np.mean(losses[a:a + 32])) for a in range(len(losses) - 128, len(losses) - 31, 16))
+    return tail / float(np.mean(losses[:k]))
 
 
 def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
@@ -140,7 +143,7 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
     losses, opt = _train(student, hp, seq, poses, cond, bg, bgc, targets, STEPS)
     assert all(np.isfinite(losses)), "training diverged"
     fall = _head_fall(losses)
-    assert fall < 0.2, f"the student did not learn: mse {np.mean(losses[:16]):.4g} -> {np.mean(losses[-16:]):.4g}"
+    assert fall < 0.1, f"the student did not learn: mse {np.mean(losses[:16]):.4g} -> x{fall:.4g}"
     moved = sum(int(not torch.equal(w0[k], v)) for k, v in student.state_dict().items() if v.is_floating_point() and not k.startswith("aabb"))
     assert moved >= 20 and int(student.density_bitfield.count_nonzero()) > 0 and student.iter_density >= STEPS // 16
 
@@ -170,18 +173,19 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
         # table gradients are float atomics, the weight-gradient GEMMs of both split their reductions), and 300 Adam steps with an occupancy
         # refresh every 16 amplify that.  Measured on the MI355X over five runs (profiles/round5/r5b_closed_loop_loss_curves.json is one): the
         # 32-step means agree to 2.2 % for the first 96 steps (a 25-fold fall); after that EITHER run may take a transient the other does
-        # not -- a refresh that flips cells sitting on the density threshold, up to x2.2 for ~40 steps -- so later windows differed by up to
-        # 13 % before step 192 and the end-of-run ratios of the five runs were 0.99, 1.14, 0.69, 0.96 and 0.9.  The bar is on what is
-        # comparable: every 32-step window of the first 96 steps within 10 %, the decades fallen over the whole run within 15 %, both runs
-        # at least a 20-fold fall, the final plateaus within a factor of 2.
+        # not -- a refresh that flips cells sitting on the density threshold, up to x2.2 for ~40 steps -- so single late windows differed by
+        # up to 13 %, and the mean of the LAST 16 steps by up to 31 % when one run ended inside a transient.  `_head_fall` therefore takes
+        # the calmest 32-step stretch of the last 128 steps as the level reached: x0.0153 / x0.0161 and x0.0173 / x0.0183 on the recorded
+        # runs (5 % apart, 1.3 % in decades).  Bars: every 32-step window of the first 96 steps within 10 %, the fall within 20 % and
+        # within 5 % in decades, both at least a 20-fold fall.
         record["fall_first_96_steps"] = {"product": float(np.mean(losses[64:96]) / np.mean(losses[:16])),
                                          "reference_kernels": float(np.mean(ref_losses[64:96]) / np.mean(ref_losses[:16]))}
         _dump(record)
         for a in range(0, 96, 32):
             wa, wb = float(np.mean(losses[a:a + 32])), float(np.mean(ref_losses[a:a + 32]))
             assert abs(wa / wb - 1.0) < 0.10, f"steps {a}..{a + 32}: mse {wa:.4g} (product) vs {wb:.4g} (reference kernels)"
-        assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.15, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
-        assert fall < 0.05 and ref_fall < 0.05 and 0.5 < fall / ref_fall < 2.0, (fall, ref_fall)
+        assert abs(fall / ref_fall - 1.0) < 0.20, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
+        assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.05 and fall < 0.05 and ref_fall < 0.05, (fall, ref_fall)
         assert abs(losses[0] / ref_losses[0] - 1.0) < 1e-3          # step 0: same weights, same draws, same picture
         # the two occupancy fields describe the same shape: after 300 steps on diverged weights the cells whose density sits near the
         # threshold fall either way (measured: 72 K of 436 K set bits differ, intersection over union 0.85)
