@@ -117,7 +117,48 @@ def golden_ops():
     print("ops.npz", len(out), "arrays")
 
 
+def golden_variants(size=48, idx=2):
+    """One head+torso frame of every OTHER RAD-NeRF configuration the reference ships (geneface_amd.hparams.VARIANTS: hashed grids, smoothstep,
+    head-aware torso with both outcomes of its per-frame coin, the audio-driven config on the second identity), rendered by the reference's own
+    Python built with those hparams (round 5: the oracle's restatement of these branches -- the strided-conv AudioNet, the head-colour encoder,
+    the hash / smoothstep flags on their way to the grid encoder -- had only been compared with the product, never with the reference)."""
+    import random
+    refshim.install()
+    import modules.radnerfs.utils as ref_utils
+    for name in ("hash", "hash_smoothstep", "smoothstep", "head_aware", "audio"):
+        hp = H_.variant_hparams(name, True)
+        seed = 1000 if name == "audio" else 0
+        sd = S.make_state_dict(hp, True, seed=seed)
+        model, rhp = refshim.build_reference_model(True, overrides=H_.VARIANTS[name][0])
+        for k in hp:
+            if k in rhp and k not in ("video_id", "head_model_dir"):
+                assert rhp[k] == hp[k], (name, k, rhp[k], hp[k])
+        model.load_state_dict(sd, strict=True)
+        seq = S.make_sequence(4, size, size, hp, seed=seed)
+        fi = frame_inputs(seq, idx, ref_utils)
+        for coin in ((0.25, 0.75) if name == "head_aware" else (0.75,)):
+            real = random.random
+            random.random = lambda: coin          # radnerf_torso.py:175: `random.random() < 0.5` -> the torso sees the head (0.25) or zeros (0.75)
+            try:
+                with refshim.cpu_mode(), torch.no_grad():
+                    out = model.render(fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], index=0, staged=False,
+                                       bg_color=fi["bg"], perturb=False, force_all_rays=True, **rhp)
+                    cond_feat = model.cal_cond_feat(fi["cond"])
+            finally:
+                random.random = real
+            tag = name + ("_coin_heads" if coin < 0.5 and name == "head_aware" else ("_coin_tails" if name == "head_aware" else ""))
+            payload = {k: v.detach().numpy() for k, v in out.items()}
+            payload["cond_feat"] = cond_feat.numpy()
+            payload["pose6"] = fi["pose6"].numpy()
+            payload["rays_d_checksum"] = np.array(float(fi["rays_d"].double().abs().sum()))
+            payload["state_dict_sha256"] = np.array(sd_checksum(sd))
+            np.savez_compressed(os.path.join(OUT, f"frame_variant_{tag}_{size}.npz"), **payload)
+            print(f"frame_variant_{tag}_{size}.npz", {k: v.shape for k, v in payload.items() if hasattr(v, "shape") and v.ndim})
+
+
 if __name__ == "__main__":
     assert refshim.available(), "needs the reference tree"
-    golden_frames()
-    golden_ops()
+    if "--variants-only" not in sys.argv:
+        golden_frames()
+        golden_ops()
+    golden_variants()

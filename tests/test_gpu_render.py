@@ -1211,3 +1211,23 @@ def test_torso_mask_list_is_rebuilt_when_its_inputs_change():
     model.density_thresh_torso, model.mean_density_torso = 0.5, 1.0               # threshold = min of the two (radnerf_torso.py:170): part of the key as well
     c = both(1)
     assert not torch.equal(b, c)
+
+
+@pytest.mark.parametrize("precision,impl", [("fp32", "fused"), ("fp32", "ops"), ("split", "fused")])
+@pytest.mark.parametrize("tag", ["hash", "hash_smoothstep", "smoothstep", "head_aware_coin_heads", "head_aware_coin_tails", "audio"])
+def test_variant_frame_vs_reference_golden(tag, precision, impl, monkeypatch):
+    """The product against frames the REFERENCE'S OWN PYTHON rendered for the other configurations it ships (tests/golden/frame_variant_*_48.npz,
+    make_golden.py::golden_variants): hashed grids, smoothstep, the head-aware torso with either outcome of its coin, the audio-driven config on
+    the second identity -- fused, op-by-op and split tier, the golden fixtures' bars."""
+    import random
+    from test_oracle_golden import variant_case
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd, fi, branch, gold = variant_case(tag)
+    m = RADNeRFTorso(hp)
+    m.load_state_dict(sd, strict=True)
+    m.render_impl, m.render_precision = impl, precision
+    m = m.to(DEV).eval()
+    monkeypatch.setattr(random, "random", lambda: 0.25 if branch else 0.75)
+    out = render_gpu(m, hp, fi)
+    check(out, gold, True)
+    assert (out["deform"].cpu().numpy() - gold["deform"]).shape == gold["deform"].shape and np.abs(out["deform"].cpu().numpy() - gold["deform"]).max() < 2e-5

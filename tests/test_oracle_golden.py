@@ -77,3 +77,42 @@ def test_frame_golden(oracle_lib, torso, size, idx):
         assert np.abs(out["torso_alpha_map"].numpy() - gold["torso_alpha_map"]).max() < 1e-5
         assert np.abs(out["torso_rgb_map"].numpy() - gold["torso_rgb_map"]).max() < 1e-5
         assert np.abs(out["deform"].numpy() - gold["deform"]).max() < 1e-5
+
+
+VARIANT_GOLD = ("hash", "hash_smoothstep", "smoothstep", "head_aware_coin_heads", "head_aware_coin_tails", "audio")
+
+
+def variant_case(tag, size=48, idx=2):
+    """(hp, sd, frame inputs, head-aware coin outcome, golden arrays) of tests/golden/frame_variant_<tag>_48.npz -- one head+torso frame of
+    another RAD-NeRF configuration the reference ships, rendered by the reference's OWN Python built with those hparams (make_golden.py::
+    golden_variants).  Shared with the GPU test of the product (tests/test_gpu_render.py)."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    name = tag.split("_coin_")[0]
+    hp = HP.variant_hparams(name, True)
+    seed = 1000 if name == "audio" else 0
+    sd = S.make_state_dict(hp, True, seed=seed)
+    fi = frame_inputs(S.make_sequence(4, size, size, hp, seed=seed), idx)
+    gold = np.load(os.path.join(GOLD, f"frame_variant_{tag}_{size}.npz"))
+    assert np.allclose(fi["pose6"].numpy(), gold["pose6"], atol=1e-6)
+    assert abs(float(fi["rays_d"].double().abs().sum()) - float(gold["rays_d_checksum"])) < 1e-3
+    return hp, sd, fi, tag.endswith("_coin_heads"), gold
+
+
+@pytest.mark.parametrize("tag", VARIANT_GOLD)
+def test_variant_frame_golden(oracle_lib, tag):
+    """The oracle's restatement of the branches only the other shipped configurations reach -- hash / smoothstep flags down to the grid
+    kernels, the head-colour encoder of torso_head_aware with both coin outcomes (radnerf_torso.py:36-46,68-74,175-179), the strided-conv
+    AudioNet of the audio-driven config (cond_encoder.py:14-41) -- against the reference's own Python on the same inputs."""
+    hp, sd, fi, branch, gold = variant_case(tag)
+    assert np.allclose(R.cal_cond_feat(sd, hp, fi["cond"]).numpy(), gold["cond_feat"], atol=1e-6)
+    out = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=True, head_aware_branch=branch)
+    assert np.abs(out["rgb_map"].numpy() - gold["rgb_map"]).max() < 3e-4
+    assert psnr(out["rgb_map"], torch.from_numpy(gold["rgb_map"])) > 70
+    assert np.abs(out["depth_map"].numpy() - gold["depth_map"]).max() < 1e-3
+    assert np.abs(out["torso_alpha_map"].numpy() - gold["torso_alpha_map"]).max() < 1e-5
+    assert np.abs(out["torso_rgb_map"].numpy() - gold["torso_rgb_map"].reshape(out["torso_rgb_map"].shape)).max() < 1e-5
+    assert np.abs(out["deform"].numpy() - gold["deform"]).max() < 1e-5
+    if tag == "head_aware_coin_heads":       # the two outcomes of the coin are different pictures
+        other = np.load(os.path.join(GOLD, "frame_variant_head_aware_coin_tails_48.npz"))
+        assert np.abs(other["torso_alpha_map"] - gold["torso_alpha_map"]).max() > 1e-3
