@@ -194,3 +194,48 @@ def test_autocast_step_costs_what_the_fp32_step_costs(ref):
     ms32b = timed(False)
     print(f"reference training step over compat, 64x64 rays: fp32 {min(ms32, ms32b):.2f} ms, fp16 autocast {ms16:.2f} ms ({ms16 / min(ms32, ms32b):.2f}x)")
     assert ms16 < 1.5 * max(ms32, ms32b)      # measured 1.11-1.12x (the remainder is torch's own autocast casts); a timing, so a loose bar
+
+
+@pytest.mark.parametrize("tag", ["hash", "hash_smoothstep", "smoothstep", "head_aware_coin_heads", "head_aware_coin_tails", "audio"])
+def test_reference_render_of_every_shipped_variant_over_compat_vs_golden(ref, tag, monkeypatch):
+    """Round 5: the reference's own RADNeRFTorso built with the hparams of the other configurations it ships (hashed grids, smoothstep,
+    head-aware torso, the audio-driven config) runs over geneface_amd.compat on the MI355X and reproduces the frames it rendered over the C
+    oracle on the CPU (tests/golden/frame_variant_*_48.npz) -- seam 1 for these configurations."""
+    import random
+    import zipfile as zf
+    from test_gpu_render import check
+    from test_oracle_golden import variant_case
+    from geneface_amd import hparams as HP
+    hp_ours, sd, fi, branch, gold = variant_case(tag)
+    ref(True)                                                    # installs the seam, imports the archive's modules
+    name = tag.split("_coin_")[0]
+    hps = json.loads(zf.ZipFile(ARCHIVE).read("refpy_hparams.json"))
+    hp = dict(hps["torso"], **{k: v for k, v in HP.VARIANTS[name][0].items() if k != "video_id"})
+    from utils.commons.hparams import hparams as global_hp
+    global_hp.clear()
+    global_hp.update(hp)
+    from modules.radnerfs.radnerf_torso import RADNeRFTorso as cls
+    model = cls(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    monkeypatch.setattr(random, "random", lambda: 0.25 if branch else 0.75)
+    with torch.no_grad():
+        out = _render(model, hp, fi)
+    check(out, gold, True)
+
+
+def test_reference_sh_encoder_degree_8_over_compat_vs_golden(ref):
+    """sphere_harmonics.py's SHEncoder(degree=8) -- the reference's own wrapper and autograd Function -- over compat._shencoder: values and the
+    gradient with respect to the directions against tests/golden/sh_deg8.npz (the reference's source expressions)."""
+    ref(False)
+    import modules.radnerfs.encoders.shencoder.sphere_harmonics as sh
+    g = np.load(os.path.join(GOLD, "sh_deg8.npz"))
+    enc = sh.SHEncoder(input_dim=3, degree=8)
+    x = torch.from_numpy(g["inputs"]).to(DEV).requires_grad_(True)
+    y = enc(x)
+    assert y.shape == (len(g["inputs"]), 64)
+    assert np.abs(y.detach().cpu().numpy() - g["values"]).max() <= 2e-6 * np.abs(g["values"]).max()
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+    (y * w).sum().backward()
+    want = torch.einsum("bk,bdk->bd", w.cpu().double(), torch.from_numpy(g["dy_dx"]).double())
+    assert (x.grad.cpu().double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
