@@ -1,0 +1,62 @@
+"""Host logic of round 5's variant fixtures (no GPU, no reference tree): the table of the other RAD-NeRF configurations the reference ships, the
+audio-driven sequence generator, the coin helper of the head-aware parity harness."""
+import random
+
+import numpy as np
+
+from geneface_amd import hparams as HP
+from geneface_amd import synthetic as S
+
+
+def test_variant_table_overrides_only_what_the_yaml_files_state():
+    base = HP.may_hparams(True)
+    assert HP.variant_hparams("default", True) == base
+    for name, (over, files) in HP.VARIANTS.items():
+        hp = HP.variant_hparams(name, True)
+        assert files and all(f.startswith("egs/") and f.endswith(".yaml") for f in files)
+        for k, v in over.items():
+            assert hp[k] == v
+        changed = {k for k in hp if hp[k] != base.get(k)}
+        assert changed <= set(over) | {"head_model_dir"}, (name, changed)
+    assert HP.variant_hparams("hash")["grid_type"] == "hashgrid" and HP.variant_hparams("hash_smoothstep")["grid_interpolation_type"] == "smoothstep"
+    assert HP.variant_hparams("head_aware")["torso_head_aware"] is True
+    a = HP.variant_hparams("audio")
+    assert (a["cond_type"], a["cond_win_size"], a["smo_win_size"], a["individual_embedding_num"]) == ("esperanto", 16, 8, 10000)
+    assert HP.may_hparams(True) == base                                   # the table hands out copies
+
+
+def test_audio_sequence_has_the_dataset_layout():
+    """cond_wins of the audio-driven config: per frame the smo_win = 8 frames around it (get_audio_features att_mode 2: left = i - 4,
+    right = i + 4, zero padded at the ends; modules/radnerfs/utils.py:85-101) of [16, 44] feature windows."""
+    hp = HP.variant_hparams("audio", True)
+    seq = S.make_sequence(12, 32, 32, hp, seed=1000)
+    w = seq["cond_wins"]
+    assert w.shape == (12, 8, 16, 44) and w.dtype == np.float32
+    feats = S.make_audio_features(12, 44, 16, seed=13 + 1000)
+    assert feats.shape == (12, 16, 44)
+    for i in (0, 3, 5, 11):
+        for k in range(8):
+            j = i - 4 + k
+            want = feats[j] if 0 <= j < 12 else np.zeros((16, 44), np.float32)
+            assert np.array_equal(w[i, k], want), (i, k)
+    assert np.array_equal(S.make_sequence(12, 32, 32, hp, seed=1000)["cond_wins"], w)            # seeded
+    assert not np.array_equal(S.make_sequence(12, 32, 32, hp, seed=0)["cond_wins"], w)
+    assert abs(float(feats[2:10].std()) - 1.0) < 0.2                                             # unit-variance AR(1) stream
+    # the landmark-driven default is untouched by the audio branch
+    d = S.make_sequence(12, 32, 32, HP.may_hparams(True))
+    assert d["cond_wins"].shape == (12, 5, 1, 204)
+    sd = S.make_state_dict(hp, True, seed=1000)
+    assert sd["cond_prenet.encoder_conv.0.weight"].shape == (32, 44, 3) and sd["cond_att_net.attentionNet.0.weight"].shape == (8, 8)
+    assert sd["individual_embeddings"].shape == (10000, 4)
+
+
+def test_coin_helper_previews_the_next_draw():
+    import bench
+    assert bench.coin({"torso_head_aware": False}, 5) is False
+    hp = {"torso_head_aware": True}
+    outcomes = set()
+    for seed in range(40):
+        c = bench.coin(hp, seed)
+        assert (random.random() < 0.5) == c          # the very next draw is the one it looked at
+        outcomes.add(c)
+    assert outcomes == {True, False}
