@@ -15,7 +15,9 @@
 // Why: the masked pixels are the lower part of the picture.  With one workgroup per 256 consecutive pixels the field ran on the ~40 % of
 // the workgroups that cover those rows, two tiles deep on each of their waves (8 tiles on 4 waves) while the others only blended; over the
 // dense list every wave of every launched workgroup has exactly one tile.  Same values: a pixel's field is a column of the MFMA tiles,
-// independent of which pixels share its tile, so frames are bit-identical to the one-kernel form (tools/frame_digests.py).
+// independent of which pixels share its tile, so the restructure itself left frames bit-identical to the one-kernel form (tools/frame_digests.py);
+// the branch-free sine that replaced sinf in the encodings in the same round (sin_reduced, <= 9.3e-8 absolute) did change last-ulp bits -- the
+// tolerance against the oracle is unchanged (2e-6 .. 3e-5 measured, bar 1e-4).
 #include "common.hpp"
 #include "frame.hpp"
 #include "grid_core.hpp"
@@ -123,11 +125,17 @@ __device__ __forceinline__ float sample_occ(const float* __restrict__ occ, int G
 // Branch-free: the sine is evaluated for every entry (on a harmless argument for the two pass-through and the six padding entries) and
 // selected afterwards, so the 24 entries of a lane are 24 independent chains the scheduler interleaves.  Arguments are 2^f x + {0, pi/2} with
 // f <= 9 and x = bg_coords * torso_shrink, |x| <= 1 for coordinates that are pixel coordinates: sin_reduced's domain (sh_core.hpp).
+// BOUNDED = false: the same entry through sin_bounded (sinf beyond |argument| = 8192, like the op seam's frequency encoder): taken by a whole
+// wave when ANY of its pixels carries a coordinate with |bg_coords * shrink| > 15.9 -- never the case for pixel coordinates, but gf_render_torso
+// is a public entry and such inputs must not give finite nonsense where the op path gives the sine.  Where both apply they agree
+// bit for bit (sin_bounded IS sin_reduced inside the range).
+template <bool BOUNDED = true>
 __device__ __forceinline__ float enc_entry(float x0, float x1, int e) {
     const int ee = e < 2 ? 2 : (e >= 42 ? 2 : e);
     const int col = ee / 2 - 1, d = ee & 1, freq = col >> 1;
     const float phase = (col & 1) ? (3.141592653589793f / 2) : 0.0f;
-    const float sv = gf::sin_reduced(scalbnf(d ? x1 : x0, freq) + phase);
+    const float arg = scalbnf(d ? x1 : x0, freq) + phase;
+    const float sv = BOUNDED ? gf::sin_reduced(arg) : gf::sin_bounded(arg);
     return e >= 42 ? 0.0f : (e < 2 ? (e ? x1 : x0) : sv);
 }
 
@@ -208,8 +216,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_torso_field(const TorsoArgs a) 
                 const float4 u = e4[0], v = e4[1];
                 e8[0] = u.x; e8[1] = u.y; e8[2] = u.z; e8[3] = u.w; e8[4] = v.x; e8[5] = v.y; e8[6] = v.z; e8[7] = v.w;
             }
+            // 2^9 |x| + pi/2 <= 8192 <=> |x| <= 15.99...: wave-uniform choice (a ballot), so the common case keeps its 24 branch-free chains
+            if (__builtin_expect(__any(!(fabsf(x0) <= 15.9f && fabsf(x1) <= 15.9f)), 0)) {
+#pragma unroll 1
+                for (int t = 0; t < 24; t++) enc[t] = enc_entry<false>(x0, x1, 24 * half + t);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 24; t++) enc[t] = enc_entry(x0, x1, 24 * half + t);
+                for (int t = 0; t < 24; t++) enc[t] = enc_entry<true>(x0, x1, 24 * half + t);
+            }
         }
         if (!weights_ready) {     // workgroup-uniform (first trip of every wave, whether it has a tile or not): the DMA has landed for everybody
             __builtin_amdgcn_s_waitcnt(0);     // this wave's asynchronous copies (vmcnt) and LDS stores

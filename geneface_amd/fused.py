@@ -493,9 +493,20 @@ def head_aware_coin(model, bg_coords=None) -> bool:
                 any_px = bool(model.torso_mask(bg_coords.reshape(-1, 2).to(grid.device)).any())
             else:       # no pixel coordinates at hand: nothing is selected by a grid that is nowhere above the threshold
                 any_px = bool((grid > thresh).any())
-        st = (key, any_px)
+        # the entry holds the tensors its key was taken from (as torso_mask_list does): while it lives the allocator cannot hand their address
+        # to different coordinates whose fresh `_version` 0 would then match a stale key
+        st = (key, any_px, grid, bg_coords)
         object.__setattr__(model, "_torso_occ_any", st)
     return st[1] and random.random() < 0.5
+
+
+def cond_encode_batch_accepts(st, cond_wins) -> bool:
+    """The ONE predicate for "gf_cond_encode_batch takes these windows": the encoder is the AudioNet + AudioAttNet pair the kernel implements
+    and cond_wins is [n, S, T, C] fp32 contiguous (rows of a contiguous block are contiguous).  FramePipeline.prepare asks it before it draws
+    a head-aware pass's coins, cond_encode_batch before it launches -- so a refusal can never follow a draw."""
+    c = st.cond
+    return c is not None and cond_wins.dim() == 4 and tuple(cond_wins.shape[1:]) == (c.S, c.T, c.C) and cond_wins.dtype == torch.float32 \
+        and cond_wins.is_contiguous()
 
 
 def cond_encode_batch(model, st, cond_wins, poses6=None, ha_branch=False):
@@ -504,8 +515,7 @@ def cond_encode_batch(model, st, cond_wins, poses6=None, ha_branch=False):
     row k is bit-identical to the single-frame launch on frame k.  None when the encoder is not the AudioNet + AudioAttNet pair the kernel
     implements (or the window is outside its limits): the caller then uses the torch modules."""
     c = st.cond
-    if c is None or cond_wins.dim() != 4 or tuple(cond_wins.shape[1:]) != (c.S, c.T, c.C) or cond_wins.dtype != torch.float32 \
-            or not cond_wins.is_contiguous():
+    if not cond_encode_batch_accepts(st, cond_wins):
         return None
     n, dev = cond_wins.shape[0], cond_wins.device
     cond_feat = torch.empty(n, c.dim_aud, dtype=torch.float32, device=dev)

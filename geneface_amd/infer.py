@@ -140,12 +140,13 @@ class FramePipeline:
         self._pre = None
         if self.impl != "fused" or self.device.type != "cuda" or stop <= first:
             return
-        from .fused import cond_encode_batch, get_state, head_aware_coin
+        from .fused import cond_encode_batch, cond_encode_batch_accepts, get_state, head_aware_coin
         st = get_state(self.model)
         coins = None
         c = st.cond
-        if c is None or self.cond_wins.dim() != 4 or tuple(self.cond_wins.shape[1:]) != (c.S, c.T, c.C):
-            return                         # an encoder / window the kernel does not implement: every frame runs the torch modules as before
+        if not cond_encode_batch_accepts(st, self.cond_wins):
+            return                         # an encoder / window the kernel does not implement (or windows it would refuse: dtype, layout -- the
+                                           # SAME predicate the launch applies, checked BEFORE any coin is drawn): every frame runs the torch modules
         if st.head_aware:
             # radnerf_torso.py:175-179 flips a coin per frame that decides what is folded into torso_bias (the encoding of a black, transparent
             # head, or zeros + the per-pixel encoding).  The pass's coins are drawn HERE, in frame order -- the draws, and their order, a
@@ -284,8 +285,12 @@ class FramePipeline:
         indices = list(indices)
         if indices and indices == list(range(indices[0], indices[-1] + 1)):
             pre = getattr(self, "_pre", None)
-            covered = pre is not None and pre["first"] <= indices[0] and indices[-1] < pre["stop"] and self.prepared(indices[0]) is not None \
-                and pre.get("coins") is None        # (a head-aware batch carries one-shot coins: every pass over the block draws its own)
+            covered = pre is not None and pre["first"] <= indices[0] and indices[-1] < pre["stop"] and self.prepared(indices[0]) is not None
+            if covered and pre.get("coins") is not None:
+                # a head-aware batch carries one-shot coins (one draw per RENDERED frame, as the reference's loop makes): an explicit
+                # prepare(a, b) followed by stream(range(a, b)) uses those draws -- n in all, not 2n -- and only a block one of whose coins
+                # has already been consumed is encoded again with fresh ones
+                covered = all(pre["coins"][i - pre["first"]] is not None for i in indices)
             if not covered:      # no batch, a stale one, or one that covers only part of the block (the rest would fall back to per-frame launches)
                 self.prepare(indices[0], indices[-1] + 1)      # every window of the block is resident: one encoder launch for all of them
         for i in indices:

@@ -5,8 +5,9 @@ Drop-in for `RADNeRFTorso` of modules/radnerfs/radnerf_torso.py:17-241 on the in
 (`rgb_map, depth_map, torso_alpha_map, torso_rgb_map, deform`).  Unlike the reference, `torso_shrink`
 and `torso_head_aware` are read from the hparams given to the constructor rather than from a
 process-global dict.  `torso_head_aware=True` (:36-46, :68-74, :175-179: a small encoder of the head's colour / opacity at the
-pixel feeds both torso MLPs, on a coin flip per frame) is served by the op-by-op path; the fused torso kernel is specialised
-for the default architecture (base.yaml:90 `torso_head_aware: false`) and `render_impl="auto"` routes accordingly.
+pixel feeds both torso MLPs, on a coin flip per frame) runs on the fused path too since round 5 (`k_torso_field<true>`: the encoder's
+outputs are eight extra MFMA steps of both first layers; `_pick_impl` says "fused" for it and tests/test_gpu_sweep.py asserts that);
+the op-by-op path stays as `render_impl="ops"`.
 """
 import random
 

@@ -176,7 +176,7 @@ typedef struct gf_frame_t {
     const float* torso_bias;    /* [96] folded per-frame constants (deform L1 64 | canonical L1 32), permuted rows */
     const float* torso_table; const int32_t* torso_offsets;
     const float* torso_occ;     /* density_grid_torso [grid*grid] */
-    const float* bg_coords;     /* [N,2] */
+    const float* bg_coords;     /* [N,2]; any finite value: beyond |bg_coords * torso_shrink| = 15.9 the encodings use the full-range sine, like gf_freq_encode_forward */
     float torso_S, torso_thresh, torso_shrink, _pad3;
     /* compositing */
     const float* bg_color;      /* [N,3] */
