@@ -98,7 +98,10 @@ def _is_torso(hparams) -> bool:
 def _new_model(hparams):
     from .radnerf import RADNeRF
     from .radnerf_torso import RADNeRFTorso
-    return (RADNeRFTorso if _is_torso(hparams) else RADNeRF)(hparams)
+    m = (RADNeRFTorso if _is_torso(hparams) else RADNeRF)(hparams)
+    if hparams.get("render_precision"):      # not a reference key: this renderer's arithmetic tier ("fp32" default, "split", "fast"), so that spawned ranks follow the parent
+        m.render_precision = hparams["render_precision"]
+    return m
 
 
 def _render_block(model, hparams, dataset, batches, device, rank, world_size, tmp_imgs_dir, pipeline_cls, collect=True):
@@ -134,13 +137,19 @@ def _render_block(model, hparams, dataset, batches, device, rank, world_size, tm
     return lo, out
 
 
-def _spawned_rank(rank, world_size, hparams, dataset, state_dict, batches, tmp_imgs_dir, pipeline_cls, use_cuda, port, block_dir):
-    """Process `rank` of forward_system's fan-out (base_nerf_infer.py:131-181): own GPU, own replica, own block of frames."""
+def _spawned_rank(rank, world_size, hparams, dataset, state_dict, batches, tmp_imgs_dir, pipeline_cls, use_cuda, port, block_dir, share_gpu=False):
+    """Process `rank` of forward_system's fan-out (base_nerf_infer.py:131-181): own GPU, own replica, own block of frames.
+    share_gpu (inp["ranks_share_gpu"], a TEST mode for a box with one GPU, like bench.py --ranks-share-gpu): every rank uses cuda:0 and gloo
+    carries the collectives (RCCL refuses two ranks on one device) -- the same replicas, broadcast, blocks and files, no scaling meaning."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"                     # init_ddp_connection, :108-113
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if use_cuda:
+    if use_cuda and share_gpu:
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    elif use_cuda:
         torch.cuda.set_device(rank)
         device = torch.device("cuda", rank)
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
@@ -288,14 +297,15 @@ class LM3d_RADNeRFInfer:
         import tempfile
         import torch.multiprocessing as mp
         use_cuda = self.device.type == "cuda"
-        if use_cuda and torch.cuda.device_count() < world:
+        share_gpu = bool(getattr(self, "inp", {}).get("ranks_share_gpu", False))
+        if use_cuda and not share_gpu and torch.cuda.device_count() < world:
             raise RuntimeError(f"forward_system: {world} ranks requested but {torch.cuda.device_count()} GPUs are visible")
         block_dir = tempfile.mkdtemp(prefix="gf_blocks_") if collect else None
         state_dict = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
         port = int(os.environ.get("MASTER_PORT", "12345"))          # the reference hard-codes 12345 (:112)
         try:
             mp.spawn(_spawned_rank, nprocs=world, join=True,
-                     args=(world, self.hparams, self.dataset, state_dict, batches, tmp_imgs_dir, self.pipeline_cls, use_cuda, port, block_dir))
+                     args=(world, self.hparams, self.dataset, state_dict, batches, tmp_imgs_dir, self.pipeline_cls, use_cuda, port, block_dir, share_gpu))
             if not collect:
                 return tmp_imgs_dir
             blocks = [np.load(os.path.join(block_dir, f)) for f in sorted(os.listdir(block_dir))]

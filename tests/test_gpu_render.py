@@ -1213,6 +1213,34 @@ def test_torso_mask_list_is_rebuilt_when_its_inputs_change():
     assert not torch.equal(b, c)
 
 
+def test_fused_torso_takes_any_finite_background_coordinate():
+    """gf_render_torso is a public entry.  Coordinates far outside the picture (|bg_coords * torso_shrink| > 15.9: the bounded-argument
+    sine of the fused encodings no longer applies) can only reach the field when the mask threshold is negative -- zero padding puts the
+    occupancy sample of such a pixel at 0 -- and then the fused path must give what the op-by-op path (full-range sine) gives, not finite
+    nonsense.  A wave with one such pixel takes the full-range sine for all of its pixels: same bits for the in-range ones."""
+    hp, sd, fused = build(True, "fused")
+    _, _, ops = build(True, "ops")
+    fi = frame_inputs(sequence(2, 64, 64), 1)
+    far = fi["bg_coords"].clone()
+    far[:, 5::7] *= 37.0           # every seventh pixel far outside, the others where they were
+    for m in (fused, ops):
+        m.density_thresh_torso = -1.0          # min(density_thresh_torso, mean_density_torso): every pixel is masked
+    outs = {}
+    for name, m in (("fused", fused), ("ops", ops)):
+        for tag, bgc in (("near", fi["bg_coords"]), ("far", far)):
+            with torch.no_grad():
+                outs[name, tag] = render_gpu(m, hp, dict(fi, bg_coords=bgc))
+    for k, tol in (("torso_alpha_map", 2e-5), ("torso_rgb_map", 2e-5), ("rgb_map", 1e-4)):
+        for tag in ("near", "far"):
+            a, b = outs["fused", tag][k], outs["ops", tag][k]
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() < tol, (k, tag, (a - b).abs().max().item())
+    # the pixels that stayed where they were: the far frame's waves took the other sine for them, the bits are the near frame's
+    keep = torch.ones(64 * 64, dtype=torch.bool)
+    keep[5::7] = False
+    assert torch.equal(outs["fused", "near"]["torso_alpha_map"].reshape(-1)[keep], outs["fused", "far"]["torso_alpha_map"].reshape(-1)[keep])
+
+
 @pytest.mark.parametrize("precision,impl", [("fp32", "fused"), ("fp32", "ops"), ("split", "fused")])
 @pytest.mark.parametrize("tag", ["hash", "hash_smoothstep", "smoothstep", "head_aware_coin_heads", "head_aware_coin_tails", "audio"])
 def test_variant_frame_vs_reference_golden(tag, precision, impl, monkeypatch):

@@ -193,6 +193,21 @@ def test_head_aware_batched_pass_draws_the_coins_a_frame_loop_draws():
     pipe.render_frame(0)
     pipe.wait()
     assert random.random() == second and first != second
+    # an explicit prepare(a, b) followed by stream(range(a, b)) uses the prepared draws: n coins in all, the frames of the frame loop, the random
+    # stream where that loop leaves it (stream() used to encode a head-aware block again, 2n draws); a second stream() over the same
+    # block -- its coins are spent -- draws n fresh ones
+    random.seed(123)
+    pipe.prepare(0, 12)
+    streamed = {i: torch.from_numpy(f.copy()) for i, f in pipe.stream(range(12))}
+    assert random.random() == after_plain
+    for i in range(12):
+        assert torch.equal(plain[i], streamed[i].view_as(plain[i])), f"frame {i}"
+    random.seed(9)
+    draws = [random.random() for _ in range(13)]
+    random.seed(9)
+    for _ in pipe.stream(range(12)):
+        pass
+    assert random.random() == draws[12]
 
 
 def test_the_oracle_moves_under_a_last_ulp_ray_change():
