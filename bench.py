@@ -518,6 +518,13 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
         if real and rank == 0:
             roofline = measure_roofline(pipe, args.impl, Wm, min(args.profile_frames, K), PEAK_F32_MFMA_TFLOPS, precision=args.precision)
 
+    # the PNG leg on N > 1 ranks (round 6): every rank writes its frames into ONE directory, as the reference's fan-out does (base_nerf_infer.py:97-101,
+    # 150-179) -- the one host-side term of the N-GPU curve.  All ranks take part (barriers inside); rank 0 keeps the result.
+    png_multi = None
+    if real and world > 1 and args.png_frames > 0:
+        with torch.no_grad():
+            png_multi = png_leg(pipe, Wm, min(args.png_frames, K), job=job)
+
     # every rank's own clock and replica checksum, gathered: the line shows N separate measurements, not just the max
     mine = [K / timed_loop.local_median_s if getattr(timed_loop, "local_median_s", None) else 0.0, float(frames[0]), float(frames[1])]
     per_rank_rows = job.gather(mine)
@@ -571,6 +578,8 @@ def run_rank(args, backend="nccl", make_pipe=None, emit=None):
             except Exception as e:      # noqa: BLE001
                 import traceback
                 return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc(limit=3)[-600:]}
+        if png_multi is not None:
+            line["with_png"] = png_multi
         if real and world == 1:
             if args.png_frames > 0:
                 line["with_png"] = leg(png_leg, pipe, Wm, min(args.png_frames, K))
@@ -736,7 +745,7 @@ def compact_line(full, details_path):
     small("stress_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
     small("heavy_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
     small("head_only", ("value", "ms_per_step"))
-    small("with_png", ("value", "frames", "png_workers", "png_MB_per_frame"))
+    small("with_png", ("value", "frames", "ranks_writing_into_one_directory", "png_workers", "host_cores_effective", "host_cores_reported", "png_zlib_level", "png_MB_per_frame"))
     lat = full.get("latency")
     if isinstance(lat, dict):
         line["latency"] = {"error": lat["error"][:200]} if "error" in lat else \
@@ -1097,34 +1106,54 @@ def apply_rank_parity_guard(line, rank_parity):
     return line
 
 
-def png_leg(pipe, first, n):
+def png_leg(pipe, first, n, job=None):
     """the rate with the PNG files of base_nerf_infer.py:97-101 written as well (worker threads off the render thread; a tmpfs
-    directory).  Reported beside `value`, never inside it."""
+    directory).  Reported beside `value`, never inside it.  With `job` (N > 1 ranks): every rank writes ITS frames into the SAME directory,
+    pool and zlib level planned for N writers sharing the host (png.plan_writer: effective cores, not os.cpu_count()), the passes bracketed
+    by barriers, value = all ranks' frames / the slowest rank's time."""
     import shutil
     import tempfile
     import torch
-    from geneface_amd.png import FrameWriter
-    out_dir = tempfile.mkdtemp(prefix="gf_png_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    workers = min(32, os.cpu_count() or 4)
+    from geneface_amd.png import FrameWriter, effective_cpus, plan_writer
+    world = job.world if job is not None else 1
+    rank = job.rank if job is not None else 0
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    if world > 1:       # one directory for all ranks, named by the rendezvous port (every rank knows it), made by whoever comes first
+        out_dir = os.path.join(base, f"gf_png_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if 'RANK' not in os.environ else 0}")
+        os.makedirs(out_dir, exist_ok=True)
+    else:
+        out_dir = tempfile.mkdtemp(prefix="gf_png_", dir=base)
+    workers, level = plan_writer(world)
     try:
-        writer = FrameWriter(out_dir, workers=workers)
+        writer = FrameWriter(out_dir, workers=workers, level=level)
         passes = 4     # the last frames' encodes (5-9 ms each) finish after the last render: over 48 frames that tail was 12 % of the leg
+        if job is not None:
+            job.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
             for rep in range(passes):
                 for i, frame in pipe.stream(range(first, first + n)):
-                    writer.submit(rep * 100000 + i, frame)
+                    writer.submit(rep * 1000000 + rank * 10000 + i, frame)
         writer.close()
         dt = time.perf_counter() - t0
+        if job is not None:
+            dt = job.reduce(dt, "max")
+            job.barrier()
         n *= passes
-        nbytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
         stages = writer.stage_seconds() if hasattr(writer, "stage_seconds") else None
+        nbytes = stages["bytes"] if stages else 0
     finally:
-        shutil.rmtree(out_dir, ignore_errors=True)
-    return {"value": n / dt, "unit": "frames/s", "frames": n, "png_workers": workers, "png_zlib": {"level": writer.level, "strategy": writer.strategy},
+        if job is not None:
+            job.barrier()
+        if rank == 0:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    return {"value": world * n / dt, "unit": "frames/s", "frames": world * n, "ranks_writing_into_one_directory": world, "png_workers": workers,
+            "host_cores_effective": effective_cpus(), "host_cores_reported": os.cpu_count(),
+            "png_zlib": {"level": writer.level, "strategy": writer.strategy}, "png_zlib_level": writer.level,
             "png_MB_per_frame": nbytes / n / 1e6, "encoder_stage_seconds": stages,
-            "note": "render + D2H + PNG encode/write on worker threads (FramePipeline.stream keeps the pipeline full)"}
+            "note": "render + D2H + PNG encode/write on worker threads (FramePipeline.stream keeps the pipeline full)"
+                    + ("; this rank's writer statistics, all ranks' frames over the slowest rank's time" if world > 1 else "")}
 
 
 def pmc_traffic():

@@ -120,8 +120,11 @@ def _render_block(model, hparams, dataset, batches, device, rank, world_size, tm
         from .png import FrameWriter
         os.makedirs(tmp_imgs_dir, exist_ok=True)
         # ~5 ms of deflate per 512x512 frame: four workers would cap the loop near 830 fps, below the split and fast tiers.  This rank's share
-        # of the host cores, at most 32 (bench.py's PNG leg sizes its pool the same way)
-        writer = FrameWriter(tmp_imgs_dir, workers=max(2, min(32, (os.cpu_count() or 4) // max(1, world_size))))
+        # of the cores the process may really use (cgroup quota and affinity, not os.cpu_count(): png.effective_cpus), at most 32; stored
+        # blocks instead of Z_RLE when the share is too small for a rank's frame rate (png.plan_writer; bench.py's PNG leg plans the same way)
+        from .png import plan_writer
+        workers, level = plan_writer(world_size, hparams.get("infer_png_zlib_level"))
+        writer = FrameWriter(tmp_imgs_dir, workers=workers, level=level)
     pipe = pipeline_cls(model, hparams, seq, device, frames=(lo, hi), impl="fused" if torch.device(device).type == "cuda" else None)
     out = np.empty((hi - lo, dataset.H, dataset.W, 3), dtype=np.uint8) if collect else None
     try:

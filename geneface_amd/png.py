@@ -48,6 +48,51 @@ def decode_rgb8(data: bytes) -> np.ndarray:
     return raw[:, 1:].reshape(H, W, 3).copy()
 
 
+def effective_cpus() -> int:
+    """Host cores this PROCESS may actually use: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU quota
+    (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  A GPU pod typically reports the node's 256 logical cores while its
+    quota is a few dozen: worker pools sized from os.cpu_count() then oversubscribe the quota and every thread is throttled -- measured on
+    the MI355X box (tools/png_scale.py, profiles/round6/r6a_png_scale_*): one writer with 8 workers deflates a frame in 4.6 ms, eight writers
+    with 32 workers each in 40-54 ms, and the aggregate FALLS from 4 000 to 2 300 frames/s."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:             # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def plan_writer(world_size: int = 1, level=None, cpus: int = None):
+    """(workers, zlib level) of ONE rank's FrameWriter when `world_size` ranks of a node write frames at once (base_nerf_infer.py:131-181: every
+    rank writes into the same tmp_imgs_dir).  The rank's share of the EFFECTIVE cores decides:
+      * share >= 8: Z_RLE level 1 (4.6 ms of deflate per 512x512 frame, 0.66 MB files), one worker per core of the share up to 32 -- a rank
+        renders 750-1 800 frames/s, i.e. needs 4-9 deflating cores;
+      * fewer: level 0, stored blocks (adler32 + crc32 + a copy: ~0.7-1.1 ms per frame, 0.79 MB files -- 19 % larger; the files are an
+        intermediate the reference deletes after the ffmpeg mux, base_nerf_infer.py:307-317), so that eight ranks need ~6 cores in all instead of ~40.
+    `level` (hparams['infer_png_zlib_level']) overrides the choice."""
+    share = max(1, (cpus if cpus is not None else effective_cpus()) // max(1, int(world_size)))
+    if level is None or level == "auto":
+        level = 1 if share >= 8 else 0
+    level = int(level)
+    workers = max(2, min(32, share)) if level > 0 else max(2, min(8, share))
+    return workers, level
+
+
 class FrameWriter:
     """Writes frames as `<dir>/<idx:05d>.png` on NATIVE worker threads (gf_png_writer_* of libgeneface_hip.so: deflate + CRC + file write with
     no interpreter lock anywhere on the path); `close()` waits for all of them.  Round 2 ran zlib.compress on a Python thread pool: the

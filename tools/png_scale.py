@@ -41,11 +41,11 @@ def synthetic_frames(n=16, size=512, seed=0):
     return out
 
 
-def _rank(rank, ranks, frames, workers, out_dir, pace, barrier, q):
+def _rank(rank, ranks, frames, workers, out_dir, pace, barrier, q, level=1, strategy=3):
     from geneface_amd.png import FrameWriter
     src = synthetic_frames()
     first = rank * frames                       # contiguous blocks, as infer.shard_range hands them out
-    w = FrameWriter(out_dir, workers=workers)
+    w = FrameWriter(out_dir, workers=workers, level=level, strategy=strategy)
     w.submit(10 ** 6 + rank, src[0])            # creates the pool outside the timed region
     barrier.wait()
     t0 = time.perf_counter()
@@ -63,13 +63,13 @@ def _rank(rank, ranks, frames, workers, out_dir, pace, barrier, q):
            "write_ms_per_frame": st["write_sum_over_workers"] / st["frames"] * 1e3, "wait_for_room_s": st["wait_for_room"], "MB_per_frame": st["bytes"] / st["frames"] / 1e6})
 
 
-def run(ranks, frames, workers, layout, pace, base):
+def run(ranks, frames, workers, layout, pace, base, level=1, strategy=3):
     ctx = mp.get_context("spawn")
     root = tempfile.mkdtemp(prefix="gf_pngscale_", dir=base)
     try:
         barrier, q = ctx.Barrier(ranks), ctx.Queue()
         dirs = [root if layout == "shared" else os.path.join(root, f"rank{r}") for r in range(ranks)]
-        ps = [ctx.Process(target=_rank, args=(r, ranks, frames, workers, dirs[r], pace, barrier, q)) for r in range(ranks)]
+        ps = [ctx.Process(target=_rank, args=(r, ranks, frames, workers, dirs[r], pace, barrier, q, level, strategy)) for r in range(ranks)]
         t0 = time.perf_counter()
         for p in ps:
             p.start()
@@ -79,7 +79,7 @@ def run(ranks, frames, workers, layout, pace, base):
         n_files = sum(len([f for f in os.listdir(d) if f.endswith(".png")]) for d in set(dirs))
         assert n_files == ranks * (frames + 1), (n_files, ranks * (frames + 1))
         slow = max(r["seconds"] for r in res)
-        return {"ranks": ranks, "workers_per_rank": workers, "layout": layout, "pace_per_rank": pace, "frames_per_rank": frames,
+        return {"zlib_level": level, "zlib_strategy": strategy, "ranks": ranks, "workers_per_rank": workers, "layout": layout, "pace_per_rank": pace, "frames_per_rank": frames,
                 "aggregate_fps": ranks * frames / slow, "slowest_rank_fps": min(r["fps"] for r in res), "MB_per_frame": res[0]["MB_per_frame"],
                 "deflate_ms_per_frame": float(np.mean([r["deflate_ms_per_frame"] for r in res])),
                 "write_ms_per_frame": float(np.mean([r["write_ms_per_frame"] for r in res])),
@@ -96,13 +96,15 @@ def main():
     ap.add_argument("--pace", type=float, default=0.0, help="frames/s each rank submits at (0: as fast as the writer accepts)")
     ap.add_argument("--layouts", default="shared,per_rank")
     ap.add_argument("--base", default="/dev/shm", help="where the directories go (/dev/shm: page cache only; a disk path: the box's file system)")
+    ap.add_argument("--level", type=int, default=1, help="zlib level (0: stored blocks -- adler32 + crc32 + copy only, 0.79 MB per 512x512 frame)")
+    ap.add_argument("--strategy", type=int, default=3, help="zlib strategy (3: Z_RLE, the writer's default)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     rec = {"host_cores": os.cpu_count(), "base": a.base, "frames": "synthetic 512x512 (gradient + textured blob), 16 distinct", "results": []}
     for layout in a.layouts.split(","):
         for workers in map(int, a.workers.split(",")):
             for ranks in map(int, a.ranks.split(",")):
-                r = run(ranks, a.frames, workers, layout, a.pace, a.base)
+                r = run(ranks, a.frames, workers, layout, a.pace, a.base, a.level, a.strategy)
                 rec["results"].append(r)
                 print(json.dumps(r), flush=True)
     if a.out:
