@@ -24,7 +24,12 @@ def main():
     ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default multi-tensor path (what the reference's trainer builds) "
                     "instead of fused=True")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast + GradScaler, as the May config trains (lm3d_radnerf.yaml:5 amp: true)")
+    ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
+                    "only torso parameters in the optimizer (networks at lr, the 2-D grid at 10 lr), mse on rgb_map + the alpha entropy term, "
+                    "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
     args = ap.parse_args()
+    if args.torso:
+        return main_torso(args)
     import torch
     from geneface_amd import hparams as HP
     from geneface_amd import synthetic as S
@@ -79,6 +84,71 @@ def main():
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
+
+
+def main_torso(args):
+    import torch
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd import utils
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+
+    dev = torch.device("cuda", 0)
+    hp = HP.may_hparams(True)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(S.make_state_dict(hp, True), strict=True)
+    model = model.to(dev).train()
+    seq = S.make_sequence(8, 512, 512, hp)
+    poses = torch.from_numpy(seq["poses"]).to(dev)
+    cond = torch.from_numpy(seq["cond_wins"]).to(dev)
+    model.poses = poses                                             # update_extra_state draws its pose from them (radnerf_torso.py:44-46, :203-207)
+    pose6 = utils.convert_poses(poses)
+    bg = torch.from_numpy(seq["bg_img"]).to(dev).view(1, -1, 3)
+    bgc = utils.get_bg_coords(512, 512, dev)
+    target = torch.rand(1, 512 * 512, 3, device=dev)
+    emb = [p for k, p in model.named_parameters() if "torso_embedder" in k]
+    net = [p for k, p in model.named_parameters() if "torso_embedder" not in k and "torso" in k]
+    for k, p in model.named_parameters():
+        if "torso" not in k:
+            p.requires_grad_(False)
+    opt = torch.optim.Adam(net, lr=5e-4, betas=(0.9, 0.99), eps=1e-15, fused=not args.foreach_adam)
+    opt.add_param_group({"params": emb, "lr": 5e-3, "betas": (0.9, 0.99), "eps": 1e-15})
+    torch.manual_seed(0)
+    scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
+    masked = [0]
+
+    def step(i):
+        if i % hp["update_extra_interval"] == 0:
+            model.update_extra_state()
+        f = i % len(poses)
+        rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], 512, 512, args.n_rays)
+        sel = rays["inds"][0]
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], pose6[f:f + 1], index=0, bg_color=bg[:, sel],
+                               perturb=True, force_all_rays=False, **hp)
+            alphas = out["torso_alpha_map"].clamp(1e-5, 1 - 1e-5)
+            loss = ((out["rgb_map"] - target[:, sel]) ** 2).mean() \
+                + 1e-3 * torch.mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas))
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rate = args.steps / dt
+    print(json.dumps({"metric": f"RAD-NeRF TORSO training steps/s (head frozen; n_rays {args.n_rays}, {'fp16 autocast' if args.amp else 'fp32'}, "
+                                f"{'foreach' if args.foreach_adam else 'fused'} Adam, torso occupancy update every 16 steps)", "value": rate,
+                      "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600,
+                      "masked_pixels_last_step": int((out["torso_alpha_map"] > 0).sum()), "head_points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
+                      "reference_published": "~4 h for the torso on an RTX 3090 Ti, docs/train_models/train_models.md:93", "data": "synthetic"}))
 
 
 if __name__ == "__main__":
