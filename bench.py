@@ -265,36 +265,77 @@ def parity_vs_oracle(pipe, hp, sd, torso, frames=PARITY_FRAMES, clock=None, graz
     return out
 
 
-def legacy_nerf_baseline(seq, rays=4096):
+def legacy_nerf_baseline(seq, rays=4096, full_size=64):
     """Baseline B2: the reference's only pure-PyTorch renderer, the vanilla Lm3dNeRF it replaced
-    (64 + 128 samples per ray, two 8x256 MLPs, chunk 2048), restated in oracle/legacy_nerf_ref.py, random weights; a bounded
-    sample of rays of one 512x512 frame, extrapolated to the frame.  Context only: a different model from the hot path."""
+    (64 + 128 samples per ray, two 8x256 MLPs, chunk 2048), random weights.  Context only: a different model from the hot path.
+    Round 6 (VERDICT r5 weak #1c): when the staged archive of the reference's Python is present (oracle/_refpy/geneface_refpy.zip, packed
+    unmodified by oracle/refpy/stage.py -- it travels to the GPU box like oracle/_ref), the reference's OWN modules.nerfs classes are timed
+    (`kind: "reference"`): `Lm3dNeRF` rendered by `render_dynamic_face` on one WHOLE full_size x full_size frame (configs[0]: 64 x 64) and on a
+    bounded sample of `rays` rays of the 512 x 512 frame, extrapolated.  Without the archive: the restatement oracle/legacy_nerf_ref.py
+    (`kind: "port"`; tests/test_vs_reference.py holds it to 1e-6 of the reference's classes on identical weights and draws)."""
     import torch
     from oracle import legacy_nerf_ref as LN
     H, W = seq["H"], seq["W"]
     fx, _, cx, cy = (float(v) for v in seq["intrinsics"])
-    w = LN.make_weights(0)
     c2w = torch.tensor([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 0.6]], dtype=torch.float32)
     bg, cond = torch.from_numpy(seq["bg_img"]).view(H, W, 3), torch.zeros(64)
+    archive = os.path.join(ROOT, "oracle", "_refpy", "geneface_refpy.zip")
+    render, kind = None, "port"
+    if os.path.exists(archive):
+        try:
+            import zipfile
+            if "modules/nerfs/lm3d_nerf/lm3d_nerf.py" in zipfile.ZipFile(archive).namelist():
+                from oracle import refshim
+                refshim.install(root=archive)
+                with refshim.cpu_mode():
+                    from modules.nerfs.commons.volume_rendering import render_dynamic_face
+                    from modules.nerfs.lm3d_nerf.lm3d_nerf import Lm3dNeRF
+                    torch.manual_seed(0)
+                    ref_model = Lm3dNeRF({"cond_dim": 64, "hidden_size": 256, "use_window_cond": True, "cond_win_size": 1, "smo_win_size": 5,
+                                          "with_att": True}).eval()
+
+                def render(h, w, f, px, py, max_rays=None):       # the reference's own chunked renderer on the first max_rays rays of an h x w frame
+                    ro, rd = LN.get_rays(h, w, f, c2w, px, py)       # (ray generation is not what is timed; same rays as the port's)
+                    n = h * w if max_rays is None else min(max_rays, h * w)
+                    ro, rd = ro.reshape(-1, 3)[:n].reshape(1, n, 3), rd.reshape(-1, 3)[:n].reshape(1, n, 3)
+                    bgs = torch.nn.functional.interpolate(bg.permute(2, 0, 1)[None], size=(h, w))[0].permute(1, 2, 0).reshape(-1, 3)[:n].reshape(1, n, 3)
+                    with torch.no_grad(), refshim.cpu_mode():
+                        return render_dynamic_face(1, n, f, px, py, chunk=2048, rays_o=ro, rays_d=rd, bc_rgb=bgs, cond=cond, near=0.3, far=0.9,
+                                                   network_fn=ref_model, N_samples=64, N_importance=128)[0]
+                kind = "reference"
+        except Exception as e:      # noqa: BLE001  (a broken archive must not cost the line its baseline: fall back to the port and say so)
+            render, kind = None, f"port (the staged reference failed to load: {type(e).__name__}: {e})"[:160]
+    if render is None:
+        w_ = LN.make_weights(0)
+
+        def render(h, w, f, px, py, max_rays=None):
+            bgs = torch.nn.functional.interpolate(bg.permute(2, 0, 1)[None], size=(h, w))[0].permute(1, 2, 0)
+            return LN.render(w_, h, w, f, px, py, c2w, bgs, cond, max_rays=max_rays)
     # 2048-ray chunks of 256-wide layers do not scale to a whole two-socket host: time one chunk at a few thread counts, keep the best
     all_threads = torch.get_num_threads()
     best_t, best_dt = all_threads, None
     for t in sorted({all_threads, min(all_threads, 32), min(all_threads, 16)}, reverse=True):
         torch.set_num_threads(t)
-        LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)        # warm-up at this thread count
+        render(H, W, fx, cx, cy, max_rays=LN.CHUNK)        # warm-up at this thread count
         t0 = time.perf_counter()
-        LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=LN.CHUNK)
+        render(H, W, fx, cx, cy, max_rays=LN.CHUNK)
         d = time.perf_counter() - t0
         if best_dt is None or d < best_dt:
             best_t, best_dt = t, d
     torch.set_num_threads(best_t)
     t0 = time.perf_counter()
-    LN.render(w, H, W, fx, cx, cy, c2w, bg, cond, max_rays=rays)
+    render(H, W, fx, cx, cy, max_rays=rays)
     dt = time.perf_counter() - t0
+    s = full_size / H
+    t0 = time.perf_counter()
+    small = render(full_size, full_size, fx * s, cx * s, cy * s)      # configs[0]: one whole 64 x 64 frame, nothing extrapolated
+    dt_small = time.perf_counter() - t0
     torch.set_num_threads(all_threads)
     s_per_frame = dt / rays * H * W
-    return {"value": 1.0 / s_per_frame, "unit": "frames/s", "s_per_frame": s_per_frame, "cores": best_t, "kind": "port",
-            "sample": f"{rays} of {H * W} rays of one frame (2 chunks of 2048), extrapolated; published anchor ~28.8 s/frame on an RTX 2080 Ti"}
+    return {"value": 1.0 / s_per_frame, "unit": "frames/s", "s_per_frame": s_per_frame, "cores": best_t, "kind": kind,
+            "whole_frame_64x64": {"s_per_frame": dt_small, "rays": int(full_size * full_size), "finite": bool(torch.isfinite(torch.as_tensor(small)).all())},
+            "sample": f"{rays} of {H * W} rays of one frame (2 chunks of 2048), extrapolated; one whole {full_size}x{full_size} frame beside it; "
+                      "published anchor ~28.8 s/frame on an RTX 2080 Ti"}
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -767,7 +808,7 @@ def compact_line(full, details_path):
 
 HEAVY_RADIUS, HEAVY_SIGMA_SCALE = 2.75, 0.3
 VARIANT_NAMES = ("hash", "hash_smoothstep", "smoothstep", "head_aware", "audio")
-VARIANT_PARITY_FRAMES = (14, 24)
+VARIANT_PARITY_FRAMES = PARITY_FRAMES      # round 6: the headline's own 8 fixture frames (round 5 checked two per variant: VERDICT r5 weak #1a); ~2 s of oracle each, reused by the split tier
 
 
 def variants_leg(args, job, parity_on, headline_fps):
@@ -775,7 +816,7 @@ def variants_leg(args, job, parity_on, headline_fps):
     lm3d_radnerf_hash.yaml:8, + smoothstep lm3d_radnerf_hash_smoothstep.yaml:8-9, smoothstep on tiled grids lm3d_radnerf_smoothstep.yaml:8,
     lm3d_radnerf_torso_head_aware.yaml:9, and the audio-driven egs_bases/radnerf/radnerf.yaml:4-7 -- 44 x 16 windows, smo_win 8, the Obama
     identity): the same workload (512x512 head+torso, K frames) on each -- fps on the exact-fp32 tier, the head kernel's roofline fraction,
-    samples per frame, fps on the split tier, and parity against the oracle on two frames of the parity fixture (identical device bits)."""
+    samples per frame, fps on the split tier, and parity against the oracle on the headline's 8 fixture frames (identical device bits)."""
     import torch
     from geneface_amd import hparams as HP
     from geneface_amd import synthetic as S

@@ -316,6 +316,239 @@ __global__ void __launch_bounds__(kThreads) k_torso_blend(const TorsoArgs a) {
     if (n == 0 && a.count_reset) *a.count_reset = 0u;     // the list is consumed (k_torso_field finished before this launch started): a second torso pass on the same head starts a new one
 }
 
+// ---------------------------------------------------------------------------------------------------- training field (round 6)
+// forward_torso (radnerf_torso.py:51-84) for the torso task's step (tasks/radnerfs/radnerf_torso.py:74-122): the same chain as k_torso_field
+// over a plain list of M pixel coordinates, every layer's activations saved row-major for the backward pass, and the input-gradient chain
+// of that field in a second launch.  Default architecture only (torso_head_aware = false); include/geneface_hip.h, gf_torso_train_t.
+struct TorsoTrainArgs {
+    uint32_t M; float shrink;
+    const float* x;
+    const float *pack, *bias, *table; const int* offsets;
+    gf::GridLevels lv;
+    float *out, *dx;
+    float *enc, *h_d1, *h_d2, *x01, *g, *h_c1, *h_c2;
+    const float *bwd, *g_out, *g_dx;
+    float *dz_c3, *dz_c2, *dz_c1, *dz_d3, *dz_d2, *dz_d1, *g_grid; uint32_t* level_max;
+};
+
+// this lane's NOB * 16 accumulator-order values <-> row j of a row-major [M, NOB * 32] matrix: registers 4q..4q+3 of block ob are the four
+// consecutive features ob * 32 + 8q + 4 half + 0..3 (mfma_mlp.hpp)
+template <int NOB>
+__device__ __forceinline__ void rows_store(float* __restrict__ G, size_t pt, int half, const float (&a)[NOB * 16]) {
+    float* row = G + pt * (NOB * 32) + 4 * half;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4*>(row + ob * 32 + 8 * q) = float4{a[ob * 16 + 4 * q], a[ob * 16 + 4 * q + 1], a[ob * 16 + 4 * q + 2], a[ob * 16 + 4 * q + 3]};
+}
+template <int NOB>
+__device__ __forceinline__ void rows_load(const float* __restrict__ G, size_t pt, int half, float (&a)[NOB * 16]) {
+    const float* row = G + pt * (NOB * 32) + 4 * half;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(row + ob * 32 + 8 * q);
+            a[ob * 16 + 4 * q] = v.x; a[ob * 16 + 4 * q + 1] = v.y; a[ob * 16 + 4 * q + 2] = v.z; a[ob * 16 + 4 * q + 3] = v.w;
+        }
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_torso_train_fwd(const TorsoTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* pack = reinterpret_cast<float*>(smem_raw);   // [TP_TOTAL]
+    float* bias = pack + gf::TP_TOTAL;                  // [TB_TOTAL]
+    float* meta = bias + gf::TB_TOTAL;                  // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    gf::dma_to_lds(pack, a.pack, (int)gf::TP_TOTAL, wave, lane);
+    if (tid < (int)gf::TB_TOTAL) bias[tid] = a.bias[tid];
+    if (tid < 16) {
+        meta[tid * 4 + 0] = a.lv.scale[tid];
+        meta[tid * 4 + 1] = __uint_as_float(a.lv.resolution[tid]);
+        meta[tid * 4 + 2] = __uint_as_float((uint32_t)a.offsets[tid]);
+        meta[tid * 4 + 3] = __uint_as_float((uint32_t)(a.offsets[tid + 1] - a.offsets[tid]));
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (uint32_t base = (uint32_t)blockIdx.x * 128u; base < a.M; base += gridDim.x * 128u) {
+        const uint32_t tile0 = base + (uint32_t)wave * 32u;
+        if (tile0 >= a.M) continue;                       // wave-uniform; no barrier inside the loop
+        const uint32_t j = tile0 + (uint32_t)(lane & 31);
+        const bool valid = j < a.M;
+        const size_t pt = valid ? j : tile0;
+        const float x0 = a.x[pt * 2] * a.shrink, x1 = a.x[pt * 2 + 1] * a.shrink;
+        float enc[24];
+        if (__builtin_expect(__any(!(fabsf(x0) <= 15.9f && fabsf(x1) <= 15.9f)), 0)) {
+#pragma unroll 1
+            for (int t = 0; t < 24; t++) enc[t] = enc_entry<false>(x0, x1, 24 * half + t);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 24; t++) enc[t] = enc_entry<true>(x0, x1, 24 * half + t);
+        }
+        if (valid) {
+            float* row = a.enc + pt * 48 + 24 * half;
+#pragma unroll
+            for (int q = 0; q < 6; q++) *reinterpret_cast<float4*>(row + 4 * q) = float4{enc[4 * q], enc[4 * q + 1], enc[4 * q + 2], enc[4 * q + 3]};
+        }
+        floatx16 h2[2];
+        float act2[32];
+        gf::mfma_layer<2, 24, true, false>(pack + gf::TP_D1, lane, enc, bias, h2);
+        gf::unpack<2>(h2, act2);
+        if (valid) rows_store<2>(a.h_d1, pt, half, act2);
+        gf::mfma_layer<2, 32, true, false>(pack + gf::TP_D2, lane, act2, nullptr, h2);
+        gf::unpack<2>(h2, act2);
+        if (valid) rows_store<2>(a.h_d2, pt, half, act2);
+        float dx[2];
+        gf::valu_rows<2, 2>(pack + gf::TP_D3, half, act2, dx);
+        const float xc[2] = {(fminf(fmaxf(x0 + dx[0], -1.0f), 1.0f) + 1.0f) / 2.0f, (fminf(fmaxf(x1 + dx[1], -1.0f), 1.0f) + 1.0f) / 2.0f};
+        float in[40];
+        {
+            float g[16];
+            gf::encode_half<2>(a.table, meta, half, 1u /*tiled*/, 0u /*linear*/, xc, g);
+            if (valid) {
+                float* row = a.g + pt * 32 + 16 * half;
+#pragma unroll
+                for (int q = 0; q < 4; q++) *reinterpret_cast<float4*>(row + 4 * q) = float4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+            }
+#pragma unroll
+            for (int t = 0; t < 16; t++) in[t] = g[t];
+#pragma unroll
+            for (int t = 0; t < 24; t++) in[16 + t] = enc[t];
+        }
+        floatx16 h1[1];
+        float act1[16];
+        gf::mfma_layer<1, 40, true, false>(pack + gf::TP_C1, lane, in, bias + 64, h1);
+        gf::unpack<1>(h1, act1);
+        if (valid) rows_store<1>(a.h_c1, pt, half, act1);
+        gf::mfma_layer<1, 16, true, false>(pack + gf::TP_C2, lane, act1, nullptr, h1);
+        gf::unpack<1>(h1, act1);
+        if (valid) rows_store<1>(a.h_c2, pt, half, act1);
+        float o4[4];
+        gf::valu_rows<4, 1>(pack + gf::TP_C3, half, act1, o4);
+        if (valid && half == 0) {
+            *reinterpret_cast<float4*>(a.out + pt * 4) = float4{1.0f / (1.0f + __expf(-o4[0])), 1.0f / (1.0f + __expf(-o4[1])),
+                                                                1.0f / (1.0f + __expf(-o4[2])), 1.0f / (1.0f + __expf(-o4[3]))};
+            *reinterpret_cast<float2*>(a.dx + pt * 2) = float2{dx[0], dx[1]};
+            *reinterpret_cast<float2*>(a.x01 + pt * 2) = float2{xc[0], xc[1]};
+        }
+    }
+}
+
+// Backward streams (floats): W_c2^T [1 block x 16 steps] | W_c1[:, grid]^T [1 x 16] | W_d2^T [2 x 32], each [ob][step/4][lane][step%4]
+constexpr uint32_t TBW_C2T = 0, TBW_C1GT = TBW_C2T + 16 * 64, TBW_D2T = TBW_C1GT + 16 * 64, TBW_TOTAL = TBW_D2T + 2 * 32 * 64;
+constexpr size_t kTorsoBwdSmem = (TBW_TOTAL + 2 * 64 + 4 * 32) * sizeof(float) + 16 * sizeof(gf::LevelMeta) + 16 * sizeof(uint32_t);
+
+__global__ void __launch_bounds__(kThreads, 2) k_torso_train_bwd(const TorsoTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* bw = reinterpret_cast<float*>(smem_raw);     // [TBW_TOTAL] transposed streams
+    float* d3 = bw + TBW_TOTAL;                         // [2][64] deform L3 rows, accumulator-layout order (the forward pack's)
+    float* c3 = d3 + 2 * 64;                            // [4][32] canonical L3 rows
+    gf::LevelMeta* meta = reinterpret_cast<gf::LevelMeta*>(c3 + 4 * 32);
+    uint32_t* lmax = reinterpret_cast<uint32_t*>(meta + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    static_assert(TBW_TOTAL % 256 == 0, "whole 1-KiB DMA instructions");
+    gf::dma_to_lds(bw, a.bwd, (int)TBW_TOTAL, wave, lane);
+    if (tid < 128) d3[tid] = a.pack[gf::TP_D3 + tid];
+    if (tid < 128) c3[tid] = a.pack[gf::TP_C3 + tid];
+    if (tid < 16) {
+        meta[tid] = gf::make_level_meta<2>(a.lv.scale[tid], a.lv.resolution[tid], a.offsets, (uint32_t)tid, 1u);
+        lmax[tid] = 0u;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (uint32_t base = (uint32_t)blockIdx.x * 128u; base < a.M; base += gridDim.x * 128u) {
+        const uint32_t tile0 = base + (uint32_t)wave * 32u;
+        if (tile0 >= a.M) continue;
+        const uint32_t j = tile0 + (uint32_t)(lane & 31);
+        const bool valid = j < a.M;
+        const size_t pt = valid ? j : tile0;
+        // ---- outputs: d z = g * s (1 - s)
+        const float4 o = *reinterpret_cast<const float4*>(a.out + pt * 4), go = *reinterpret_cast<const float4*>(a.g_out + pt * 4);
+        float dz3[4] = {go.x * o.x * (1.0f - o.x), go.y * o.y * (1.0f - o.y), go.z * o.z * (1.0f - o.z), go.w * o.w * (1.0f - o.w)};
+        if (!valid) { dz3[0] = dz3[1] = dz3[2] = dz3[3] = 0.0f; }
+        if (valid && half == 0) *reinterpret_cast<float4*>(a.dz_c3 + pt * 4) = float4{dz3[0], dz3[1], dz3[2], dz3[3]};
+        // ---- canonical net, back to front
+        float act[16], dz[16];
+        rows_load<1>(a.h_c2, pt, half, act);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 s4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 w = *reinterpret_cast<const float4*>(c3 + c * 32 + half * 16 + 4 * q);
+                s4.x = __builtin_fmaf(dz3[c], w.x, s4.x); s4.y = __builtin_fmaf(dz3[c], w.y, s4.y);
+                s4.z = __builtin_fmaf(dz3[c], w.z, s4.z); s4.w = __builtin_fmaf(dz3[c], w.w, s4.w);
+            }
+            dz[4 * q] = act[4 * q] > 0.0f ? s4.x : 0.0f; dz[4 * q + 1] = act[4 * q + 1] > 0.0f ? s4.y : 0.0f;
+            dz[4 * q + 2] = act[4 * q + 2] > 0.0f ? s4.z : 0.0f; dz[4 * q + 3] = act[4 * q + 3] > 0.0f ? s4.w : 0.0f;
+        }
+        if (valid) rows_store<1>(a.dz_c2, pt, half, dz);
+        floatx16 h1[1];
+        gf::mfma_layer<1, 16, false, false>(bw + TBW_C2T, lane, dz, nullptr, h1);
+        rows_load<1>(a.h_c1, pt, half, act);
+#pragma unroll
+        for (int r = 0; r < 16; r++) dz[r] = act[r] > 0.0f ? h1[0][r] : 0.0f;
+        if (valid) rows_store<1>(a.dz_c1, pt, half, dz);
+        gf::mfma_layer<1, 16, false, false>(bw + TBW_C1GT, lane, dz, nullptr, h1);
+        // h1[0][r] = d loss / d grid feature 16 half + r  (level 8 half + r / 2, channel r & 1: the rows of the stream are permuted for this)
+        float gg[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) gg[r] = valid ? h1[0][r] : 0.0f;
+        if (valid) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(a.g_grid + ((size_t)(8 * half + l) * a.M + pt) * 2) = float2{gg[2 * l], gg[2 * l + 1]};
+            if (a.level_max) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const uint32_t m0 = __float_as_uint(gg[2 * l]) & 0x7fffffffu, m1 = __float_as_uint(gg[2 * l + 1]) & 0x7fffffffu;
+                    atomicMax(&lmax[8 * half + l], m0 > m1 ? m0 : m1);
+                }
+            }
+        }
+        // ---- through the lookup (input gradient, re-gathered) and the clamp to d dx
+        const float2 xv = *reinterpret_cast<const float2*>(a.x + pt * 2), dxs = *reinterpret_cast<const float2*>(a.dx + pt * 2);
+        const float2 x01 = *reinterpret_cast<const float2*>(a.x01 + pt * 2);
+        const float pre[2] = {xv.x * a.shrink + dxs.x, xv.y * a.shrink + dxs.y};
+        const float xq[2] = {x01.x, x01.y};
+        float dxc[2];
+        gf::encode8_grad2(a.table, meta + 8 * half, 1u, 0u, xq, gg, dxc);
+        dxc[0] += __shfl_xor(dxc[0], 32);
+        dxc[1] += __shfl_xor(dxc[1], 32);
+        float ddx[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            ddx[i] = (pre[i] >= -1.0f && pre[i] <= 1.0f) ? 0.5f * dxc[i] : 0.0f;       // x01 = (clamp(x + dx, -1, 1) + 1) / 2
+            if (a.g_dx) ddx[i] += a.g_dx[pt * 2 + i];
+            if (!valid) ddx[i] = 0.0f;
+        }
+        if (valid && half == 0) *reinterpret_cast<float2*>(a.dz_d3 + pt * 2) = float2{ddx[0], ddx[1]};
+        // ---- deform net, back to front
+        float act2[32], dz2[32];
+        rows_load<2>(a.h_d2, pt, half, act2);
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 w0 = *reinterpret_cast<const float4*>(d3 + ob * 32 + half * 16 + 4 * q), w1 = *reinterpret_cast<const float4*>(d3 + 64 + ob * 32 + half * 16 + 4 * q);
+                const float v[4] = {__builtin_fmaf(ddx[1], w1.x, ddx[0] * w0.x), __builtin_fmaf(ddx[1], w1.y, ddx[0] * w0.y),
+                                    __builtin_fmaf(ddx[1], w1.z, ddx[0] * w0.z), __builtin_fmaf(ddx[1], w1.w, ddx[0] * w0.w)};
+#pragma unroll
+                for (int i = 0; i < 4; i++) dz2[ob * 16 + 4 * q + i] = act2[ob * 16 + 4 * q + i] > 0.0f ? v[i] : 0.0f;
+            }
+        if (valid) rows_store<2>(a.dz_d2, pt, half, dz2);
+        floatx16 h2[2];
+        gf::mfma_layer<2, 32, false, false>(bw + TBW_D2T, lane, dz2, nullptr, h2);
+        rows_load<2>(a.h_d1, pt, half, act2);
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dz2[ob * 16 + r] = act2[ob * 16 + r] > 0.0f ? h2[ob][r] : 0.0f;
+        if (valid) rows_store<2>(a.dz_d1, pt, half, dz2);
+    }
+    __syncthreads();
+    if (a.level_max && tid < 16 && lmax[tid]) atomicMax(&a.level_max[tid], lmax[tid]);
+}
+
 constexpr size_t kTorsoSmem = (gf::TP_TOTAL + gf::TB_TOTAL + 64) * sizeof(float);
 
 }  // namespace
@@ -387,6 +620,48 @@ GF_EXPORT int gf_torso_mask_list(const float* bg_coords, const float* torso_occ,
                        list, dense_of, count);
     return gf_check_launch("torso_mask_list");
 }
+
+// ---- training field (gf_torso_train_t): forward with saves, input-gradient chain
+static int torso_train_args(const gf_torso_train_t* t, TorsoTrainArgs& a, bool backward) {
+    if (!t) return gf_set_error(GF_ERR_INVALID, "torso_train: null descriptor");
+    if (!t->x || !t->torso_pack || !t->torso_table || !t->torso_offsets || !t->out || !t->dx || !t->h_d1 || !t->h_d2 || !t->x01 || !t->h_c1 || !t->h_c2)
+        return gf_set_error(GF_ERR_INVALID, "torso_train: null pointer");
+    if (!backward && (!t->torso_bias || !t->enc || !t->g)) return gf_set_error(GF_ERR_INVALID, "torso_train_forward: null pointer");
+    if (backward && (!t->bwd_streams || !t->g_out || !t->dz_c3 || !t->dz_c2 || !t->dz_c1 || !t->dz_d3 || !t->dz_d2 || !t->dz_d1 || !t->g_grid))
+        return gf_set_error(GF_ERR_INVALID, "torso_train_backward: null pointer");
+    a.M = t->M; a.shrink = t->torso_shrink; a.x = t->x;
+    a.pack = t->torso_pack; a.bias = t->torso_bias; a.table = t->torso_table; a.offsets = t->torso_offsets;
+    if (gf::fill_grid_levels(a.lv, 16, t->torso_S, t->base_res)) return gf_set_error(GF_ERR_INVALID, "torso_train: bad grid levels");
+    a.out = t->out; a.dx = t->dx; a.enc = t->enc; a.h_d1 = t->h_d1; a.h_d2 = t->h_d2; a.x01 = t->x01; a.g = t->g; a.h_c1 = t->h_c1; a.h_c2 = t->h_c2;
+    a.bwd = t->bwd_streams; a.g_out = t->g_out; a.g_dx = t->g_dx;
+    a.dz_c3 = t->dz_c3; a.dz_c2 = t->dz_c2; a.dz_c1 = t->dz_c1; a.dz_d3 = t->dz_d3; a.dz_d2 = t->dz_d2; a.dz_d1 = t->dz_d1; a.g_grid = t->g_grid;
+    a.level_max = t->level_max;
+    return GF_OK;
+}
+
+GF_EXPORT int gf_torso_train_forward(const gf_torso_train_t* t, void* stream) {
+    TorsoTrainArgs a = {};
+    if (const int e = torso_train_args(t, a, false)) return e;
+    if (a.M == 0) return GF_OK;
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_torso_train_fwd), (int)kTorsoSmem, "torso_train_forward")) return e;
+    const uint32_t wgs = gf_div_up(a.M, 128u);
+    hipLaunchKernelGGL(k_torso_train_fwd, dim3(wgs < 512u ? wgs : 512u), dim3(kThreads), kTorsoSmem, gf_stream(stream), a);
+    return gf_check_launch("torso_train_forward");
+}
+
+GF_EXPORT int gf_torso_train_backward(const gf_torso_train_t* t, void* stream) {
+    TorsoTrainArgs a = {};
+    if (const int e = torso_train_args(t, a, true)) return e;
+    if (a.M == 0) return GF_OK;
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_torso_train_bwd), (int)kTorsoBwdSmem, "torso_train_backward")) return e;
+    const uint32_t wgs = gf_div_up(a.M, 128u);
+    hipLaunchKernelGGL(k_torso_train_bwd, dim3(wgs < 512u ? wgs : 512u), dim3(kThreads), kTorsoBwdSmem, gf_stream(stream), a);
+    return gf_check_launch("torso_train_backward");
+}
+
+GF_EXPORT uint32_t gf_torso_bwd_stream_floats(void) { return TBW_TOTAL; }
 
 #ifdef GF_TRACE
 // trace build only: device buffer of 64 workgroups x 4 waves x 16 uint64 slots (tools/trace_torso.py)

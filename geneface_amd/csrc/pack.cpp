@@ -195,6 +195,28 @@ static int torso_pack_impl(const float* d0, uint32_t ld_d0, const float* d1, con
     return GF_OK;
 }
 
+// One hidden -> hidden weight matrix W [nob * 32][ld] as an A-operand stream (the layout of the second layers above): the training backward's
+// transposed blocks (frame_torso.hip, k_torso_train_bwd) are packed with it, one call each.
+GF_EXPORT int gf_mlp_stream_pack(const float* W, uint32_t ld, uint32_t nob, uint32_t nsteps, float* out) {
+    if (!W || !out || nob == 0 || nsteps == 0 || nsteps % 4) return gf_set_error(GF_ERR_INVALID, "mlp_stream_pack: bad argument");
+    for (uint32_t ob = 0; ob < nob; ob++)
+        for (uint32_t t = 0; t < nsteps; t++)
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t c = hidden_col(t, l >> 5);
+                out[((ob * (nsteps / 4) + t / 4) * 64 + l) * 4 + (t & 3u)] = c < ld ? W[(size_t)(ob * 32 + (l & 31u)) * ld + c] : 0.0f;
+            }
+    return GF_OK;
+}
+
+// Row p = c_row(r, h) of the transposed grid block must hold grid feature 16 h + r: then accumulator register r of lane half h is the gradient
+// of the lane's own level 8 h + r / 2, channel r & 1 -- the layout encode8_grad2 and the level-major gradient store want.
+GF_EXPORT int gf_torso_bwd_grid_row_perm(uint32_t* perm32) {
+    if (!perm32) return gf_set_error(GF_ERR_INVALID, "torso_bwd_grid_row_perm: null pointer");
+    for (uint32_t h = 0; h < 2; h++)
+        for (uint32_t r = 0; r < 16; r++) perm32[c_row(r, h)] = 16 * h + r;
+    return GF_OK;
+}
+
 GF_EXPORT int gf_torso_pack(const float* d0, const float* d1, const float* d2, const float* c0, const float* c1, const float* c2, float* out) {
     return torso_pack_impl(d0, 104, d1, d2, c0, 136, c1, c2, out);
 }

@@ -55,6 +55,11 @@ class RADNeRFTorso(RADNeRF):
 
     def forward_torso(self, x, poses, c=None, image=None, weights_sum=None):
         """x [m,2] in [-1,1], poses [1,6], c [8] -> alpha [m,1], colour [m,3], dx [m,2]."""
+        if self._fused_torso_train_ok(x, c, image):
+            # training (round 6): the whole field as ONE autograd node -- fused forward with saves, one-launch input-gradient chain
+            # (train_torso.py); ~180 launches of the op graph below become 2 + the six weight-gradient products
+            from .train_torso import forward_torso_fused
+            return forward_torso_fused(self, x, poses, c)
         m = x.shape[0]
         x = x * self.torso_shrink
         parts = [self.torso_deform_pos_embedder(x), self.torso_pose_embedder(poses).reshape(1, -1).expand(m, -1)]
@@ -70,6 +75,28 @@ class RADNeRFTorso(RADNeRF):
         xc = (x + dx).clamp(-1, 1).float()
         h = self.torso_canonicial_net(torch.cat([self.torso_embedder(xc, bound=1), h], dim=-1))
         return torch.sigmoid(h[..., :1]), torch.sigmoid(h[..., 1:]), dx
+
+    def _fused_torso_train_ok(self, x, c, image):
+        """Under autograd, on the GPU, default architecture, and only when the model has not been pinned to the op graph (`field_impl` /
+        `render_impl`, like RADNeRF.forward's fused head field)."""
+        if not (torch.is_grad_enabled() and x.is_cuda and c is not None and image is None and self.field_impl == "auto"
+                and self.render_impl in ("auto", "fused") and x.shape[0] > 0):
+            return False
+        if self._pick_impl("auto", False, 1) != "fused":
+            return False
+        from .train_torso import supported
+        return supported(self)
+
+    def _cond_feat_no_grad(self, cond):
+        """cal_cond_feat for a FROZEN head (the torso task: tasks/radnerfs/radnerf_torso.py:40-42): one HIP launch (gf_cond_encode) instead of
+        the ~30 launches of the conv / attention graph; the torch modules whenever the kernel does not cover the encoder or the window."""
+        if cond.is_cuda and cond.dim() == 3 and self.field_impl == "auto" and self.render_impl in ("auto", "fused") \
+                and self._pick_impl("auto", False, 1) == "fused":
+            from .fused import cond_encode_batch, get_state
+            r = cond_encode_batch(self, get_state(self), cond[None].float().contiguous())
+            if r is not None:
+                return r[0][0]
+        return self.cal_cond_feat(cond)
 
     def torso_mask(self, bg_coords):
         thresh = min(self.density_thresh_torso, self.mean_density_torso)
@@ -87,7 +114,7 @@ class RADNeRFTorso(RADNeRF):
             bg_coords = bg_coords.contiguous().view(-1, 2)
             N, device = rays_o.shape[0], rays_o.device
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
-            cond_feat = self.cal_cond_feat(cond)
+            cond_feat = self._cond_feat_no_grad(cond)
             ind_code = self.individual_embeddings[index] if self.individual_embedding_dim > 0 else None
             weights_sum, ambient_sum, depth, image = self._march_head_train(rays_o, rays_d, nears, fars, cond_feat, ind_code, dt_gamma, perturb,
                                                                             force_all_rays, max_steps)

@@ -326,6 +326,42 @@ int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, 
 int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
                                    uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                    const uint32_t* level_max, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Torso field for TRAINING (round 6): RADNeRFTorso.forward_torso (modules/radnerfs/radnerf_torso.py:51-84) on a list of M pixel coordinates
+ * as two launches -- forward with every layer's activations saved, and the input-gradient chain -- replacing the ~60 + ~120 torch launches
+ * of the op graph in the torso task's step (tasks/radnerfs/radnerf_torso.py:74-122; the default architecture, torso_head_aware = false).
+ * Same building blocks as gf_render_torso's field kernel (f32 MFMA, register-chained layers, the 2-D tiled grid lookup).
+ *   forward : x [M,2] = bg_coords of the masked pixels (shrunk inside, :57) -> out [M,4] = sigmoid(alpha, r, g, b), dx [M,2], and the saves:
+ *             enc [M,48] frequency encoding of x (42 entries + 6 zeros), h_d1 / h_d2 [M,64] deform net activations after ReLU, x01 [M,2] the
+ *             clamped canonical coordinate mapped to [0,1] (what the grid encoder was evaluated at), g [M,32] its grid features,
+ *             h_c1 / h_c2 [M,32] canonical net activations after ReLU.  torso_pack / torso_bias as gf_frame_t's.
+ *   backward: g_out [M,4], g_dx [M,2] or NULL in; pre-activation gradients out: dz_c3 [M,4], dz_c2 / dz_c1 [M,32], dz_d3 [M,2] (the total
+ *             gradient of dx: through the grid lookup's input gradient and the clamp, plus g_dx), dz_d2 / dz_d1 [M,64], the grid feature
+ *             gradient g_grid [16 levels][M][2] (the layout gf_grid_encode_backward_scaled reads) and its per-level max |g| (level_max [16],
+ *             ZEROED by the caller).  Weight gradients are tall products of these with the saves (host side, geneface_amd/train_torso.py).
+ *             bwd_streams: gf_torso_bwd_stream_floats() floats = the transposed blocks W_c2^T | W_c1[:, grid columns]^T (rows in the lane
+ *             order of the lookup: gf_torso_bwd_grid_row_perm) | W_d2^T as A-operand streams (gf_mlp_stream_pack).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gf_torso_train {
+    uint32_t M; float torso_shrink; float torso_S; uint32_t base_res;
+    const float* x;                                  /* [M,2] */
+    const float* torso_pack; const float* torso_bias; const float* torso_table; const int32_t* torso_offsets;
+    float* out; float* dx;                           /* [M,4], [M,2]: written by the forward, read by the backward */
+    float* enc; float* h_d1; float* h_d2; float* x01; float* g; float* h_c1; float* h_c2;   /* saves (forward out, backward in: h_*, x01) */
+    /* backward only */
+    const float* bwd_streams; const float* g_out; const float* g_dx;
+    float* dz_c3; float* dz_c2; float* dz_c1; float* dz_d3; float* dz_d2; float* dz_d1; float* g_grid; uint32_t* level_max;
+} gf_torso_train_t;
+int gf_torso_train_forward(const gf_torso_train_t* t, void* stream);
+int gf_torso_train_backward(const gf_torso_train_t* t, void* stream);
+uint32_t gf_torso_bwd_stream_floats(void);
+/* HOST: one weight matrix W [nob*32 rows][ld] as an MFMA A-operand stream [ob][step/4][lane][step%4] whose step t consumes the hidden feature
+ * of accumulator position t (hidden -> hidden layers: the layout of gf_torso_pack's second layers); out [nob * nsteps * 64] floats */
+int gf_mlp_stream_pack(const float* W_host, uint32_t ld, uint32_t nob, uint32_t nsteps, float* out_host);
+/* HOST: perm[32]: row p of the transposed grid block W_c1[:, 0:32]^T handed to gf_mlp_stream_pack must be grid feature perm[p], so that a
+ * lane's accumulator registers hold the gradients of ITS eight levels (16 half + r) */
+int gf_torso_bwd_grid_row_perm(uint32_t* perm32_host);
+
 uint64_t gf_grid_update_ws_bytes(uint32_t C, uint32_t H);
 int gf_grid_update(float* density_grid, const float* tmp_grid, uint32_t C, uint32_t H, float decay, float density_thresh,
                    uint8_t* bitfield, void* partial_ws, float* stats_dev, void* stream);

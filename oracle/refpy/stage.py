@@ -40,10 +40,14 @@ def staged() -> bool:
 
 def _files(ref_root):
     out = []
-    for d, _, names in os.walk(os.path.join(ref_root, "modules", "radnerfs")):
-        for n in sorted(names):
-            if n.endswith(".py") and n not in SKIP:
-                out.append(os.path.relpath(os.path.join(d, n), ref_root))
+    # modules/nerfs (round 6): the legacy pure-PyTorch renderer -- Lm3dNeRF + render_dynamic_face, baseline B2 of BASELINE.md section 3 --
+    # so that bench.py's `cpu_baseline.legacy_nerf` times the reference's OWN module on the GPU box's host cores (kind "reference") instead of
+    # the restatement oracle/legacy_nerf_ref.py (kind "port")
+    for sub in ("radnerfs", "nerfs"):
+        for d, _, names in os.walk(os.path.join(ref_root, "modules", sub)):
+            for n in sorted(names):
+                if n.endswith(".py") and n not in SKIP:
+                    out.append(os.path.relpath(os.path.join(d, n), ref_root))
     return sorted(out) + EXTRA
 
 

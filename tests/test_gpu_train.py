@@ -370,3 +370,38 @@ def test_non_finite_gradients_reach_the_tables(bad):
     ws[77] = bad
     ((s_ * ws).sum() + c_.sum() + a_.sum()).backward()
     assert not torch.isfinite(m.position_embedder.embeddings.grad).all()
+
+
+# ----------------------------------------------------------------------------------------------- fused torso training field (round 6)
+@pytest.mark.parametrize("M", [1, 37, 4096 + 77])
+def test_fused_torso_field_vs_op_graph(M):
+    """forward_torso as ONE autograd node (train_torso.py: gf_torso_train_forward / _backward) against the same module's torch op graph on the
+    same pixels: outputs, and the gradients of every torso parameter (grid table, six Linear weights, identity code) for a loss that
+    touches alpha, colour AND the deformation (the reference returns `deform`; a regulariser on it must reach the deform net too).
+    fp32 on both sides; what differs is summation order (MFMA k-order vs rocBLAS) and the fused sine of the encodings (<= 9.3e-8 abs)."""
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp, sd = model_fixture(True)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(M, 2, device=DEV, generator=g) * 2.4 - 1.2          # some pixels beyond the picture: the clamp's zero-gradient branch
+    pose = torch.tensor([[0.1, -0.2, 0.05, 0.3, -0.1, 3.2]], device=DEV)
+    wa, wc, wd = torch.rand(M, 1, device=DEV, generator=g), torch.rand(M, 3, device=DEV, generator=g), torch.rand(M, 2, device=DEV, generator=g)
+    names = [n for n, _ in model.named_parameters() if "torso" in n]
+    res = {}
+    for impl in ("auto", "ops"):
+        model.field_impl = impl
+        model.zero_grad(set_to_none=True)
+        code = model.torso_individual_codes[0]
+        assert model._fused_torso_train_ok(x, code, None) == (impl == "auto")
+        a, c, dx = model.forward_torso(x, pose, code)
+        ((a * wa).sum() + (c * wc).sum() + 0.3 * (dx * wd).sum()).backward()
+        res[impl] = ([t.detach().clone() for t in (a, c, dx)], {n: p.grad.detach().clone() for n, p in model.named_parameters() if n in names and p.grad is not None})
+    for u, v, tol in zip(res["auto"][0], res["ops"][0], (2e-6, 2e-6, 2e-6)):
+        assert u.shape == v.shape and float((u - v).abs().max()) < tol, float((u - v).abs().max())
+    assert set(res["auto"][1]) == set(res["ops"][1]) and len(res["ops"][1]) >= 8, sorted(res["ops"][1])
+    for n, gr in res["ops"][1].items():
+        d = (res["auto"][1][n] - gr).double()
+        l2 = float(d.norm() / gr.double().norm().clamp(min=1e-20))
+        assert l2 < 2e-4, (n, l2)         # measured 1e-6 .. 3e-5

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
                     "only torso parameters in the optimizer (networks at lr, the 2-D grid at 10 lr), mse on rgb_map + the alpha entropy term, "
                     "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
+    ap.add_argument("--op-graph", action="store_true", help="--torso: pin the torso field to the torch op graph (RADNeRFTorso.field_impl = 'ops' for the torso "
+                    "field only: the tree before round 6's fused node), for same-box before / after")
     args = ap.parse_args()
     if args.torso:
         return main_torso(args)
@@ -98,6 +100,9 @@ def main_torso(args):
     model = RADNeRFTorso(hp)
     model.load_state_dict(S.make_state_dict(hp, True), strict=True)
     model = model.to(dev).train()
+    if args.op_graph:      # the torso field and the frozen head's condition encoder as round 5 ran them (the head's own fused field stays)
+        model._fused_torso_train_ok = lambda *a, **k: False
+        model._cond_feat_no_grad = model.cal_cond_feat
     seq = S.make_sequence(8, 512, 512, hp)
     poses = torch.from_numpy(seq["poses"]).to(dev)
     cond = torch.from_numpy(seq["cond_wins"]).to(dev)
