@@ -125,13 +125,16 @@ class RADNeRFTorso(RADNeRF):
         mask = self.torso_mask(bg_coords)
         torso_alpha = torch.zeros([N, 1], device=device)
         torso_color = torch.zeros([N, 3], device=device)
-        if mask.any():
+        # the masked pixels' indices ONCE (one compaction, one host sync): `t[mask]` / `t[mask] = v` each run their own nonzero() -- three
+        # compactions and three syncs per step for the reference's three boolean-mask statements (radnerf_torso.py:174-184); same values
+        sel = mask.nonzero(as_tuple=True)[0]
+        if sel.numel() > 0:
             if self.torso_head_aware and random.random() < 0.5:
-                a, c, deform = self.forward_torso(bg_coords[mask], poses, code, image[mask], weights_sum.unsqueeze(-1)[mask])
+                a, c, deform = self.forward_torso(bg_coords[sel], poses, code, image[sel], weights_sum.unsqueeze(-1)[sel])
             else:
-                a, c, deform = self.forward_torso(bg_coords[mask], poses, code)
-            torso_alpha[mask] = a.float()
-            torso_color[mask] = c.float()
+                a, c, deform = self.forward_torso(bg_coords[sel], poses, code)
+            torso_alpha = torso_alpha.index_copy(0, sel, a.float())
+            torso_color = torso_color.index_copy(0, sel, c.float())
             results["deform"] = deform
         bg_color = torso_color * torso_alpha + bg_color * (1 - torso_alpha)
         results["torso_alpha_map"] = torso_alpha
@@ -199,6 +202,11 @@ class RADNeRFTorso(RADNeRF):
         elif ind_code is None and self.torso_individual_embedding_dim > 0:
             ind_code = self.torso_individual_codes[0]
         G = self.grid_size
+        fused_query = False
+        if dev.type == "cuda" and ind_code is not None and self.field_impl == "auto" and self.render_impl in ("auto", "fused") \
+                and self._pick_impl("auto", False, 1) == "fused":
+            from .train_torso import supported, torso_field_no_grad
+            fused_query = supported(self)
         tmp = torch.zeros_like(self.density_grid_torso)
         X = torch.arange(G, dtype=torch.int32, device=dev).split(S)
         half_grid_size = 1 / G
@@ -210,7 +218,10 @@ class RADNeRFTorso(RADNeRF):
                 xys = (2 * coords.float() / (G - 1) - 1) * (1 - half_grid_size)
                 noise = _rand_like(xys, generator)
                 xys = xys + (noise * 2 - 1) * half_grid_size
-                alphas, _, _ = self.forward_torso(xys, pose6.to(dev), ind_code)
+                if fused_query:       # one launch (train_torso.torso_field_no_grad) instead of the ~60 of the op graph
+                    alphas, _, _ = torso_field_no_grad(self, xys, pose6.to(dev), ind_code)
+                else:
+                    alphas, _, _ = self.forward_torso(xys, pose6.to(dev), ind_code)
                 tmp[indices] = alphas.squeeze(1).float()
         tmp = torch.nn.functional.max_pool2d(tmp.view(1, 1, G, G), kernel_size=5, stride=1, padding=2).view(-1)
         self.density_grid_torso = torch.maximum(self.density_grid_torso * decay, tmp)

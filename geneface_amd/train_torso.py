@@ -145,6 +145,21 @@ class _TorsoField(torch.autograd.Function):
                 cast(g_wc2, wc2), cast(g_wc3, wc3))
 
 
+def torso_field_no_grad(model, x, poses, code):
+    """The same one-launch forward WITHOUT autograd (update_extra_state's query of the field on the 128 x 128 jittered cell centres,
+    radnerf_torso.py:225-232): alpha [M,1], colour [M,3], dx [M,2].  The activations go to scratch buffers nobody reads."""
+    with torch.no_grad():
+        d, c = model.torso_deform_net.net, model.torso_canonicial_net.net
+        return _TorsoField.forward(_NoCtx(), model, x, poses, code, model.torso_embedder.embeddings, d[0].weight, d[1].weight, d[2].weight, c[0].weight,
+                                   c[1].weight, c[2].weight)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when the forward runs outside autograd."""
+    def save_for_backward(self, *a):
+        pass
+
+
 def forward_torso_fused(model, x, poses, code):
     """forward_torso (radnerf_torso.py:51-84) through the fused node: x [M,2], poses [1,6], code [8] -> alpha [M,1], colour [M,3], dx [M,2]."""
     d, c = model.torso_deform_net.net, model.torso_canonicial_net.net
