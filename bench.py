@@ -794,7 +794,10 @@ def compact_line(full, details_path):
     if isinstance(tr, dict):
         line["train_step"] = {"ms_per_step": _r(tr.get("ms_per_step"), 3), "steps_per_s": _r(tr.get("steps_per_s"), 2),
                               "reference_kernels_ms_per_step": _r((tr.get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2),
-                              "speedup_vs_reference_kernels": _r(tr.get("speedup_vs_reference_kernels"), 2), "error": tr.get("error")}
+                              "speedup_vs_reference_kernels": _r(tr.get("speedup_vs_reference_kernels"), 2), "error": tr.get("error"),
+                              "roofline_frac": _r((tr.get("roofline") or {}).get("frac"), 3),
+                              "torso_ms_per_step": _r((tr.get("torso") or {}).get("ms_per_step"), 3),
+                              "torso_reference_kernels_ms_per_step": _r(((tr.get("torso") or {}).get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2)}
     pr = full.get("per_rank")
     if isinstance(pr, dict):
         pf = pr.get("parity_first_frame")
@@ -999,9 +1002,9 @@ def train_step_leg(args, job):
     test infrastructure, only when present), and the parity of ONE step's gradients against the oracle's autograd on the CPU."""
     import subprocess
 
-    def run(script):
+    def run(script, *extra):
         try:
-            r = subprocess.run([sys.executable, script, "--steps", "48", "--warmup", "16"], capture_output=True, text=True, timeout=420)
+            r = subprocess.run([sys.executable, script, "--steps", "48", "--warmup", "16", *extra], capture_output=True, text=True, timeout=420)
         except subprocess.TimeoutExpired:
             return {"error": "timeout"}
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1020,6 +1023,24 @@ def train_step_leg(args, job):
                                                            "reference's structure (the field as a torch op graph over its encoders, block-wise density-grid refresh)"}
         if refk.get("ms_per_step") and prod.get("ms_per_step"):
             out["speedup_vs_reference_kernels"] = refk["ms_per_step"] / prod["ms_per_step"]
+    # what the step's arithmetic is worth against the matrix pipe (round 6): forward + input-gradient chain + weight gradients = 3 x the
+    # field's algorithmic FLOPs per evaluated point (SURVEY 8d's 178 688), over the whole step's time -- marcher, compositor, table scatter,
+    # Adam and the harness included, so this is a floor for the kernels' own rate
+    if prod.get("ms_per_step") and prod.get("points_last_step"):
+        tf = 3 * FLOP_PER_HEAD_SAMPLE * prod["points_last_step"] / (prod["ms_per_step"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "dtype": "f32", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                           "flop_per_step": 3 * FLOP_PER_HEAD_SAMPLE * prod["points_last_step"],
+                           "note": "3 x 178 688 FLOP per evaluated point (forward, dX chain, dW products) / the WHOLE step's time"}
+    # the TORSO task's step (tasks/radnerfs/radnerf_torso.py:74-122: head frozen, torso field trained; round 6: the field as one autograd node)
+    tor = run(os.path.join(ROOT, "tools", "bench_train.py"), "--torso")
+    out["torso"] = {"ms_per_step": tor.get("ms_per_step"), "steps_per_s": tor.get("value"), "workload": tor.get("metric"), "error": tor.get("error"),
+                    "masked_pixels_last_step": tor.get("masked_pixels_last_step"), "head_points_last_step": tor.get("head_points_last_step"),
+                    "note": "the step is bound by the host's launch rate (~200 launches of which the field is 2 + 6 products): see NOTES 10"}
+    if ref_kernels.available("fast"):
+        tref = run(os.path.join(ROOT, "tests", "train_rate_reference.py"), "--torso")
+        out["torso"]["reference_kernels_same_host_code"] = {"ms_per_step": tref.get("ms_per_step"), "error": tref.get("error")}
+        if tref.get("ms_per_step") and tor.get("ms_per_step"):
+            out["torso"]["speedup_vs_reference_kernels"] = tref["ms_per_step"] / tor["ms_per_step"]
     if not args.no_cpu_baseline:
         out["gradient_parity"] = train_gradient_parity(job)
     return out

@@ -238,3 +238,153 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
         # and the trained student does look like the teacher now (it is a 300-step fit, not a converged one: a loose bar)
         assert float(((out - targets[i].cpu()) ** 2).mean()) < 2.0 * np.mean(losses[-16:]) + 1e-3
     print(f"closed loop: mse {np.mean(losses[:16]):.4g} -> {np.mean(losses[-16:]):.4g} (x{fall:.3f}); trained-weights parity {worst:.3g}")
+
+
+# ----------------------------------------------------------------------------------------------- the torso stage (round 6)
+TORSO_STEPS = 160
+
+
+def _torso_fixture(hp):
+    """Teacher = the synthetic identity's head + torso (seed 0); student = the SAME head (the torso task loads the trained head and freezes
+    it: tasks/radnerfs/radnerf_torso.py:30-42) with another seed's torso field and an empty torso occupancy."""
+    from geneface_amd import synthetic as S
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    sd_t = S.make_state_dict(hp, True, seed=0)
+    teacher = RADNeRFTorso(hp)
+    teacher.load_state_dict(sd_t, strict=True)
+    teacher = teacher.to(DEV).eval()
+    sd_s = dict(sd_t)
+    other = S.make_state_dict(hp, True, seed=5)
+    for k in sd_s:
+        if "torso" in k:
+            sd_s[k] = other[k]
+    return teacher, sd_s
+
+
+def _train_torso(model, hp, seq, poses, pose6, cond, bg, bgc, targets, steps, n_rays=8192):
+    """The torso task's step (tasks/radnerfs/radnerf_torso.py:50-66, 74-122): torso occupancy refresh every 16 steps, render in training mode
+    (head under no_grad), mse on rgb_map + the alpha entropy term, Adam over the torso networks (lr) and the torso grid (10 lr) only."""
+    import random
+    from geneface_amd import utils
+    torch.manual_seed(21)
+    random.seed(21)
+    gen = torch.Generator(device=DEV).manual_seed(22)
+    model.poses = poses
+    emb = [p for k, p in model.named_parameters() if "torso_embedder" in k]
+    net = [p for k, p in model.named_parameters() if "torso_embedder" not in k and "torso" in k]
+    for k, p in model.named_parameters():
+        p.requires_grad_("torso" in k)
+    opt = torch.optim.Adam(net, lr=5e-4, betas=(0.9, 0.99), eps=1e-15)
+    opt.add_param_group({"params": emb, "lr": 5e-3, "betas": (0.9, 0.99), "eps": 1e-15})
+    losses = []
+    for i in range(steps):
+        if i % hp["update_extra_interval"] == 0:
+            model.update_extra_state(pose6=pose6[i % T:i % T + 1], generator=gen)
+        f = i % T
+        rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], SIZE, SIZE, n_rays)
+        sel = rays["inds"][0]
+        out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], pose6[f:f + 1], index=0, bg_color=bg[:, sel], perturb=True,
+                           force_all_rays=False, **hp)
+        mse = ((out["rgb_map"] - targets[f:f + 1, sel]) ** 2).mean()
+        alphas = out["torso_alpha_map"].clamp(1e-5, 1 - 1e-5)
+        loss = mse + 1e-3 * torch.mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas))
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(mse))
+    model.update_extra_state(pose6=pose6[:1], generator=gen)
+    return losses, opt
+
+
+def test_torso_stage_frozen_head_train_checkpoint_reload_render(tmp_path):
+    """The second half of the reference's training recipe (docs/train_models/train_models.md:93: ~4 of its ~10 hours) as a closed loop: a
+    teacher head + torso renders the target frames; a student with the teacher's (frozen) head and another torso field trains TORSO_STEPS
+    steps through the product's training branch -- the torso field as ONE autograd node (train_torso.py), the frozen head's condition encoder
+    and field in one launch each -- ; the same loop with the torso field pinned to the torch op graph follows the same curve; the checkpoint
+    is written in the Trainer's layout, reloaded through the entry point (head_model_dir + work_dir, as RADNeRFTorsoTask.build_model) and
+    the fused renderer agrees with the oracle on the TRAINED weights to the strict 1e-4."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd import utils
+    from geneface_amd.infer import FramePipeline
+    from geneface_amd.lm3d_radnerf_infer import LM3d_RADNeRFInfer, RADNeRFPoseSource
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    hp = HP.may_hparams(True)
+    seq = S.make_sequence(T, SIZE, SIZE, hp)
+    teacher, sd_student = _torso_fixture(hp)
+    poses = torch.from_numpy(seq["poses"]).to(DEV)
+    pose6 = utils.convert_poses(poses)
+    cond = torch.from_numpy(seq["cond_wins"]).to(DEV)
+    bg = torch.from_numpy(seq["bg_img"]).to(DEV).view(1, -1, 3)
+    bgc = utils.get_bg_coords(SIZE, SIZE, DEV)
+    tg = []
+    with torch.no_grad():
+        for f in range(T):
+            rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], SIZE, SIZE, -1)
+            tg.append(teacher.render(rays["rays_o"], rays["rays_d"], cond[f], bgc, pose6[f:f + 1], index=0, bg_color=bg, perturb=False,
+                                     force_all_rays=True, **hp)["rgb_map"].reshape(1, -1, 3).clone())
+    targets = torch.cat(tg)
+
+    def student():
+        m = RADNeRFTorso(hp)
+        m.load_state_dict(sd_student, strict=True)
+        m = m.to(DEV).train()
+        m.density_grid_torso.zero_()
+        m.mean_density_torso = 0
+        return m
+    model = student()
+    assert model._fused_torso_train_ok(bgc.view(-1, 2)[:64], model.torso_individual_codes[0], None)
+    head0 = {k: v.detach().clone() for k, v in model.state_dict().items() if "torso" not in k}
+    torso0 = {k: v.detach().clone() for k, v in model.state_dict().items() if "torso" in k and v.is_floating_point()}
+    losses, opt = _train_torso(model, hp, seq, poses, pose6, cond, bg, bgc, targets, TORSO_STEPS)
+    assert all(np.isfinite(losses))
+    fall = float(np.mean(losses[-16:]) / np.mean(losses[:8]))
+    assert fall < 0.5, f"the torso did not learn: mse {np.mean(losses[:8]):.4g} -> x{fall:.3g}"
+    for k, v in model.state_dict().items():          # the head is frozen: bit for bit what was loaded
+        if k in head0:
+            assert torch.equal(v, head0[k]), k
+    moved = sum(int(not torch.equal(torso0[k], model.state_dict()[k])) for k in torso0)
+    assert moved >= 8 and float(model.density_grid_torso.max()) > 0, moved
+    # the same loop over the torch op graph of the torso field (what round 5 ran): the two curves agree over the first 32 steps, where the
+    # chaos of two Adam runs has had no time to act, and both fall
+    ref_model = student()
+    ref_model._fused_torso_train_ok = lambda *a, **k: False
+    ref_losses, _ = _train_torso(ref_model, hp, seq, poses, pose6, cond, bg, bgc, targets, 48)
+    assert abs(losses[0] / ref_losses[0] - 1.0) < 1e-3, (losses[0], ref_losses[0])
+    assert abs(np.mean(losses[:32]) / np.mean(ref_losses[:32]) - 1.0) < 0.10, (np.mean(losses[:32]), np.mean(ref_losses[:32]))
+    record = {"steps": TORSO_STEPS, "fused_field": {"mse": losses, "fall": fall}, "op_graph_first_48": ref_losses}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "closed_loop_torso_loss_curves.json"), "w") as f:
+            json.dump(record, f)
+
+    # ---- checkpoints in the Trainer's layout: the head's in head_model_dir, the torso task's in work_dir -> the entry point's build_model
+    head_dir, work_dir = str(tmp_path / "checkpoints" / "May" / "lm3d_radnerf"), str(tmp_path / "checkpoints" / "May" / "lm3d_radnerf_torso")
+    from geneface_amd.radnerf import RADNeRF
+    head = RADNeRF(HP.may_hparams(False))
+    head.load_state_dict({k: v for k, v in model.state_dict().items() if k in head.state_dict()}, strict=True)
+    _save_trainer_checkpoint(os.path.join(head_dir, "model_ckpt_steps_250000.ckpt"), head, torch.optim.Adam(head.parameters()), 250000)
+    _save_trainer_checkpoint(os.path.join(work_dir, f"model_ckpt_steps_{TORSO_STEPS}.ckpt"), model, opt, TORSO_STEPS)
+    dd, _ = S.make_dataset_dict(T=T + 2, H=SIZE, W=SIZE)
+    hp_inf = dict(hp, work_dir=work_dir, head_model_dir=head_dir)
+    inf = LM3d_RADNeRFInfer(hp_inf, dataset=RADNeRFPoseSource(dd, hp_inf), device=DEV)
+    assert inf.global_step == TORSO_STEPS and isinstance(inf.model, RADNeRFTorso)
+    loaded = inf.model.to(DEV).eval()
+    sd_trained = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, v in loaded.state_dict().items():
+        assert torch.equal(v.cpu(), sd_trained[k]), k
+    assert loaded.mean_density_torso == 0           # not in the state dict: a freshly loaded model thresholds its torso mask at 0 (radnerf_torso.py:27), the oracle too
+    assert loaded._pick_impl("auto", False, hp["max_steps"]) == "fused"
+    pipe = FramePipeline(loaded, hp, seq, DEV, impl="fused")
+    oracle_threads(16)
+    worst = 0.0
+    for i in (1, 5):
+        with torch.no_grad():
+            smp = pipe.sample(i)
+            out = pipe.run_model(smp)
+            host = {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in smp.items()}
+            ref = R.render(sd_trained, hp, host["rays_o"], host["rays_d"], host["cond_wins"], host["bg_coords"], host["pose"], host["bg_img"], torso=True)
+        err = float((out["rgb_map"].reshape(-1, 3).cpu() - ref["rgb_map"].reshape(-1, 3)).abs().max())
+        worst = max(worst, err)
+        assert err < 1e-4, f"frame {i}: max|d rgb| {err:.3g} on the trained torso"
+    print(f"torso stage: mse {np.mean(losses[:8]):.4g} -> {np.mean(losses[-16:]):.4g} (x{fall:.3f}); trained-weights parity {worst:.3g}")
