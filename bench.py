@@ -754,6 +754,11 @@ def compact_line(full, details_path):
             rr["pipelined"] = {"achieved": _r(r["pipelined"]["achieved"]), "frac": _r(r["pipelined"]["frac"])}
         if isinstance(r.get("mfma"), dict):
             rr["mfma"] = {k: _r(v) for k, v in r["mfma"].items() if k != "note"}
+        if isinstance(r.get("issue_roofline"), dict):
+            ir = r["issue_roofline"]
+            rr["issue_roofline"] = {"bound": ir["bound"].split(" (")[0], "cycles_min_per_simd": _r(ir["cycles_min_per_simd"], 0), "time_min_ms": _r(ir["time_min_ms"]),
+                                    "measured_ms": _r(ir["measured_ms"]), "frac": _r(ir["frac"]), "valu_per_mfma": _r(ir["valu_per_mfma"], 2),
+                                    "source": ir["source"], "stale": ir["stale"]}
         m = r.get("marcher")
         if isinstance(m, dict):
             rr["marcher"] = {"kernel": "k_frame_init", "ms": _r(m.get("ms")), "achieved": _r(m.get("achieved")), "peak": m.get("peak"), "unit": m.get("unit"),
@@ -783,6 +788,8 @@ def compact_line(full, details_path):
     small("split_tier", ("value", "unit", "ms_per_step", "frames_in_flight", "kernel_ms_per_frame"))
     if isinstance(full.get("split_tier"), dict) and isinstance(full["split_tier"].get("mfma"), dict):
         line["split_tier"]["mfma_frac"] = _r(full["split_tier"]["mfma"]["frac"])
+    if isinstance(full.get("split_tier"), dict) and isinstance(full["split_tier"].get("issue_roofline"), dict):
+        line["split_tier"]["valu_issue_frac"] = _r(full["split_tier"]["issue_roofline"]["frac"])
     small("stress_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
     small("heavy_fixture", ("value", "samples_per_frame", "roofline_frac", "kernel_ms_per_frame", "tile_fill"))
     small("head_only", ("value", "ms_per_step"))
@@ -968,7 +975,7 @@ def split_tier_leg(args, job, hp, torso, seq, sd, parity_frames, cache):
         r = measure_roofline(pipe, args.impl, args.warmup, min(4, args.steps), precision="split")
     return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": dt / args.steps * 1e3, "repeats": len(dts), "frames_in_flight": pipe.in_flight,
             "host_enqueue_ms_per_step": getattr(timed_loop, "host_enqueue_ms_per_step", None),
-            "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "mfma": r.get("mfma"), "parity": parity,
+            "kernel_ms_per_frame": r.get("kernel_ms_per_frame"), "mfma": r.get("mfma"), "issue_roofline": r.get("issue_roofline"), "parity": parity,
             "dtype": "f32 values as two-term f16 splits (hi + lo' * 2^-11), three v_mfma_f32_32x32x16_f16 per product term set, f32 accumulate",
             "note": "opt-in (model.render_precision = 'split'): strict tolerance, not fp32 bit patterns; the headline `value` is the exact-fp32 tier"}
 
@@ -1248,6 +1255,36 @@ def pmc_traffic():
     return None, None, None
 
 
+def issue_roofline(precision, avg_launch_ms, samples_per_frame=None):
+    """The instruction-issue bound of k_head_phase (round 6): the kernel's instruction mix per launch from the SQ counters
+    (committed: profiles/round*/r*_issue_roofline.json, tools/issue_roofline.py) priced with the issue costs tools/shadow_probe.hip measured on
+    the MI355X -- 5 cycles of vector issue per wave64 VALU; the f32 MFMA (64 cycles) does NOT overlap with VALU work, so the exact tier's bound
+    is their SUM; the f16 MFMA (32 cycles) runs beside up to 6.4 VALU, so the f16 tiers (10 / 23 VALU per MFMA) are VALU-issue bound -- against
+    this run's live launch time.  cycles at the nominal 2.4 GHz the MFMA roofline is priced at.  `stale`: the mix was counted on other sources."""
+    import glob
+    import re
+    key = {"fp32": "fp32", "split": "split", "fast": "fast"}.get(precision)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*issue_roofline.json")),
+                   key=lambda q: (int((re.search(r"round(\d+)", q) or [0, -1])[1]), os.path.basename(q)))
+    if not files or not avg_launch_ms or key is None:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        t = doc[key]
+        from geneface_amd.csrc.build import source_digest
+        stale = doc.get("_source_digest") != source_digest()
+    except Exception:      # noqa: BLE001
+        return None
+    cyc = t["cycles_min_per_simd"]
+    if samples_per_frame and doc.get("samples_per_frame"):      # another fixture: the mix scales with the evaluated samples
+        cyc *= samples_per_frame / doc["samples_per_frame"]
+    t_min_ms = cyc / 2.4e9 * 1e3
+    return {"bound": t["bound"], "cycles_min_per_simd": cyc, "time_min_ms": t_min_ms, "measured_ms": avg_launch_ms, "frac": t_min_ms / avg_launch_ms,
+            "valu_per_mfma": t["valu_per_mfma"], "instructions_per_launch": t["instructions_per_launch"], "source": os.path.relpath(files[-1], ROOT),
+            "stale": stale, "frac_at_measured_clock_in_the_counter_pass": t["counter_pass"]["frac_at_measured_clock"],
+            "samples_per_frame_of_the_mix": doc.get("samples_per_frame")}
+
+
 def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
     """Dominant-kernel roofline from live HIP-event timing of that kernel's launches (outside the fps region)."""
     if impl == "fused":
@@ -1274,10 +1311,16 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
             # the f16-operand kernels keep the matrix pipe busy for 5-15 % of a round: they are bound by the table gathers (TA issue + L2
             # latency; the tables are L2 / Infinity-Cache resident, so neither the MFMA nor the HBM peak prices them).  Report the algorithmic
             # gather rate; the guide gives no L2 gather peak to divide by, so no fraction is claimed for these secondary lines.
+            # Round 6: they are bound by VECTOR INSTRUCTION ISSUE (10 / 23 VALU per MFMA against the 6.4 a SIMD can issue beside one f16 MFMA:
+            # tools/shadow_probe.hip), so the roofline of these lines is the VALU issue rate: wave-instructions per second and SIMD against
+            # 2.4 GHz / 5 cycles (issue_roofline).
             ms = r["kernel_ms_per_frame"]
-            r.update({"bound": "l2-gather", "unit": "GB/s", "peak": None, "frac": None, "mfma_tflops_f32_equivalent": r["achieved"],
-                      "achieved": spf * BYTES_PER_HEAD_SAMPLE / (ms * 1e-3) / 1e9 if ms else None,
-                      "traffic": None, "note": "f16-operand tier: gather bound; algorithmic table bytes per second, no peak claimed"})
+            ir = issue_roofline(precision, r.get("avg_launch_ms"), spf)
+            r.update({"bound": "valu-issue", "unit": "G wave-instructions/s per SIMD", "mfma_tflops_f32_equivalent": r["achieved"],
+                      "gather_GBps": spf * BYTES_PER_HEAD_SAMPLE / (ms * 1e-3) / 1e9 if ms else None,
+                      "achieved": (ir["instructions_per_launch"]["VALU"] * (spf / (ir.get("samples_per_frame_of_the_mix") or spf)) / 1024 / (r["avg_launch_ms"] * 1e-3) / 1e9) if ir else None,
+                      "peak": 2.4 / 5.0, "frac": ir["frac"] if ir else None,
+                      "traffic": None, "note": "f16-operand tier: neither HBM nor the matrix pipe binds; vector instruction issue does (issue_roofline)"})
             for k in ("frac_composited", "mfma_executed_frac"):
                 r.pop(k, None)
             if precision == "split":
@@ -1289,6 +1332,7 @@ def measure_roofline(pipe, impl, first, n_frames, peak=None, precision="fp32"):
                                      "f32 <-> split conversions, march / composite and barriers (profiles/round4/r4e_head_timeline_split.txt)"}
             return r
         r["traffic"], r["traffic_source"], r["traffic_stale"] = pmc_traffic()
+        r["issue_roofline"] = issue_roofline(precision, r.get("avg_launch_ms"), spf)
         return r
     # impl == "ops": the dominant kernel is whichever rocBLAS SGEMM torch dispatches; it is not ours to time per launch.
     return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,

@@ -820,7 +820,44 @@ __device__ __forceinline__ void store16h(_Float16* dst, const float (&f)[16]) {
     }
 }
 
-__device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane) {
+// Training forward on the f16 tier (round 6, gf_field_forward_train16): what the backward pass needs of every layer as binary16 [M, width]
+// matrices -- the values the MFMAs consumed, i.e. the activations the reference's autocast run keeps -- plus the ReLU masks (same layout as
+// the fp32 SaveBufs).
+struct SaveBufs16 {
+    _Float16 *f3, *ha1, *ha2, *f2, *hs1, *hs2, *geo, *hc1, *sh;   // [M,32] [M,128] [M,128] [M,32] [M,128] [M,128] [M,128] [M,128] [M,16]
+    uint16_t *m_ha1, *m_ha2, *m_hs1, *m_hs2, *m_hc1;
+};
+
+template <bool RELU>
+__device__ __forceinline__ void obw16_save(_Float16* __restrict__ G, uint32_t gbase, uint32_t Mv, int wave, int lane, const floatx16 (&acc)[4], int nt,
+                                           uint16_t* __restrict__ mask = nullptr) {
+    const int half = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t < nt) {
+            if (mask) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) bits |= (acc[t][r] > 0.0f ? 1u : 0u) << r;
+                mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane] = (uint16_t)bits;
+            }
+            if ((uint32_t)(t * 32 + j) < Mv) {
+                _Float16* row = G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                    if (RELU) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+                    *reinterpret_cast<half4*>(row + 8 * q) = half4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                }
+            }
+        }
+    }
+}
+
+// TRAIN (dense point lists only): tanh(ambient) is left in s.sdt / s.st [raw] and every layer's activations go to `sv`.
+template <bool TRAIN = false>
+__device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, uint32_t Mv, int nt, int wave, int lane, const SaveBufs16* sv = nullptr,
+                                              uint32_t gbase = 0) {
     const int half = lane >> 5, j = lane & 31;
     const uint32_t sI = (uint32_t)(wave * 32 + j);
     const bool tile_on = wave < nt;
@@ -848,6 +885,9 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         float sh[16];
         gf::sh4(s.p_dx[slot], s.p_dy[slot], s.p_dz[slot], sh);
         store16h(SHT + slot * 16, sh);
+        if constexpr (TRAIN) {
+            if ((uint32_t)slot < Mv) store16h(sv->sh + (size_t)(gbase + (uint32_t)slot) * 16, sh);
+        }
     }
 #ifdef GF_DIAG
     uint32_t dkey = 0xFFFFFFFFu;
@@ -864,6 +904,9 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         float pf[16];
         gf::encode8<3>(a.pos_table, meta + half * 8, a.gridtype, a.interp, x3, pf);
         store16h(Frow + 16 * half, pf);
+        if constexpr (TRAIN) {
+            if (valid) store16h(sv->f3 + (size_t)(gbase + sI) * 32 + 16 * half, pf);
+        }
 #ifdef GF_DIAG
         dkey = valid ? s.dkey[raw] : 0xFFFFFFFFu;
         float c = 0.0f;
@@ -881,6 +924,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     GF_STAMP(9);
     GF_STAMP(10);
     obw16_store<true>(Hw, A, nt);          // H is not read by this layer: no barrier before the write-back
+    if constexpr (TRAIN) obw16_save<true>(sv->ha1, gbase, Mv, wave, lane, A, nt, sv->m_ha1);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
@@ -900,6 +944,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         GF_STAMP(14);
         skinny_publish<4, 2, kHF16>(Hf + j * kHF16 + 16 + 4 * wave, half, part);   // floats 16..31 = halves 32..63: behind the 2-D features (halves 0..31)
     }
+    if constexpr (TRAIN) obw16_save<true>(sv->ha2, gbase, Mv, wave, lane, A, nt, sv->m_ha2);
 #else
     __syncthreads();
     GF_STAMP(14);
@@ -919,9 +964,15 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         // (tanh(v) + 1) / 2 = 1 / (1 + exp(-2 v))
         const float e2[2] = {__expf(-2.0f * ambient[0]), __expf(-2.0f * ambient[1])};
         const float x2[2] = {1.0f / (1.0f + e2[0]), 1.0f / (1.0f + e2[1])};
+        if constexpr (TRAIN) {
+            if (valid && half == 0) { s.sdt[raw] = 2.0f * x2[0] - 1.0f; s.st[raw] = 2.0f * x2[1] - 1.0f; }     // tanh(ambient)
+        }
         float af[16];
         gf::encode8<2>(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, af);
         store16h(Hrow + 16 * half, af);
+        if constexpr (TRAIN) {
+            if (valid) store16h(sv->f2 + (size_t)(gbase + sI) * 32 + 16 * half, af);
+        }
 #ifdef GF_DIAG
         float c = 0.0f, cf = 0.0f;
         for (int i = 0; i < 16; i++) { c += (float)(_Float16)af[i]; cf += af[i]; }
@@ -950,6 +1001,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(20);
     obw16_store<true>(Hw, A, nt);
+    if constexpr (TRAIN) obw16_save<true>(sv->hs1, gbase, Mv, wave, lane, A, nt, sv->m_hs1);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
@@ -967,6 +1019,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         skinny_publish<4, 1, kHF16>(Hf + j * kHF16 + 64 + wave, half, part);       // the row's 16 pad bytes (halves 128..135)
     }
 #endif
+    if constexpr (TRAIN) obw16_save<true>(sv->hs2, gbase, Mv, wave, lane, A, nt, sv->m_hs2);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
@@ -990,6 +1043,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(28);
     obw16_store<false>(Hw, A, nt);
+    if constexpr (TRAIN) obw16_save<false>(sv->geo, gbase, Mv, wave, lane, A, nt);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
@@ -1021,6 +1075,7 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         GF_STAMP(32);
         skinny_publish<4, 3, kHF16>(Hf + j * kHF16 + 4 * wave, half, part);
     }
+    if constexpr (TRAIN) obw16_save<true>(sv->hc1, gbase, Mv, wave, lane, A, nt, sv->m_hc1);
 #else
     __syncthreads();
     GF_STAMP(32);
@@ -1687,7 +1742,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_head_phase(const HeadArgs a) {
             GF_STAMP(6);
             const uint32_t nt = (Mv + 31) / 32;
             if constexpr (MODE == 1) {
-                field_round16(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
+                field_round16<false>(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane);
             } else if constexpr (MODE == 2) {
                 // two instantiations, ONE arithmetic: every floating-point operation of the round is an explicit builtin (MFMA, fmaf, med3,
                 // round-to-nearest conversions), so which of them evaluates a sample cannot change its value (the fast tier once differed
@@ -1915,6 +1970,55 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_points(const HeadArgs a, 
 }
 
 
+// The training forward on the f16 tier (gf_field_forward_train16): f16 MFMA operands, fp32 accumulation -- the arithmetic the reference's
+// autocast run has (cond_encoder.py:106-111 under utils/commons/trainer.py:307-382) -- with every layer's activations saved as binary16.
+struct PointArgs16 {
+    const float* xyz; const float* dirs; const float* col_bias;
+    float* sigma; float* rgb; float* ambient;
+    uint32_t M;
+    SaveBufs16 sv;
+};
+
+__global__ void __launch_bounds__(kThreads, 2) k_field_points16(const HeadArgs a, const PointArgs16 u) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
+    __syncthreads();
+    if (u.col_bias && tid < 128) s.P[P_SMALL + gf::HS_COLBIAS + tid] = u.col_bias[tid];
+    if (tid < 128) s.P[P_AMBBIAS + tid] = a.amb_bias[tid];
+    if (tid < 32) {
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
+    }
+    const uint32_t chunks = (u.M + kPass - 1) / kPass;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        __syncthreads();   // previous round retired
+        const uint32_t i = chunk * kPass + (uint32_t)tid;
+        if (tid < kPass) {
+            const bool in = i < u.M;
+            const size_t p = in ? i : (size_t)chunk * kPass;      // slots beyond the list: a valid stand-in (their SH rows are read by no live column)
+            s.sx[tid] = u.xyz[p * 3]; s.sy[tid] = u.xyz[p * 3 + 1]; s.sz[tid] = u.xyz[p * 3 + 2];
+            s.p_dx[tid] = u.dirs[p * 3]; s.p_dy[tid] = u.dirs[p * 3 + 1]; s.p_dz[tid] = u.dirs[p * 3 + 2];
+            s.d2r[tid] = (uint8_t)tid;
+            s.rrank[tid] = (uint8_t)tid;
+        }
+        const uint32_t left = u.M - chunk * kPass;
+        const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
+        __syncthreads();
+        const uint32_t nt = (Mv + 31) / 32;
+        field_round16<true>(a, s, Mv, __builtin_amdgcn_readfirstlane((int)nt), wave, lane, &u.sv, chunk * kPass);
+        if (tid < kPass && i < u.M) {
+            u.sigma[i] = s.sx[tid];
+            u.rgb[(size_t)i * 3] = s.sy[tid]; u.rgb[(size_t)i * 3 + 1] = s.sz[tid]; u.rgb[(size_t)i * 3 + 2] = s.ob[tid];
+            u.ambient[(size_t)i * 2] = s.sdt[tid]; u.ambient[(size_t)i * 2 + 1] = s.st[tid];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- field backward (dX chain)
 // The input-gradient chain of RADNeRF.forward for a dense point list in ONE launch (geneface_amd/train_field.py): from (d sigma, d rgb,
 // d ambient) back through colour net -> geometry feature -> sigma net -> 2-D lookup (input gradient, re-gathered) -> ambient net, writing
@@ -1938,7 +2042,8 @@ struct BwdArgs {
 };
 
 // accumulators -> LDS (and row gbase + sample of G), optionally through the ReLU mask of the layer whose pre-activation gradient this is
-template <int NT, bool MASK>
+// O16: the rows of G are binary16 (the AMP tier: the weight-gradient products then run on half operands, as the reference's autocast step does)
+template <int NT, bool MASK, bool O16 = false>
 __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
                                           int lane, const floatx16 (&acc)[4], float* colsum = nullptr /* LDS [128]: running column sums of G, or NULL */) {
     const int half = lane >> 5, j = lane & 31;
@@ -1950,7 +2055,9 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
         uint32_t bits = 0xFFFFu;
         if (MASK) bits = mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane];
         const bool ok = (uint32_t)(t * 32 + j) < Mv;
-        float* row = G ? G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half : nullptr;
+        const size_t roff = (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half;
+        float* row = (G && !O16) ? G + roff : nullptr;
+        _Float16* row16 = (G && O16) ? reinterpret_cast<_Float16*>(G) + roff : nullptr;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
@@ -1960,6 +2067,7 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
             }
             *reinterpret_cast<float4*>(Hw + t * 32 * kHS + 8 * q) = v;
             if (row && ok) *reinterpret_cast<float4*>(row + 8 * q) = v;
+            if (O16 && row16 && ok) *reinterpret_cast<half4*>(row16 + 8 * q) = half4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
             if (colsum && ok) { part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w; }
         }
     }
@@ -1978,7 +2086,7 @@ __device__ __forceinline__ void bwd_store(float* Hw, float* __restrict__ G, cons
 
 // a layer whose result was written to H in ROW layout (the two rank-k products): pull this lane's accumulator-layout share back,
 // mask it, write it to H and to G
-template <int NT>
+template <int NT, bool O16 = false>
 __device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
                                               int lane, floatx16 (&acc)[4], float* colsum = nullptr) {
 #pragma unroll
@@ -1988,10 +2096,10 @@ __device__ __forceinline__ void bwd_mask_pass(float* Hw, float* __restrict__ G, 
             const float4 v = *reinterpret_cast<const float4*>(Hw + t * 32 * kHS + 8 * q);
             acc[t][4 * q + 0] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
         }
-    bwd_store<NT, true>(Hw, G, mask, gbase, Mv, wave, lane, acc, colsum);
+    bwd_store<NT, true, O16>(Hw, G, mask, gbase, Mv, wave, lane, acc, colsum);
 }
 
-template <int NT>
+template <int NT, bool O16 = false>
 __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int wave, int lane,
                                           float* cs_hc1, float* cs_ha1 /* LDS [128] each */) {
     const int half = lane >> 5, j = lane & 31;
@@ -2035,13 +2143,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
     }
     __syncthreads();
-    bwd_mask_pass<NT>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A, cs_hc1);      // d h_c1 (pre-activation)
+    bwd_mask_pass<NT, O16>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A, cs_hc1);      // d h_c1 (pre-activation)
     __syncthreads();
     // ---- d geo = W_c1[:, 16:144]^T d h_c1
     obw_zero<NT>(A);
     obw_mfma<NT, BG_C1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, false>(Hw, u.g_geo, nullptr, gbase, Mv, wave, lane, A);
+    bwd_store<NT, false, O16>(Hw, u.g_geo, nullptr, gbase, Mv, wave, lane, A);
     __syncthreads();
     // ---- d h_s2 = W_s3[1:]^T d geo + d h0 (x) W_s3[0], masked
     {
@@ -2058,13 +2166,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     }
     obw_mfma<NT, BG_S3, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true>(Hw, u.g_hs2, u.m_hs2, gbase, Mv, wave, lane, A);
+    bwd_store<NT, true, O16>(Hw, u.g_hs2, u.m_hs2, gbase, Mv, wave, lane, A);
     __syncthreads();
     // ---- d h_s1 = W_s2^T d h_s2, masked
     obw_zero<NT>(A);
     obw_mfma<NT, BG_S2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true>(Hw, u.g_hs1, u.m_hs1, gbase, Mv, wave, lane, A);
+    bwd_store<NT, true, O16>(Hw, u.g_hs1, u.m_hs1, gbase, Mv, wave, lane, A);
     __syncthreads();
     // ---- [d f3 (sigma branch) | d f2] = W_s1^T d h_s1   (64 real outputs, zero-padded to 128)
     obw_zero<NT>(A);
@@ -2117,13 +2225,13 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
     }
     __syncthreads();
-    bwd_mask_pass<NT>(Hw, u.g_ha2, u.m_ha2, gbase, Mv, wave, lane, A);      // d h_a2
+    bwd_mask_pass<NT, O16>(Hw, u.g_ha2, u.m_ha2, gbase, Mv, wave, lane, A);      // d h_a2
     __syncthreads();
     // ---- d h_a1 = W_a2^T d h_a2, masked
     obw_zero<NT>(A);
     obw_mfma<NT, BG_A2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A, cs_ha1);
+    bwd_store<NT, true, O16>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A, cs_ha1);
     __syncthreads();
     // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1   (32 real outputs, zero-padded)
     obw_zero<NT>(A);
@@ -2156,6 +2264,7 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     __syncthreads();
 }
 
+template <bool O16>
 __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a, const BwdArgs u) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem s = carve(smem_raw);
@@ -2179,10 +2288,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
         const uint32_t left = u.M - gbase;
         const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
         const uint32_t nt = (Mv + 31) / 32;
-        if (nt == 4) bwd_round<4>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
-        else if (nt == 3) bwd_round<3>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
-        else if (nt == 2) bwd_round<2>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
-        else bwd_round<1>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        if (nt == 4) bwd_round<4, O16>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else if (nt == 3) bwd_round<3, O16>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else if (nt == 2) bwd_round<2, O16>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
+        else bwd_round<1, O16>(a, u, s, Mv, gbase, wave, lane, cs_hc1, cs_ha1);
     }
     __syncthreads();
     if (tid < 128) {   // one atomic per feature and workgroup
@@ -2521,6 +2630,35 @@ static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float
     return gf_check_launch("field_forward");
 }
 
+// The training forward on the f16 tier: f->head_pack16 (gf_head_pack16) beside head_pack (its fp32 skinny rows and constant bias are read too);
+// the nine matrices of `saves` are binary16, the masks as in gf_field_forward_train.
+GF_EXPORT int gf_field_forward_train16(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null, float* sigma,
+                                       float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream) {
+    if (M == 0) return GF_OK;
+    if (!f || !xyz || !dirs || !sigma || !rgb || !ambient || !saves) return gf_set_error(GF_ERR_INVALID, "field_forward_train16: null pointer");
+    if (!f->pos_table || !f->pos_offsets || !f->amb_table || !f->amb_offsets || !f->head_pack || !f->head_pack16 || !f->amb_bias)
+        return gf_set_error(GF_ERR_INVALID, "field_forward_train16: null pointer in the field description (head_pack16 is needed)");
+    if (f->gridtype > 1 || f->interp > 1) return gf_set_error(GF_ERR_INVALID, "field_forward_train16: gridtype/interp must be 0 or 1");
+    if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1 || !saves->sh ||
+        !saves->m_ha1 || !saves->m_ha2 || !saves->m_hs1 || !saves->m_hs2 || !saves->m_hc1)
+        return gf_set_error(GF_ERR_INVALID, "field_forward_train16: null save buffer");
+    HeadArgs ha = {};
+    if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
+        return gf_set_error(GF_ERR_INVALID, "field_forward_train16: bad grid levels");
+    ha.pos_table = f->pos_table; ha.pos_offsets = f->pos_offsets; ha.amb_table = f->amb_table; ha.amb_offsets = f->amb_offsets;
+    ha.head_pack = f->head_pack; ha.head_pack16 = f->head_pack16; ha.amb_bias = f->amb_bias;
+    ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
+    auto h = [](float* p) { return reinterpret_cast<_Float16*>(p); };
+    PointArgs16 pa = {xyz, dirs, col_bias_or_null, sigma, rgb, ambient, M,
+                      {h(saves->f3), h(saves->ha1), h(saves->ha2), h(saves->f2), h(saves->hs1), h(saves->hs2), h(saves->geo), h(saves->hc1), h(saves->sh),
+                       saves->m_ha1, saves->m_ha2, saves->m_hs1, saves->m_hs2, saves->m_hc1}};
+    static GfLdsAttr lds;
+    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_field_points16), kSmemBytes, "field_forward_train16")) return e;
+    const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
+    hipLaunchKernelGGL(k_field_points16, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, pa);
+    return gf_check_launch("field_forward_train16");
+}
+
 GF_EXPORT int gf_field_forward(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
                                float* sigma, float* rgb, float* ambient_or_null, void* stream) {
     return field_forward_impl(f, xyz, dirs, M, col_bias_or_null, sigma, rgb, ambient_or_null, nullptr, stream);
@@ -2555,10 +2693,12 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     BwdArgs ba = {bwd_stream, g->g_sigma, g->g_rgb, g->g_amb, g->sigma, g->rgb, g->amb, g->m_hc1, g->m_hs2, g->m_hs1, g->m_ha2, g->m_ha1,
                   g->g_zc, g->g_h0, g->g_za, g->g_hc1, g->g_geo, g->g_hs2, g->g_hs1, g->g_ha2, g->g_ha1, g->g_f3, g->g_f2, g->s_hc1, g->s_ha1, g->level_max, M};
-    static GfLdsAttr lds;
-    if (const int e = gf_raise_lds_limit(lds, reinterpret_cast<const void*>(k_field_backward), kSmemBytes, "field_backward")) return e;
+    static GfLdsAttr lds[2];
+    if (const int e = gf_raise_lds_limit(lds[0], reinterpret_cast<const void*>(k_field_backward<false>), kSmemBytes, "field_backward")) return e;
+    if (const int e = gf_raise_lds_limit(lds[1], reinterpret_cast<const void*>(k_field_backward<true>), kSmemBytes, "field_backward")) return e;
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
-    hipLaunchKernelGGL(k_field_backward, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
+    if (g->out16) hipLaunchKernelGGL(k_field_backward<true>, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
+    else hipLaunchKernelGGL(k_field_backward<false>, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
     return gf_check_launch("field_backward");
 }
 

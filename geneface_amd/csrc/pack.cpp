@@ -98,6 +98,33 @@ GF_EXPORT int gf_head_pack16(const float* amb0, const float* amb1, const float* 
     return GF_OK;
 }
 
+// Where every half of gf_head_pack16's output comes from: 1-based flat index into cat(amb0, amb1, sig0, sig1, sig2, col0) (row-major), 0 = a
+// zero slot.  With it a training step re-gathers the f16 streams from the current fp32 master weights ON THE DEVICE (one cat + half() +
+// gather) instead of a device -> host -> pack -> device round trip: the AMP tier's forward (gf_field_forward_train16) needs them every step.
+GF_EXPORT int gf_head_pack16_index(uint32_t* out_index) {
+    using namespace gf;
+    if (!out_index) return gf_set_error(GF_ERR_INVALID, "head_pack16_index: null pointer");
+    memset(out_index, 0, sizeof(uint32_t) * HP16_HALVES);
+    const uint32_t base_amb0 = 1, base_amb1 = base_amb0 + 128 * 96, base_sig0 = base_amb1 + 128 * 128, base_sig1 = base_sig0 + 128 * 64,
+                   base_sig2 = base_sig1 + 128 * 128, base_col0 = base_sig2 + 129 * 128;
+    auto layer = [&](uint32_t g0, uint32_t groups, uint32_t base, uint32_t ld, uint32_t row0, uint32_t col0) {
+        for (uint32_t w = 0; w < 4; w++)
+            for (uint32_t u = 0; u < groups; u++)
+                for (uint32_t l = 0; l < 64; l++)
+                    for (uint32_t i = 0; i < 8; i++)
+                        out_index[(((size_t)w * H16_TOTAL + g0 + u) * 64 + l) * 8 + i] = base + (row0 + 32 * w + (l & 31u)) * ld + col0 + 16 * u + 8 * (l >> 5) + i;
+    };
+    layer(H16_AMB1, 2, base_amb0, 96, 0, 0);
+    layer(H16_AMB2, 8, base_amb1, 128, 0, 0);
+    layer(H16_SIG1A, 2, base_sig0, 64, 0, 0);
+    layer(H16_SIG1B, 2, base_sig0, 64, 0, 32);
+    layer(H16_SIG2, 8, base_sig1, 128, 0, 0);
+    layer(H16_SIG3, 8, base_sig2, 128, 1, 0);
+    layer(H16_COL1S, 1, base_col0, 148, 0, 0);
+    layer(H16_COL1G, 8, base_col0, 148, 0, 16);
+    return GF_OK;
+}
+
 // Split path (gf_frame_t.precision = 2): the same matrices as two-term f16 splits (layout and arithmetic: frame.hpp, SP_*).
 // out_halves [gf_head_pack_split_halves()].  A weight beyond the f16 range cannot be split: GF_ERR_UNSUPPORTED (the caller stays on fp32).
 GF_EXPORT uint32_t gf_head_pack_split_halves(void) { return gf::HPS_HALVES; }

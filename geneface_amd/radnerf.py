@@ -81,6 +81,9 @@ class RADNeRF(NeRFRenderer):
     #: "auto": under autograd the field is ONE graph node (train_field.head_field: fused forward, hand-written backward) whenever the
     #: kernels cover this model; "ops": the reference's op-by-op torch graph.
     field_impl = "auto"
+    #: under torch.autocast(float16): "f16" = the fused field on the f16 matrix pipe (train_field._HeadFieldAMP: the arithmetic of the
+    #: reference's AMP training, base.yaml:49), "f32" = the exact-fp32 node even under autocast (custom_fwd(cast_inputs=float32), round 5)
+    amp_field = "f16"
 
     def forward(self, position, direction, cond_feat, individual_code):
         if self._fused_field_ok(position):

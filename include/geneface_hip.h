@@ -302,6 +302,12 @@ typedef struct gf_field_saves {
 } gf_field_saves_t;
 int gf_field_forward_train(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
                            float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream);
+/* The same launch on the f16 tier (round 6; the arithmetic of the reference's AMP training: /root/reference/egs/egs_bases/radnerf/base.yaml:49
+ * amp: true, utils/commons/trainer.py:307-382 autocast + GradScaler, cond_encoder.py:106-111 Linear layers in half): f16 MFMA operands
+ * (f->head_pack16 beside f->head_pack), fp32 accumulation, fp32 outputs.  The nine matrices of `saves` are BINARY16 here (the activations
+ * the MFMAs consumed), the five masks as above and all required. */
+int gf_field_forward_train16(const gf_frame_t* f, const float* xyz, const float* dirs, uint32_t M, const float* col_bias_or_null,
+                             float* sigma, float* rgb, float* ambient, const gf_field_saves_t* saves, void* stream);
 /* The input-gradient (dX) chain of the same field in one launch: from the gradients of the three outputs back through every layer, the
  * ReLU derivatives taken from the forward's mask bits, the 2-D lookup's input gradient re-gathered.  It writes the pre-activation gradient
  * of every layer (what the weight gradients are tall products of, with the saved activations) and the gradients of both grid feature sets
@@ -318,6 +324,7 @@ typedef struct gf_field_grads {
     float* s_hc1; float* s_ha1;                                     /* out, ZEROED by the caller: [128] column sums of g_hc1 / g_ha1 over the points */
     uint32_t* level_max;                                            /* out or NULL, ZEROED by the caller: [2][16] max |g_f3| (first 16) and |g_f2| per level,
                                                                        as bit patterns of non-negative floats: what gf_grid_encode_backward_scaled takes */
+    uint32_t out16; uint32_t _pad;                                  /* 1: the six [M,128] outputs are binary16 (AMP tier: half operands for the weight-gradient products) */
 } gf_field_grads_t;
 uint32_t gf_field_bwd_stream_floats(void);
 int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
@@ -384,6 +391,9 @@ int gf_head_pack(const float* amb0_host, const float* amb1_host, const float* am
 uint32_t gf_head_pack16_halves(void);
 int gf_head_pack16(const float* amb0_host, const float* amb1_host, const float* sig0_host, const float* sig1_host,
                    const float* sig2_host, const float* col0_host, uint16_t* out_halves_host);
+/* HOST: out_index_host [gf_head_pack16_halves()]: the 1-based flat index into cat(amb0, amb1, sig0, sig1, sig2, col0) every half of that layout
+ * is taken from (0: a zero slot) -- for re-gathering the streams on the device after every optimizer step (the AMP training tier) */
+int gf_head_pack16_index(uint32_t* out_index_host);
 /* split path (gf_frame_t.precision = 2): the same six layers as two-term f16 splits; GF_ERR_UNSUPPORTED when a weight is outside the f16 range */
 uint32_t gf_head_pack_split_halves(void);
 int gf_head_pack_split(const float* amb0_host, const float* amb1_host, const float* sig0_host, const float* sig1_host,

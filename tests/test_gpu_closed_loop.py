@@ -334,7 +334,9 @@ def test_torso_stage_frozen_head_train_checkpoint_reload_render(tmp_path):
         return m
     model = student()
     assert model._fused_torso_train_ok(bgc.view(-1, 2)[:64], model.torso_individual_codes[0], None)
-    head0 = {k: v.detach().clone() for k, v in model.state_dict().items() if "torso" not in k}
+    # (parameters and the head's occupancy: `step_counter` / `mean_count` are the training marcher's bookkeeping and do move)
+    frozen = {n for n, _ in model.named_parameters() if "torso" not in n} | {"density_grid", "density_bitfield", "aabb_train", "aabb_infer"}
+    head0 = {k: v.detach().clone() for k, v in model.state_dict().items() if k in frozen}
     torso0 = {k: v.detach().clone() for k, v in model.state_dict().items() if "torso" in k and v.is_floating_point()}
     losses, opt = _train_torso(model, hp, seq, poses, pose6, cond, bg, bgc, targets, TORSO_STEPS)
     assert all(np.isfinite(losses))

@@ -405,3 +405,82 @@ def test_fused_torso_field_vs_op_graph(M):
         d = (res["auto"][1][n] - gr).double()
         l2 = float(d.norm() / gr.double().norm().clamp(min=1e-20))
         assert l2 < 2e-4, (n, l2)         # measured 1e-6 .. 3e-5
+
+
+# ----------------------------------------------------------------------------------------------- AMP training tier (round 6)
+def test_amp_field_node_vs_fp32_node():
+    """Under torch.autocast(float16) the fused field runs on the f16 tier (train_field._HeadFieldAMP: f16 MFMA operands re-gathered from the
+    fp32 master weights, fp32 accumulation, binary16 saves, half operands in the weight-gradient products) -- the arithmetic of the
+    reference's AMP step (base.yaml:49 amp: true; trainer.py:307-382).  Against the exact-fp32 node on the same points: outputs and every
+    gradient within half-precision bars (operands rounded to 11 bits: ~1e-3 relative per product, sqrt(K)-averaged over K = 32..144)."""
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.train_field import _HeadField, _HeadFieldAMP, head_field
+    hp, sd = model_fixture(False)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M = 5000 + 77
+    xyz = torch.rand(M, 3, device=DEV, generator=g) * 1.6 - 0.8
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, device=DEV, generator=g), dim=-1)
+    cond = torch.randn(64, device=DEV, generator=g) * 0.3
+    code = model.individual_embeddings[0]
+    ws, wc, wa = torch.rand(M, device=DEV, generator=g), torch.rand(M, 3, device=DEV, generator=g), torch.rand(M, 2, device=DEV, generator=g)
+    res = {}
+    for tier in ("f32", "f16"):
+        model.amp_field = tier
+        model.zero_grad(set_to_none=True)
+        cf = cond.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb, amb = head_field(model, xyz, dirs, cf, code)
+            assert sigma.dtype == rgb.dtype == amb.dtype == torch.float32
+        # log-density weighs the (exp-amplified) sigma so that no single sample dominates the comparison
+        ((torch.log1p(sigma) * ws).sum() + (rgb * wc).sum() + (amb * wa).sum()).backward()
+        res[tier] = ([t.detach().clone() for t in (sigma, rgb, amb)], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None},
+                     cf.grad.detach().float().clone())
+    model.amp_field = "f16"
+    (s32, c32, a32), (s16, c16, a16) = res["f32"][0], res["f16"][0]
+    assert float((c16 - c32).abs().max()) < 3e-2 and float((a16 - a32).abs().max()) < 3e-2
+    assert float(((s16 - s32).abs() / (s32.abs() + 1e-3)).median()) < 2e-2
+    assert set(res["f16"][1]) == set(res["f32"][1]) and len(res["f32"][1]) >= 11
+    for n, gr in res["f32"][1].items():
+        d = (res["f16"][1][n] - gr).double()
+        l2 = float(d.norm() / gr.double().norm().clamp(min=1e-20))
+        assert l2 < 5e-2, (n, l2)
+    dcf = float((res["f16"][2] - res["f32"][2]).double().norm() / res["f32"][2].double().norm())
+    assert dcf < 5e-2, dcf
+
+
+def test_amp_training_steps_follow_the_fp32_steps():
+    """Eight optimizer steps of the training branch under fp16 autocast + GradScaler on the f16 tier against the same eight steps in fp32:
+    the loss curves agree within half-precision noise and no step is skipped (finite gradients at the initial scale)."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    curves = {}
+    for amp in (False, True):
+        model = RADNeRF(hp)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).train()
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=256.0, enabled=amp)
+        losses = []
+        for _ in range(8):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+                loss = _loss(out, target)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(loss))
+        curves[amp] = losses
+        if amp:
+            assert scaler.get_scale() >= 256.0          # no inf / nan step
+    a, b = curves[True], curves[False]
+    assert all(abs(x / y - 1.0) < 5e-2 for x, y in zip(a, b)), (a, b)
+    assert b[-1] < b[0] and a[-1] < a[0]

