@@ -728,9 +728,9 @@ template <int G>
 __device__ __forceinline__ half8 wpipe16_take(const WPipe16& wp) {
     return __builtin_bit_cast(half8, wp.q[G % kWAhead16]);
 }
-template <int G>
+template <int G, int GEND = (int)gf::H16_TOTAL>
 __device__ __forceinline__ void wpipe16_refill(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16) {
-    if constexpr (G + kWAhead16 < (int)gf::H16_TOTAL) wp.q[G % kWAhead16] = load_group(Ws, G + kWAhead16, lane16);
+    if constexpr (G + kWAhead16 < GEND) wp.q[G % kWAhead16] = load_group(Ws, G + kWAhead16, lane16);
 }
 
 // Hb = &H16[lane & 31][8 * (lane >> 5)]: tile t is 32 rows further, group u sixteen halves further.
@@ -738,7 +738,7 @@ __device__ __forceinline__ void wpipe16_refill(WPipe16& wp, const char* __restri
 // instantiation means one instruction selection for every fp32 -> f16 conversion and fma, so a sample's result does not depend on
 // how full the round it happens to land in is.  (With four instantiations the frames differed from run to run in a few
 // hundredths of a percent of the pixels: the dynamic ray queue decides which instantiation evaluates which sample.)
-template <int G0, int U, int u, int RS>
+template <int G0, int U, int u, int RS, int GEND = (int)gf::H16_TOTAL>
 __device__ __forceinline__ void obw16_step(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4],
                                            const half8 (&b)[4], int nt) {
     if constexpr (u < U) {
@@ -753,19 +753,19 @@ __device__ __forceinline__ void obw16_step(WPipe16& wp, const char* __restrict__
 #pragma unroll
         for (int t = 0; t < 4; t++)
             if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
-        wpipe16_refill<G0 + u>(wp, Ws, lane16);
+        wpipe16_refill<G0 + u, GEND>(wp, Ws, lane16);
         __builtin_amdgcn_sched_barrier(0);
-        obw16_step<G0, U, u + 1, RS>(wp, Ws, lane16, Hb, acc, bn, nt);
+        obw16_step<G0, U, u + 1, RS, GEND>(wp, Ws, lane16, Hb, acc, bn, nt);
     }
 }
-template <int G0, int U, int RS = kHS16>
+template <int G0, int U, int RS = kHS16, int GEND = (int)gf::H16_TOTAL>
 __device__ __forceinline__ void obw16_mfma(WPipe16& wp, const char* __restrict__ Ws, uint32_t lane16, const _Float16* Hb, floatx16 (&acc)[4], int nt) {
     half8 b[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
         if (t < nt) b[t] = *reinterpret_cast<const half8*>(Hb + t * 32 * RS);
     __builtin_amdgcn_sched_barrier(0);
-    obw16_step<G0, U, 0, RS>(wp, Ws, lane16, Hb, acc, b, nt);
+    obw16_step<G0, U, 0, RS, GEND>(wp, Ws, lane16, Hb, acc, b, nt);
 }
 
 // Hw = &H16[lane & 31][32 * wave + 4 * (lane >> 5)]: registers 4q..4q+3 -> four consecutive halves (one ds_write_b64)
@@ -2302,6 +2302,288 @@ __global__ void __launch_bounds__(kThreads, 2) k_field_backward(const HeadArgs a
     if (u.lvl_max && tid < 32 && s.hist[tid]) atomicMax(&u.lvl_max[tid], s.hist[tid]);
 }
 
+// ---------------------------------------------------------------------------------------------------- field backward on the f16 tier (round 6)
+// The same input-gradient chain with f16 MFMA operands (the AMP training tier: the reference's autocast step back-propagates its Linear layers
+// in half, fp32 accumulation).  Six transposed 128 x 128 blocks as f16 A-operand streams [wave][layer 6][group 8][lane][8 halves]
+// (element = Wt[32 wave + (lane & 31)][16 group + 8 (lane >> 5) + i]), the round's gradients as binary16 rows [128][136] in LDS, accumulators,
+// masks, column sums, the three skinny transposes, the lookup's input gradient and both grid-feature gradients in fp32.  Differences from
+// bwd_round beyond the operand type: the two rank-k products (W_c2^T d z_c, W_a3^T d z_a) are computed directly in ACCUMULATOR layout from
+// per-sample scalars in LDS (no row pass + re-read), and the two narrow layers' real outputs (64 / 32 features) go to an fp32 scratch
+// [128][64] behind the f16 rows instead of through them: the grid-feature gradients never see f16.
+constexpr int BH_C1 = 0, BH_S3 = 8, BH_S2 = 16, BH_S1 = 24, BH_A2 = 32, BH_A1 = 40, BH_TOTAL = 48;
+static_assert(kPass * kHS16 * 2 + kPass * 64 * 4 <= kPass * kHS * 4, "f16 gradient rows + the fp32 scratch fit the activation buffer");
+
+// accumulators -> f16 LDS rows (and binary16 row gbase + sample of G), optionally through a ReLU mask; running column sums in fp32
+template <bool MASK, bool CS = false>
+__device__ __forceinline__ void bwd16_store(_Float16* Hw, _Float16* __restrict__ G, const uint16_t* __restrict__ mask, uint32_t gbase, uint32_t Mv, int wave,
+                                            int lane, const floatx16 (&acc)[4], int nt, float* colsum = nullptr) {
+    const int half = lane >> 5, j = lane & 31;
+    float part[CS ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (CS ? 16 : 1); r++) part[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t < nt) {
+            uint32_t bits = 0xFFFFu;
+            if (MASK) bits = mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane];
+            const bool ok = (uint32_t)(t * 32 + j) < Mv;
+            _Float16* row = G ? G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half : nullptr;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                if (MASK) {
+                    v.x = (bits >> (4 * q + 0)) & 1u ? v.x : 0.0f; v.y = (bits >> (4 * q + 1)) & 1u ? v.y : 0.0f;
+                    v.z = (bits >> (4 * q + 2)) & 1u ? v.z : 0.0f; v.w = (bits >> (4 * q + 3)) & 1u ? v.w : 0.0f;
+                }
+                const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<half4*>(Hw + t * 32 * kHS16 + 8 * q) = h;
+                if (row && ok) *reinterpret_cast<half4*>(row + 8 * q) = h;
+                if constexpr (CS) {
+                    if (ok) { part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w; }
+                }
+            }
+        }
+    }
+    if constexpr (CS) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = part[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (j == 0) colsum[32 * wave + 8 * (r >> 2) + 4 * half + (r & 3)] += v;
+        }
+    }
+}
+
+// acc[t][r] = sum_c z_c[sample t * 32 + j] * rows[c][32 wave + 8 q + 4 half + i]: a rank-NC product straight into accumulator layout
+template <int NC>
+__device__ __forceinline__ void rank_k_acc(const float* const (&z)[NC], const float* rows, int wave, int half, int j, floatx16 (&acc)[4], int nt) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t < nt) {
+            float zc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) zc[c] = z[c][t * 32 + j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float4 v = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float4 w = *reinterpret_cast<const float4*>(rows + c * 128 + 32 * wave + 8 * q + 4 * half);
+                    v.x = __builtin_fmaf(zc[c], w.x, v.x); v.y = __builtin_fmaf(zc[c], w.y, v.y);
+                    v.z = __builtin_fmaf(zc[c], w.z, v.z); v.w = __builtin_fmaf(zc[c], w.w, v.w);
+                }
+                acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
+            }
+        }
+    }
+}
+
+// the real outputs of a narrow layer (features < NREAL) from accumulator layout into the fp32 scratch [128][64]
+template <int NREAL>
+__device__ __forceinline__ void scratch_store(float* scr, int wave, int lane, const floatx16 (&acc)[4], int nt) {
+    const int half = lane >> 5, j = lane & 31;
+    if (32 * wave >= NREAL) return;       // wave-uniform
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (t < nt) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4*>(scr + (t * 32 + j) * 64 + 32 * wave + 8 * q + 4 * half) = float4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        }
+}
+
+__device__ __forceinline__ void bwd_round16(const HeadArgs& a, const BwdArgs& u, const Smem& s, uint32_t Mv, uint32_t gbase, int nt, int wave, int lane_in,
+                                            float* cs_hc1, float* cs_ha1 /* LDS [128] each */) {
+    // The lane index is made opaque once per round: left visible, every lane-dependent part of the ~60 global addresses of a round (six
+    // [M,128] outputs x 4 tiles, the level-major grid gradients, the masks) is loop-invariant over the chunk loop, gets hoisted in front of
+    // it as 64-bit values and spilled (288 bytes of scratch per lane; a launch that touches scratch at all pays for it: NOTES 4.7).
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t sI = (uint32_t)(wave * 32 + j);
+    const bool tile_on = wave < nt;
+    const bool valid = sI < Mv;
+    const size_t pt = (size_t)gbase + (valid ? sI : 0u);
+    _Float16* H16 = reinterpret_cast<_Float16*>(s.H);
+    const _Float16* Hb = H16 + j * kHS16 + 8 * half;
+    _Float16* Hw = H16 + j * kHS16 + 32 * wave + 4 * half;
+    float* scr = reinterpret_cast<float*>(H16 + kPass * kHS16);            // [128][64] fp32
+    const char* Ws = reinterpret_cast<const char*>(u.stream) + (size_t)wave * BH_TOTAL * 1024;
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    const gf::LevelMeta* meta = reinterpret_cast<const gf::LevelMeta*>(s.P + P_META);
+    auto G16 = [](float* p) { return reinterpret_cast<_Float16*>(p); };
+    floatx16 A[4];
+    WPipe16 wp;
+#pragma unroll
+    for (int g = 0; g < kWAhead16; g++) wp.q[g] = load_group(Ws, g, lane16);
+
+    // ---- per-sample scalars: d z_c = d rgb * rgb (1 - rgb), d h0 = d sigma * exp(clamp(h0)) -> LDS by sample (zeros beyond the list)
+    if (tile_on && half == 0) {
+        float gz[3] = {0.0f, 0.0f, 0.0f}, gh0 = 0.0f;
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float r = u.rgb[pt * 3 + c]; gz[c] = u.g_rgb[pt * 3 + c] * r * (1.0f - r); }
+            gh0 = u.g_sigma[pt] * fminf(fmaxf(u.sigma[pt], 3.0590232e-7f), 3269017.37f);
+            u.g_zc[pt * 3] = gz[0]; u.g_zc[pt * 3 + 1] = gz[1]; u.g_zc[pt * 3 + 2] = gz[2]; u.g_h0[pt] = gh0;
+        }
+        s.sx[sI] = gz[0]; s.sy[sI] = gz[1]; s.sz[sI] = gz[2]; s.sdt[sI] = gh0;
+    }
+    __syncthreads();
+    // ---- d h_c1 = W_c2^T d z_c, masked (accumulator layout directly)
+    {
+        const float* const z[3] = {s.sx, s.sy, s.sz};
+        rank_k_acc<3>(z, s.P + P_SMALL + gf::HS_COL2, wave, half, j, A, nt);
+    }
+    bwd16_store<true, true>(Hw, G16(u.g_hc1), u.m_hc1, gbase, Mv, wave, lane, A, nt, cs_hc1);
+    __syncthreads();
+    // ---- d geo = W_c1[:, 16:144]^T d h_c1
+    obw_zero<4>(A);
+    obw16_mfma<BH_C1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    __syncthreads();
+    bwd16_store<false>(Hw, G16(u.g_geo), nullptr, gbase, Mv, wave, lane, A, nt);
+    __syncthreads();
+    // ---- d h_s2 = W_s3[1:]^T d geo + d h0 (x) W_s3[0], masked
+    {
+        const float* const z[1] = {s.sdt};
+        rank_k_acc<1>(z, s.P + P_SMALL + gf::HS_SIGROW, wave, half, j, A, nt);
+    }
+    obw16_mfma<BH_S3, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    __syncthreads();
+    bwd16_store<true>(Hw, G16(u.g_hs2), u.m_hs2, gbase, Mv, wave, lane, A, nt);
+    __syncthreads();
+    // ---- d h_s1 = W_s2^T d h_s2, masked
+    obw_zero<4>(A);
+    obw16_mfma<BH_S2, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    __syncthreads();
+    bwd16_store<true>(Hw, G16(u.g_hs1), u.m_hs1, gbase, Mv, wave, lane, A, nt);
+    __syncthreads();
+    // ---- [d f3 (sigma branch) | d f2] = W_s1^T d h_s1  (64 real outputs) -> fp32 scratch
+    obw_zero<4>(A);
+    obw16_mfma<BH_S1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    scratch_store<64>(scr, wave, lane, A, nt);
+    __syncthreads();
+    // ---- 2-D lookup: d f2 out, input gradient in; ambient tail d z_a = (d amb + 0.5 d x2) (1 - amb^2) -> LDS by sample
+    if (tile_on) {
+        if (valid) {      // d f3 of the sigma branch: parked in its final place until the ambient branch's share arrives (registers: bwd_round does the same)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v3 = *reinterpret_cast<const float4*>(scr + sI * 64 + 16 * half + 4 * q);
+                *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + 2 * q) * u.M + pt) * 2) = float2{v3.x, v3.y};
+                *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + 2 * q + 1) * u.M + pt) * 2) = float2{v3.z, v3.w};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float gf2[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v2 = *reinterpret_cast<const float4*>(scr + sI * 64 + 32 + 16 * half + 4 * q);
+            gf2[4 * q] = v2.x; gf2[4 * q + 1] = v2.y; gf2[4 * q + 2] = v2.z; gf2[4 * q + 3] = v2.w;
+        }
+        float gamb[2] = {0.0f, 0.0f}, ambv[2] = {0.0f, 0.0f};
+        if (valid) {
+            gamb[0] = u.g_amb[pt * 2]; gamb[1] = u.g_amb[pt * 2 + 1];
+            ambv[0] = u.amb[pt * 2]; ambv[1] = u.amb[pt * 2 + 1];
+#pragma unroll
+            for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f2 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf2[2 * l], gf2[2 * l + 1]};
+            if (u.lvl_max) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const uint32_t m0 = __float_as_uint(gf2[2 * l]) & 0x7fffffffu, m1 = __float_as_uint(gf2[2 * l + 1]) & 0x7fffffffu;
+                    atomicMax(&s.hist[16 + 8 * half + l], m0 > m1 ? m0 : m1);
+                }
+            }
+        }
+        const float x2[2] = {(ambv[0] + 1.0f) / 2.0f, (ambv[1] + 1.0f) / 2.0f};
+        float dx[2];
+        gf::encode8_grad2(a.amb_table, meta + 16 + half * 8, a.gridtype, a.interp, x2, gf2, dx);
+        dx[0] += __shfl_xor(dx[0], 32);
+        dx[1] += __shfl_xor(dx[1], 32);
+        const float gza[2] = {valid ? (gamb[0] + 0.5f * dx[0]) * (1.0f - ambv[0] * ambv[0]) : 0.0f,
+                              valid ? (gamb[1] + 0.5f * dx[1]) * (1.0f - ambv[1] * ambv[1]) : 0.0f};
+        if (half == 0) {
+            if (valid) { u.g_za[pt * 2] = gza[0]; u.g_za[pt * 2 + 1] = gza[1]; }
+            s.st[sI] = gza[0]; s.ob[sI] = gza[1];
+        }
+    }
+    __syncthreads();
+    // ---- d h_a2 = W_a3^T d z_a, masked
+    {
+        const float* const z[2] = {s.st, s.ob};
+        rank_k_acc<2>(z, s.P + P_SMALL + gf::HS_AMB3, wave, half, j, A, nt);
+    }
+    bwd16_store<true>(Hw, G16(u.g_ha2), u.m_ha2, gbase, Mv, wave, lane, A, nt);
+    __syncthreads();
+    // ---- d h_a1 = W_a2^T d h_a2, masked
+    obw_zero<4>(A);
+    obw16_mfma<BH_A2, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    __syncthreads();
+    bwd16_store<true, true>(Hw, G16(u.g_ha1), u.m_ha1, gbase, Mv, wave, lane, A, nt, cs_ha1);
+    __syncthreads();
+    // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1  (32 real outputs) -> fp32 scratch, added to the sigma branch's share
+    obw_zero<4>(A);
+    obw16_mfma<BH_A1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
+    scratch_store<32>(scr, wave, lane, A, nt);
+    __syncthreads();
+    if (tile_on && valid) {
+        float gf3[16];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {   // this lane's own store of two layers ago (same thread, same address: ordered)
+            const float2 p = *reinterpret_cast<const float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2);
+            gf3[2 * l] = p.x; gf3[2 * l + 1] = p.y;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(scr + sI * 64 + 16 * half + 4 * q);
+            gf3[4 * q] += v.x; gf3[4 * q + 1] += v.y; gf3[4 * q + 2] += v.z; gf3[4 * q + 3] += v.w;
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++) *reinterpret_cast<float2*>(u.g_f3 + ((size_t)(8 * half + l) * u.M + pt) * 2) = float2{gf3[2 * l], gf3[2 * l + 1]};
+        if (u.lvl_max) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                const uint32_t m0 = __float_as_uint(gf3[2 * l]) & 0x7fffffffu, m1 = __float_as_uint(gf3[2 * l + 1]) & 0x7fffffffu;
+                atomicMax(&s.hist[8 * half + l], m0 > m1 ? m0 : m1);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kThreads, 2) k_field_backward16(const HeadArgs a, const BwdArgs u) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem s = carve(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < (int)gf::HS_TOTAL; i += kThreads) s.P[P_SMALL + i] = a.head_pack[gf::HP_SMALL + i];
+    if (tid < 32) {
+        const uint32_t g = tid >> 4, l = tid & 15;
+        gf::LevelMeta* m = reinterpret_cast<gf::LevelMeta*>(s.P + P_META) + tid;
+        *m = g ? gf::make_level_meta<2>(a.lv2.scale[l], a.lv2.resolution[l], a.amb_offsets, l, a.gridtype)
+               : gf::make_level_meta<3>(a.lv3.scale[l], a.lv3.resolution[l], a.pos_offsets, l, a.gridtype);
+    }
+    if (tid < 32) s.hist[tid] = 0;
+    const uint32_t chunks = (u.M + kPass - 1) / kPass;
+    float* cs_hc1 = s.p_dx;   // [128] each: the pool-direction arrays are free in this kernel (the sample staging arrays carry the per-sample scalars)
+    float* cs_ha1 = s.p_dy;
+    if (tid < 128) { cs_hc1[tid] = 0.0f; cs_ha1[tid] = 0.0f; }
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        __syncthreads();
+        const uint32_t gbase = chunk * kPass;
+        const uint32_t left = u.M - gbase;
+        const uint32_t Mv = left < (uint32_t)kPass ? left : (uint32_t)kPass;
+        bwd_round16(a, u, s, Mv, gbase, __builtin_amdgcn_readfirstlane((int)((Mv + 31) / 32)), wave, lane, cs_hc1, cs_ha1);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        atomicAdd(&u.s_hc1[tid], cs_hc1[tid]);
+        atomicAdd(&u.s_ha1[tid], cs_ha1[tid]);
+    }
+    __syncthreads();
+    if (u.lvl_max && tid < 32 && s.hist[tid]) atomicMax(&u.lvl_max[tid], s.hist[tid]);
+}
+
 // ---------------------------------------------------------------------------------------------------- frame setup
 // Pinhole ray of pixel n: pixel centres at +0.5, row-major pixels (utils.py:296-363), same operation order as the torch code, no
 // contraction.  ONE definition for k_frame_init (pose mode) and k_pinhole_rays (gf_pinhole_rays: the same rays as tensors), so a frame
@@ -2677,6 +2959,7 @@ GF_EXPORT int gf_field_forward_train(const gf_frame_t* f, const float* xyz, cons
 // 128 x 128 weight blocks as A-operand streams; f supplies the ambient table / offsets / level scales, head_pack (its skinny rows) and
 // gridtype / interp.  All [M, *] outputs are fully written for the M points.
 GF_EXPORT uint32_t gf_field_bwd_stream_floats(void) { return 4u * BG_TOTAL * 256u; }
+GF_EXPORT uint32_t gf_field_bwd16_stream_halves(void) { return 4u * BH_TOTAL * 512u; }
 
 GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream) {
     if (M == 0) return GF_OK;
@@ -2697,7 +2980,11 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     if (const int e = gf_raise_lds_limit(lds[0], reinterpret_cast<const void*>(k_field_backward<false>), kSmemBytes, "field_backward")) return e;
     if (const int e = gf_raise_lds_limit(lds[1], reinterpret_cast<const void*>(k_field_backward<true>), kSmemBytes, "field_backward")) return e;
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
-    if (g->out16) hipLaunchKernelGGL(k_field_backward<true>, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
+    if (g->out16 == 2) {      // the whole chain on the f16 matrix pipe: bwd_stream holds gf_field_bwd16_stream_halves() binary16 values
+        static GfLdsAttr lds16;
+        if (const int e = gf_raise_lds_limit(lds16, reinterpret_cast<const void*>(k_field_backward16), kSmemBytes, "field_backward")) return e;
+        hipLaunchKernelGGL(k_field_backward16, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
+    } else if (g->out16) hipLaunchKernelGGL(k_field_backward<true>, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
     else hipLaunchKernelGGL(k_field_backward<false>, dim3(chunks < 512u ? chunks : 512u), dim3(kThreads), kSmemBytes, gf_stream(stream), ha, ba);
     return gf_check_launch("field_backward");
 }

@@ -84,6 +84,7 @@ class RADNeRF(NeRFRenderer):
     #: under torch.autocast(float16): "f16" = the fused field on the f16 matrix pipe (train_field._HeadFieldAMP: the arithmetic of the
     #: reference's AMP training, base.yaml:49), "f32" = the exact-fp32 node even under autocast (custom_fwd(cast_inputs=float32), round 5)
     amp_field = "f16"
+    amp_backward = "f16"      # the AMP node's dX chain: "f16" (k_field_backward16) or "f32" (the fp32 chain writing binary16 rows)
 
     def forward(self, position, direction, cond_feat, individual_code):
         if self._fused_field_ok(position):

@@ -62,6 +62,29 @@ def _bwd_stream_index(shapes):
     return torch.from_numpy(idx.reshape(-1))
 
 
+def _bwd16_stream_index(shapes):
+    """The same six transposed blocks for the f16 chain (k_field_backward16): [wave 4][layer 6][group 8][lane 64][8] halves, element =
+    Wt[32 wave + (lane & 31)][16 group + 8 (lane >> 5) + i]; indices into cat([0], weights) as in _bwd_stream_index."""
+    names = ["a1", "a2", "a3", "s1", "s2", "s3", "c1", "c2"]
+    base, off = {}, 1
+    for n, shp in zip(names, shapes):
+        base[n] = (off, shp)
+        off += shp[0] * shp[1]
+    layers = [("c1", 0, 16, 128), ("s3", 1, 0, 128), ("s2", 0, 0, 128), ("s1", 0, 0, 64), ("a2", 0, 0, 128), ("a1", 0, 0, 32)]
+    w = np.arange(4).reshape(4, 1, 1, 1, 1)
+    u = np.arange(8).reshape(1, 1, 8, 1, 1)
+    l = np.arange(64).reshape(1, 1, 1, 64, 1)
+    i = np.arange(8).reshape(1, 1, 1, 1, 8)
+    n = 32 * w + (l & 31)
+    o = 16 * u + 8 * (l >> 5) + i
+    idx = np.zeros((4, 6, 8, 64, 8), dtype=np.int64)
+    for k, (name, o0, n0, width) in enumerate(layers):
+        b0, (rows, cols) = base[name]
+        src = b0 + (o0 + o) * cols + (n0 + n)
+        idx[:, k] = np.where(np.broadcast_to(n < width, src.shape), src, 0)[:, 0]
+    return torch.from_numpy(idx.reshape(-1))
+
+
 def _tall_tn(g, x, out_dtype=None):
     """g^T @ x for g [M,O], x [M,I] with M ~ 10^6: batched partial products + a sum (see cond_encoder._linear_tall).
     out_dtype: the partial products are added (and returned) in this dtype -- the AMP tier multiplies half operands and adds in fp32."""
@@ -227,9 +250,10 @@ class _HeadFieldAMP(torch.autograd.Function):
     (egs/egs_bases/radnerf/base.yaml:49 amp: true; utils/commons/trainer.py:307-382 autocast + GradScaler) runs its Linear layers in half:
     operands f16, accumulation fp32, master weights fp32, loss scaling outside.  Here: forward = gf_field_forward_train16 (f16 MFMA operands
     re-gathered from the fp32 master weights on the device, fp32 accumulators, fp32 outputs, every layer's activations saved as BINARY16 --
-    half the save traffic of the fp32 node); backward = the fp32 dX chain over the masks, writing its six [M,128] pre-activation gradients
-    as binary16 (gf_field_grads_t.out16) so that the weight-gradient products run on half operands like autocast's own; tables, column
-    sums, skinny layers and every returned gradient stay fp32.  A scaled loss whose gradients leave the f16 range gives inf there, which
+    half the save traffic of the fp32 node); backward = the dX chain on the f16 matrix pipe as well (k_field_backward16: transposed f16
+    blocks, binary16 gradient rows in LDS, fp32 accumulators / masks / column sums / skinny transposes / lookup gradient / grid-feature
+    gradients), writing its six [M,128] pre-activation gradients as binary16 so that the weight-gradient products run on half operands
+    like autocast's own; every returned gradient is fp32.  `model.amp_backward = "f32"` keeps the fp32 chain (binary16 outputs only).  A scaled loss whose gradients leave the f16 range gives inf there, which
     is what GradScaler looks for (it skips the step and lowers the scale), exactly as with the reference's half Linear layers."""
 
     @staticmethod
@@ -291,10 +315,17 @@ class _HeadFieldAMP(torch.autograd.Function):
         g_amb = g_amb.float().contiguous() if g_amb is not None else z(M, 2)
         cond = cond_feat.reshape(-1).float()
         st = fused.get_state(model)
-        if getattr(st, "_bwd_idx", None) is None:
-            st._bwd_idx = _bwd_stream_index([tuple(w.shape) for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)]).to(dev)
+        f16_chain = getattr(model, "amp_backward", "f16") == "f16"      # "f32": the fp32 dX chain writing binary16 rows (stage 1 of round 6)
         flat = torch.cat([z(1)] + [w.detach().reshape(-1).float() for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)])
-        stream = flat[st._bwd_idx]
+        if f16_chain:
+            if getattr(st, "_bwd16_idx", None) is None:
+                st._bwd16_idx = _bwd16_stream_index([tuple(w.shape) for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)]).to(dev)
+                assert st._bwd16_idx.numel() == lib().gf_field_bwd16_stream_halves()
+            stream = flat.half()[st._bwd16_idx]
+        else:
+            if getattr(st, "_bwd_idx", None) is None:
+                st._bwd_idx = _bwd_stream_index([tuple(w.shape) for w in (wa1, wa2, wa3, ws1, ws2, ws3, wc1, wc2)]).to(dev)
+            stream = flat[st._bwd_idx]
         out = {n: torch.empty(M, 128, **f16) for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1")}
         out.update({n: torch.empty(M, w, **f32) for n, w in (("g_zc", 3), ("g_za", 2), ("g_f3", 32), ("g_f2", 32))})
         out["g_h0"] = torch.empty(M, **f32)
@@ -310,8 +341,8 @@ class _HeadFieldAMP(torch.autograd.Function):
             f.head_pack = ptr(st.head_pack)
             g = GfFieldGrads(g_sigma=g_sigma.data_ptr(), g_rgb=g_rgb.data_ptr(), g_amb=g_amb.data_ptr(), sigma=sigma.data_ptr(), rgb=rgb.data_ptr(),
                              amb=amb.data_ptr(), m_hc1=m_hc1.data_ptr(), m_hs2=m_hs2.data_ptr(), m_hs1=m_hs1.data_ptr(), m_ha2=m_ha2.data_ptr(),
-                             m_ha1=m_ha1.data_ptr(), level_max=level_max.data_ptr(), out16=1, **{n: t.data_ptr() for n, t in out.items()})
-            check(lib().gf_field_backward(C.byref(f), ptr(stream, torch.float32), M, C.byref(g), current_stream(dev)))
+                             m_ha1=m_ha1.data_ptr(), level_max=level_max.data_ptr(), out16=2 if f16_chain else 1, **{n: t.data_ptr() for n, t in out.items()})
+            check(lib().gf_field_backward(C.byref(f), ptr(stream), M, C.byref(g), current_stream(dev)))
         g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
         # ---- weight gradients: half x half products (fp32 accumulation inside the GEMM), partial sums added in fp32

@@ -324,9 +324,13 @@ typedef struct gf_field_grads {
     float* s_hc1; float* s_ha1;                                     /* out, ZEROED by the caller: [128] column sums of g_hc1 / g_ha1 over the points */
     uint32_t* level_max;                                            /* out or NULL, ZEROED by the caller: [2][16] max |g_f3| (first 16) and |g_f2| per level,
                                                                        as bit patterns of non-negative floats: what gf_grid_encode_backward_scaled takes */
-    uint32_t out16; uint32_t _pad;                                  /* 1: the six [M,128] outputs are binary16 (AMP tier: half operands for the weight-gradient products) */
+    uint32_t out16; uint32_t _pad;                                  /* 1: the six [M,128] outputs are binary16 (AMP tier: half operands for the weight-gradient
+                                                                       products); 2: also the chain itself on the f16 matrix pipe -- bwd_stream then points at
+                                                                       gf_field_bwd16_stream_halves() binary16 values: the same six transposed blocks as
+                                                                       [wave 4][layer 6][group 8][lane 64][8], element = Wt[32 wave + (lane & 31)][16 group + 8 (lane >> 5) + i] */
 } gf_field_grads_t;
 uint32_t gf_field_bwd_stream_floats(void);
+uint32_t gf_field_bwd16_stream_halves(void);
 int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
 /* gf_grid_encode_backward (gridencoder.cu:248-339) for a gradient already in [L, B, C] order whose per-level max |g| is known on the device
  * (level_max[L]; gf_field_backward produces both): the table scatter without its max pass; no input gradient.  D = 2 or 3. */

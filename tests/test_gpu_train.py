@@ -408,7 +408,8 @@ def test_fused_torso_field_vs_op_graph(M):
 
 
 # ----------------------------------------------------------------------------------------------- AMP training tier (round 6)
-def test_amp_field_node_vs_fp32_node():
+@pytest.mark.parametrize("backward", ["f16", "f32"])
+def test_amp_field_node_vs_fp32_node(backward):
     """Under torch.autocast(float16) the fused field runs on the f16 tier (train_field._HeadFieldAMP: f16 MFMA operands re-gathered from the
     fp32 master weights, fp32 accumulation, binary16 saves, half operands in the weight-gradient products) -- the arithmetic of the
     reference's AMP step (base.yaml:49 amp: true; trainer.py:307-382).  Against the exact-fp32 node on the same points: outputs and every
@@ -419,6 +420,7 @@ def test_amp_field_node_vs_fp32_node():
     model = RADNeRF(hp)
     model.load_state_dict(sd, strict=True)
     model = model.to(DEV).train()
+    model.amp_backward = backward      # the dX chain on the f16 matrix pipe (k_field_backward16), or the fp32 chain with binary16 outputs
     g = torch.Generator(device=DEV).manual_seed(3)
     M = 5000 + 77
     xyz = torch.rand(M, 3, device=DEV, generator=g) * 1.6 - 0.8

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--amp", action="store_true", help="fp16 autocast + GradScaler, as the May config trains (lm3d_radnerf.yaml:5 amp: true)")
     ap.add_argument("--amp-f32-field", action="store_true", help="--amp with the exact-fp32 field node under autocast (RADNeRF.amp_field = 'f32': round 5's "
                     "behaviour) instead of the f16 tier")
+    ap.add_argument("--amp-f32-backward", action="store_true", help="--amp with the fp32 dX chain (RADNeRF.amp_backward = 'f32': stage 1 of round 6)")
     ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
                     "only torso parameters in the optimizer (networks at lr, the 2-D grid at 10 lr), mse on rgb_map + the alpha entropy term, "
                     "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
@@ -48,6 +49,8 @@ def main():
     model = model.to(dev).train()
     if args.amp_f32_field:
         model.amp_field = "f32"
+    if args.amp_f32_backward:
+        model.amp_backward = "f32"
     seq = S.make_sequence(8, 512, 512, hp)
     poses = torch.from_numpy(seq["poses"]).to(dev)
     cond = torch.from_numpy(seq["cond_wins"]).to(dev)
