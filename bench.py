@@ -803,6 +803,9 @@ def compact_line(full, details_path):
                               "reference_kernels_ms_per_step": _r((tr.get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2),
                               "speedup_vs_reference_kernels": _r(tr.get("speedup_vs_reference_kernels"), 2), "error": tr.get("error"),
                               "roofline_frac": _r((tr.get("roofline") or {}).get("frac"), 3),
+                              "amp_ms_per_step": _r(tr.get("amp_ms_per_step"), 3),
+                              "amp_roofline_frac": _r(((tr.get("amp") or {}).get("roofline") or {}).get("frac"), 4),
+                              "amp_hbm_frac": _r((((tr.get("amp") or {}).get("roofline") or {}).get("hbm") or {}).get("frac"), 3),
                               "torso_ms_per_step": _r((tr.get("torso") or {}).get("ms_per_step"), 3),
                               "torso_reference_kernels_ms_per_step": _r(((tr.get("torso") or {}).get("reference_kernels_same_host_code") or {}).get("ms_per_step"), 2)}
     pr = full.get("per_rank")
@@ -1038,6 +1041,26 @@ def train_step_leg(args, job):
         out["roofline"] = {"bound": "mfma", "dtype": "f32", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
                            "flop_per_step": 3 * FLOP_PER_HEAD_SAMPLE * prod["points_last_step"],
                            "note": "3 x 178 688 FLOP per evaluated point (forward, dX chain, dW products) / the WHOLE step's time"}
+    # the same step as the May config really trains it (egs/egs_bases/radnerf/base.yaml:49 amp: true; utils/commons/trainer.py:307-382: fp16
+    # autocast + GradScaler): the field's forward, dX chain and weight-gradient products on the f16 matrix pipe (round 6), master weights,
+    # accumulators, tables, marcher, compositor and Adam in fp32
+    amp = run(os.path.join(ROOT, "tools", "bench_train.py"), "--amp")
+    out["amp_ms_per_step"] = amp.get("ms_per_step")
+    out["amp"] = {"ms_per_step": amp.get("ms_per_step"), "steps_per_s": amp.get("value"), "workload": amp.get("metric"), "error": amp.get("error"),
+                  "points_last_step": amp.get("points_last_step"), "tier": amp.get("amp"), "hours_for_250k_steps": amp.get("hours_for_250k_steps")}
+    if amp.get("ms_per_step") and amp.get("points_last_step"):
+        tf = 3 * FLOP_PER_HEAD_SAMPLE * amp["points_last_step"] / (amp["ms_per_step"] * 1e-3) / 1e12
+        # what the field's three passes must move per evaluated point at least (binary16 saves written once and read once by the weight-
+        # gradient kernel, the six gradient rows likewise, masks, the grid feature gradients, inputs / outputs): csrc/field_wgrad.hip's header
+        bytes_pt = 2 * (848 * 2) + 2 * (6 * 256) + 2 * 80 + 2 * 256 + 96
+        gbs = bytes_pt * amp["points_last_step"] / (amp["ms_per_step"] * 1e-3) / 1e9
+        out["amp"]["roofline"] = {"bound": "mfma", "dtype": "f16 operands, fp32 accumulate", "achieved": tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": tf / PEAK_F16_MFMA_TFLOPS, "flop_per_step": 3 * FLOP_PER_HEAD_SAMPLE * amp["points_last_step"],
+                                  "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                          "algorithmic_bytes_per_point": bytes_pt},
+                                  "note": "3 x 178 688 FLOP per evaluated point / the WHOLE step's time.  Neither roof binds the step: the field's "
+                                          "forward and dX chain are VALU-issue bound like the inference fast tier (issue_roofline), the table scatter "
+                                          "is LDS-atomic bound, the weight-gradient kernel alone is HBM-bound (NOTES 10.4)"}
     # the TORSO task's step (tasks/radnerfs/radnerf_torso.py:74-122: head frozen, torso field trained; round 6: the field as one autograd node)
     tor = run(os.path.join(ROOT, "tools", "bench_train.py"), "--torso")
     out["torso"] = {"ms_per_step": tor.get("ms_per_step"), "steps_per_s": tor.get("value"), "workload": tor.get("metric"), "error": tor.get("error"),

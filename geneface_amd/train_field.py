@@ -37,6 +37,13 @@ class GfFieldGrads(C.Structure):
                [("out16", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class GfFieldWgrad(C.Structure):
+    """ctypes mirror of gf_field_wgrad_t."""
+    _fields_ = [(n, _vp) for n in ("f3", "ha1", "ha2", "f2", "hs1", "hs2", "geo", "hc1", "sh", "g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1",
+                                   "g_zc", "g_h0", "g_za", "gw_color1", "gw_color0", "gw_sigma2", "gw_sigma1", "gw_sigma0", "gw_ambient2", "gw_ambient1",
+                                   "gw_ambient0")] + [("ld_color0", C.c_uint32), ("ld_ambient0", C.c_uint32), ("workspace", _vp)]
+
+
 def _bwd_stream_index(shapes):
     """Index map of gf_field_backward's A-operand stream into cat([0], W_a1, W_a2, W_a3, W_s1, W_s2, W_s3, W_c1, W_c2) (1-based, 0 = zero
     padding): six transposed 128 x 128 blocks, element [wave][layer][group][lane][i] = Wt[32 wave + (lane & 31)][8 group + 4 (lane >> 5) + i]
@@ -345,22 +352,44 @@ class _HeadFieldAMP(torch.autograd.Function):
             check(lib().gf_field_backward(C.byref(f), ptr(stream), M, C.byref(g), current_stream(dev)))
         g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
-        # ---- weight gradients: half x half products (fp32 accumulation inside the GEMM), partial sums added in fp32
-        tn = lambda gg, xx: _tall_tn(gg.half() if gg.dtype != torch.float16 else gg, xx, out_dtype=torch.float32)
+        # ---- weight gradients: the eight tall products G^T X (half operands, fp32 accumulation) in one launch + one fixed-order reduction
+        # (gf_field_wgrad16, csrc/field_wgrad.hip; `model.amp_wgrad = "gemm"` keeps round 6 stage 2's batched library products)
         s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
-        g_wc2 = tn(g_zc, hc1)
-        parts = [tn(g_hc1, sh), tn(g_hc1, geo)]
         g_code = None
+        if getattr(model, "amp_wgrad", "fused") == "fused":
+            if getattr(st, "_wgrad_ws", None) is None:
+                st._wgrad_ws = torch.empty(lib().gf_field_wgrad16_ws_bytes() // 4, **f32)
+            g_wc2, g_wc1, g_ws3, g_ws2, g_ws1, g_wa3, g_wa2, g_wa1 = (torch.empty(w.shape, **f32) for w in (wc2, wc1, ws3, ws2, ws1, wa3, wa2, wa1))
+            wg = GfFieldWgrad(**{n: t.data_ptr() for n, t in (("f3", f3), ("ha1", ha1), ("ha2", ha2), ("f2", f2), ("hs1", hs1), ("hs2", hs2), ("geo", geo),
+                                                              ("hc1", hc1), ("sh", sh), ("g_hc1", g_hc1), ("g_geo", g_geo), ("g_hs2", g_hs2), ("g_hs1", g_hs1),
+                                                              ("g_ha2", g_ha2), ("g_ha1", g_ha1), ("g_zc", g_zc), ("g_h0", g_h0), ("g_za", g_za),
+                                                              ("gw_color1", g_wc2), ("gw_color0", g_wc1), ("gw_sigma2", g_ws3), ("gw_sigma1", g_ws2),
+                                                              ("gw_sigma0", g_ws1), ("gw_ambient2", g_wa3), ("gw_ambient1", g_wa2), ("gw_ambient0", g_wa1),
+                                                              ("workspace", st._wgrad_ws))},
+                              ld_color0=wc1.shape[1], ld_ambient0=wa1.shape[1])
+            assert tuple(wc2.shape) == (3, 128) and wc1.shape[0] == 128 and tuple(ws3.shape) == (129, 128) and tuple(ws2.shape) == (128, 128) and \
+                tuple(ws1.shape) == (128, 64) and tuple(wa3.shape) == (2, 128) and tuple(wa2.shape) == (128, 128) and wa1.shape[0] == 128
+            check(lib().gf_field_wgrad16(M, C.byref(wg), current_stream(dev)))
+            if ctx.has_code:
+                g_wc1[:, 144:] = torch.outer(s_hc1, ind_code.reshape(-1).float())
+            elif wc1.shape[1] > 144:
+                g_wc1[:, 144:] = 0
+            g_wa1[:, 32:] = torch.outer(s_ha1, cond)
+        else:
+            tn = lambda gg, xx: _tall_tn(gg.half() if gg.dtype != torch.float16 else gg, xx, out_dtype=torch.float32)
+            g_wc2 = tn(g_zc, hc1)
+            parts = [tn(g_hc1, sh), tn(g_hc1, geo)]
+            if ctx.has_code:
+                parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
+            g_wc1 = torch.cat(parts, dim=1)
+            g_ws3 = torch.cat([tn(g_h0.unsqueeze(1), hs2), tn(g_geo, hs2)], dim=0)
+            g_ws2 = tn(g_hs2, hs1)
+            g_ws1 = torch.cat([tn(g_hs1, f3), tn(g_hs1, f2)], dim=1)
+            g_wa3 = tn(g_za, ha2)
+            g_wa2 = tn(g_ha2, ha1)
+            g_wa1 = torch.cat([tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         if ctx.has_code:
-            parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
             g_code = (s_hc1 @ wc1[:, 144:].float()).view_as(ind_code)
-        g_wc1 = torch.cat(parts, dim=1)
-        g_ws3 = torch.cat([tn(g_h0.unsqueeze(1), hs2), tn(g_geo, hs2)], dim=0)
-        g_ws2 = tn(g_hs2, hs1)
-        g_ws1 = torch.cat([tn(g_hs1, f3), tn(g_hs1, f2)], dim=1)
-        g_wa3 = tn(g_za, ha2)
-        g_wa2 = tn(g_ha2, ha1)
-        g_wa1 = torch.cat([tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         g_cond = (s_ha1 @ wa1[:, 32:].float()).view_as(cond_feat).to(cond_feat.dtype)
         lm = level_max if M > 0 else None
         g_amb_tab, _ = _grid_backward(model.ambient_embedder, (amb + 1) / 2, out["g_f2"], False, level_major=True, level_max=None if lm is None else lm[16:])

@@ -332,6 +332,25 @@ typedef struct gf_field_grads {
 uint32_t gf_field_bwd_stream_floats(void);
 uint32_t gf_field_bwd16_stream_halves(void);
 int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, uint32_t M, const gf_field_grads_t* g, void* stream);
+/* The weight gradients of the same field on the AMP tier (round 6): the eight tall products dW = G^T X that autograd derives for the Linear
+ * layers of radnerf.py:73-105 (cond_encoder.py:106-111) under the trainer's autocast (utils/commons/trainer.py:307-382: half operands, fp32
+ * accumulation), in one launch + one fixed-order reduction -- every binary16 row read once.  In: the nine binary16 saves of
+ * gf_field_forward_train16, the six binary16 [M,128] pre-activation gradients of gf_field_backward (out16 != 0) and its fp32 g_zc [M,3],
+ * g_h0 [M], g_za [M,2] (rounded to binary16 inside, as a half GEMM operand would be).  Out (fp32, fully written for the listed blocks):
+ *   gw_color1 [3,128]; gw_color0 [128, ld_color0] columns 0..143 (SH | geometry feature; the identity-code columns are the caller's outer
+ *   product); gw_sigma2 [129,128] (row 0 = the density row); gw_sigma1 [128,128]; gw_sigma0 [128,64] (3-D | 2-D grid features);
+ *   gw_ambient2 [2,128]; gw_ambient1 [128,128]; gw_ambient0 [128, ld_ambient0] columns 0..31 (the condition columns are the caller's).
+ * workspace: gf_field_wgrad16_ws_bytes() bytes of device scratch.  The result does not depend on the run (no atomics). */
+typedef struct gf_field_wgrad {
+    const void* f3; const void* ha1; const void* ha2; const void* f2; const void* hs1; const void* hs2; const void* geo; const void* hc1; const void* sh;
+    const void* g_hc1; const void* g_geo; const void* g_hs2; const void* g_hs1; const void* g_ha2; const void* g_ha1;
+    const float* g_zc; const float* g_h0; const float* g_za;
+    float* gw_color1; float* gw_color0; float* gw_sigma2; float* gw_sigma1; float* gw_sigma0; float* gw_ambient2; float* gw_ambient1; float* gw_ambient0;
+    uint32_t ld_color0; uint32_t ld_ambient0;
+    float* workspace;
+} gf_field_wgrad_t;
+uint64_t gf_field_wgrad16_ws_bytes(void);
+int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stream);
 /* gf_grid_encode_backward (gridencoder.cu:248-339) for a gradient already in [L, B, C] order whose per-level max |g| is known on the device
  * (level_max[L]; gf_field_backward produces both): the table scatter without its max pass; no input gradient.  D = 2 or 3. */
 int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
