@@ -406,6 +406,7 @@ def head_field(model, position, direction, cond_feat, individual_code):
     node = _HeadField
     if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16 and getattr(model, "amp_field", "f16") == "f16":
         node = _HeadFieldAMP
+    model._last_field_node = "amp_f16" if node is _HeadFieldAMP else "f32"      # which arithmetic the last call ran in (tests assert the tier)
     return node.apply(model, position, direction, cond_feat, individual_code, model.position_embedder.embeddings,
                             model.ambient_embedder.embeddings, a[0].weight, a[1].weight, a[2].weight, s[0].weight, s[1].weight, s[2].weight,
                             c[0].weight, c[1].weight)

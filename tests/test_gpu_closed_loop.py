@@ -74,7 +74,7 @@ def _optimizer(model, lr=5e-4):
     return opt
 
 
-def _train(model, hp, seq, poses, cond, bg, bgc, targets, steps, n_rays=8192):
+def _train(model, hp, seq, poses, cond, bg, bgc, targets, steps, n_rays=8192, amp=False):
     """The task's step (radnerf.py:185-216) `steps` times; every random draw (pixel choice, march jitter, grid jitter, the window
     update_extra_state picks) comes from generators seeded here, so two runs over different kernels see the same draws."""
     import random
@@ -85,6 +85,8 @@ def _train(model, hp, seq, poses, cond, bg, bgc, targets, steps, n_rays=8192):
     model.conds = cond[:, cond.shape[1] // 2]
     model.mark_untrained_grid(poses, seq["intrinsics"])
     opt = _optimizer(model)
+    # amp: the Trainer's autocast + GradScaler around the same step (utils/commons/trainer.py:307-382; base.yaml:49 amp: true)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=amp)
     losses = []
     for i in range(steps):
         if i % hp["update_extra_interval"] == 0:
@@ -92,14 +94,18 @@ def _train(model, hp, seq, poses, cond, bg, bgc, targets, steps, n_rays=8192):
         f = i % T
         rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], SIZE, SIZE, n_rays)
         sel = rays["inds"][0]
-        out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel], perturb=True,
-                           force_all_rays=False, **hp)
-        mse = ((out["rgb_map"] - targets[f:f + 1, sel]) ** 2).mean()
-        loss = mse + 1e-3 * out["ambient"].abs().mean()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel], perturb=True,
+                               force_all_rays=False, **hp)
+            mse = ((out["rgb_map"].float() - targets[f:f + 1, sel]) ** 2).mean()
+            loss = mse + 1e-3 * out["ambient"].float().abs().mean()
         opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
         losses.append(float(mse))
+    if amp:
+        assert scaler.get_scale() >= 1024.0, "a step was skipped (non-finite gradients at the initial scale)"
     model.update_extra_state(generator=gen)      # the bitfield the checkpoint carries belongs to the final weights
     return losses, opt
 
@@ -238,6 +244,39 @@ def test_train_refresh_checkpoint_reload_render(tmp_path, monkeypatch):
         # and the trained student does look like the teacher now (it is a 300-step fit, not a converged one: a loose bar)
         assert float(((out - targets[i].cpu()) ** 2).mean()) < 2.0 * np.mean(losses[-16:]) + 1e-3
     print(f"closed loop: mse {np.mean(losses[:16]):.4g} -> {np.mean(losses[-16:]):.4g} (x{fall:.3f}); trained-weights parity {worst:.3g}")
+
+
+def test_amp_loop_follows_the_fp32_loop():
+    """VERDICT r5 next #3, the closed-loop half: the same student, the same draws, 128 steps of the task's loop under fp16 autocast + GradScaler
+    on the product's AMP tier (field forward, dX chain and weight gradients on the f16 matrix pipe) against the fp32 loop.  Gated like the
+    comparison with the reference's kernels above: step 0 within fp16 noise, the 32-step windows of the first 64 steps within 10 % (the third 25 %), the
+    same >= 10-fold fall over those steps (within 10 % in decades), and no skipped step."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    hp = HP.may_hparams(False)
+    seq = S.make_sequence(T, SIZE, SIZE, hp)
+    poses, cond, bg, bgc, targets = _teacher_targets(hp, seq)
+    curves = {}
+    for amp in (False, True):
+        student = _student(hp)
+        curves[amp], _ = _train(student, hp, seq, poses, cond, bg, bgc, targets, 128, amp=amp)
+        assert all(np.isfinite(curves[amp]))
+        if amp:
+            assert student._last_field_node == "amp_f16"
+    a, b = curves[True], curves[False]
+    rec = {"amp_mse": a, "fp32_mse": b, "windows": [float(np.mean(a[k:k + 32]) / np.mean(b[k:k + 32])) for k in range(0, 128, 32)]}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "closed_loop_amp_loss_curves.json"), "w") as f:
+            json.dump(rec, f)
+    print("AMP loop / fp32 loop, mse per 32-step window:", rec["windows"])
+    assert abs(a[0] / b[0] - 1.0) < 2e-2
+    # two runs on the MI355X (r6h): windows [1.025, 1.022, 1.009, 1.12] and [1.024, 1.025, 1.089, 1.012] -- the first 64 steps are tight, after
+    # that either curve may take a refresh transient the other does not (the fp32 loop against ITSELF does the same, see above)
+    assert abs(rec["windows"][0] - 1.0) < 0.10 and abs(rec["windows"][1] - 1.0) < 0.10, rec["windows"]
+    assert abs(rec["windows"][2] - 1.0) < 0.25, rec["windows"]
+    fa, fb = float(np.mean(a[64:96]) / np.mean(a[:16])), float(np.mean(b[64:96]) / np.mean(b[:16]))
+    assert fa < 0.1 and fb < 0.1 and abs(np.log(fa) / np.log(fb) - 1.0) < 0.10, (fa, fb)
 
 
 # ----------------------------------------------------------------------------------------------- the torso stage (round 6, VERDICT r5 next #2)

@@ -157,6 +157,62 @@ def test_reference_training_step_under_autocast_over_compat(ref):
     assert scaler.get_scale() >= 1024.0
 
 
+def test_product_amp_step_vs_reference_python_under_autocast(ref):
+    """the product's AMP tier (geneface_amd RADNeRF under torch.autocast(float16): the field's forward, dX chain and
+    weight-gradient products on the f16 matrix pipe, fp32 master weights / accumulators / tables) against the REFERENCE'S OWN Python under the
+    same autocast over compat (its Linear layers in half through torch, its grid wrapper handing half tables: grid.py:41-44), same weights,
+    same rays, same loss, same GradScaler scale.  Two half-precision evaluations of one function: image within fp16 noise, and every trained
+    tensor's gradient no further from the fp32 oracle's than the reference's own half arithmetic puts it."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    rmodel, hp, sd = ref(False, train=True)
+    ohp = model_fixture(False)[0]
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8))
+    sd_g = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith(("aabb", "density")) else v) for k, v in sd.items()}
+    want = R.render_train(sd_g, ohp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=False)
+    _loss(want, target).backward()
+    pmodel = RADNeRF(ohp)
+    pmodel.load_state_dict(sd, strict=True)
+    pmodel = pmodel.to(DEV).train()
+    grads, imgs = {}, {}
+    for tag, model, h in (("reference", rmodel, hp), ("product", pmodel, ohp)):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = _render(model, h, fi)
+            loss = _loss(out, target.to(DEV))
+        (loss * 1024.0).backward()
+        imgs[tag] = out["rgb_map"].detach().float().cpu()
+        grads[tag] = {n: (p.grad.detach().float().cpu().double() / 1024.0) for n, p in model.named_parameters() if p.grad is not None}
+    assert pmodel._last_field_node == "amp_f16"        # the f16 tier did run (not the exact-fp32 node, not the op graph)
+    assert (imgs["product"] - imgs["reference"]).abs().max() < 3e-2
+    assert (imgs["product"] - want["rgb_map"].detach()).abs().max() < 3e-2
+    assert set(grads["product"]) == set(grads["reference"]) and len(grads["product"]) >= 20
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-20))
+    report = {}
+    for n, gr in grads["reference"].items():
+        gp, go = grads["product"][n], sd_g[n].grad.double()
+        report[n] = (rel(gp, gr), rel(gp, go), rel(gr, go))
+        assert torch.isfinite(gp).all(), n
+    print("AMP step, relative L2 (product vs reference-autocast, product vs fp32 oracle, reference-autocast vs fp32 oracle):")
+    for n, v in report.items():
+        print(f"  {n:44s} {v[0]:.3e} {v[1]:.3e} {v[2]:.3e}")
+    # What half arithmetic does to THIS step (measured on the MI355X, round 6, visit r6h): the reference's own autocast step is 9-12 % away
+    # from the fp32 oracle on both tables and the ambient net (the ambient coordinate feeds a 2-D hash lookup: a rounding of the coordinate
+    # moves the cell), 12-14 % on the condition pre-net behind it, and 20-97 % on the attention net, whose gradients underflow binary16 at
+    # this loss scale; 0.5-1.2 % on the sigma / colour nets.  The product's tier is as close or closer to fp32 on every field tensor (6-7 %
+    # where the reference has 9-12 %).  So the bar is the reference's own distance from fp32, not a constant: every field tensor no further
+    # than 1.5 x that (+ 5e-3), the condition networks -- torch modules under autocast on both sides, fed by d cond_feat -- no further than
+    # 2 x (+ 2e-2), and product vs reference inside the triangle both distances span.
+    field = ("embedder", "_net.net.", "individual_embeddings")
+    for n, (pr, po, ro) in report.items():
+        if any(k in n for k in field) and "cond" not in n:
+            assert po < 1.5 * ro + 5e-3, (n, po, ro)
+        else:
+            assert po < 2.0 * ro + 2e-2, (n, po, ro)
+        assert pr < 1.05 * (po + ro) + 1e-6, (n, pr, po, ro)
+
+
 def test_autocast_step_costs_what_the_fp32_step_costs(ref):
     """Seam 1 under autocast: the compat grid encoder reads the half table the reference's wrapper hands it as it is (gf_grid_encode_forward_f16)
     and the backward no longer touches the table at all -- until round 4 every call converted the whole 6.9 MB table to fp32 and back.
