@@ -2736,6 +2736,33 @@ __global__ void __launch_bounds__(256) k_ctrl_clear(uint32_t* __restrict__ ctrl,
     for (uint32_t i = threadIdx.x; i < words; i += 256) ctrl[i] = 0u;
 }
 
+#ifdef GF_CUMASK
+// A/B build only (tools/cumask_ab.py): GF_CUMASK_RESERVE = R keeps the persistent head grids OFF R compute units, so the
+// small kernels of the frames in flight (k_frame_init, the condition encoder, the torso launches -- all still on the caller's unmasked stream)
+// always find R CUs with free registers.  The two phase kernels go to a stream created with a CU mask (one per caller stream), ordered with
+// the caller's by events; their grid is 2 workgroups per CU they may use.  GF_CUMASK_HIGH=1 takes the R HIGHEST mask bits instead of the lowest.
+struct MaskedStream { hipStream_t caller, head; hipEvent_t e_init, e_head; };
+static MaskedStream g_masked[16];
+static int g_n_masked = 0, g_reserve = -1;
+static MaskedStream* masked_stream_for(hipStream_t s) {
+    if (g_reserve < 0) { const char* e = getenv("GF_CUMASK_RESERVE"); g_reserve = e ? atoi(e) : 0; if (g_reserve < 0 || g_reserve > 128) g_reserve = 0; }
+    if (g_reserve == 0) return nullptr;
+    for (int i = 0; i < g_n_masked; i++) if (g_masked[i].caller == s) return &g_masked[i];
+    if (g_n_masked == 16) return nullptr;
+    MaskedStream& m = g_masked[g_n_masked];
+    uint32_t mask[8];
+    for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
+    const char* hi = getenv("GF_CUMASK_HIGH");
+    for (int b = 0; b < g_reserve; b++) { const int bit = (hi && atoi(hi)) ? 255 - b : b; mask[bit >> 5] &= ~(1u << (bit & 31)); }
+    if (hipExtStreamCreateWithCUMask(&m.head, 8, mask) != hipSuccess) return nullptr;
+    (void)hipEventCreateWithFlags(&m.e_init, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&m.e_head, hipEventDisableTiming);
+    m.caller = s;
+    g_n_masked++;
+    return &m;
+}
+#endif
+
 int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 6 events around the two phase kernels (0..3) and k_frame_init (4, 5) */) {
     const gf::FrameWs w = gf::carve_workspace(f->workspace, f->n_rays);
     const uint32_t N = f->n_rays;
@@ -2807,15 +2834,32 @@ int launch_head(const gf_frame_t* f, hipStream_t s, hipEvent_t* ev /* nullable: 
 #ifdef GF_DIAG
     if (g_diag_cfg[2] >= 1 && g_diag_cfg[2] <= 512) grid = g_diag_cfg[2];
 #endif
+    hipStream_t hs = s;
+#ifdef GF_CUMASK
+    MaskedStream* ms = ev ? nullptr : masked_stream_for(s);
+    if (ms) {
+        hs = ms->head;
+        const uint32_t g = 2u * (256u - (uint32_t)g_reserve);
+        if (grid > g) grid = g;
+        (void)hipEventRecord(ms->e_init, s);
+        (void)hipStreamWaitEvent(hs, ms->e_init, 0);
+    }
+#endif
     for (uint32_t phase = 0; phase < 2; phase++) {
         ha.phase = phase;
         ha.queue = phase ? w.alive_a : w.alive_b;
         if (ev) (void)hipEventRecord(ev[2 * phase], s);
-        if (mode == 1) hipLaunchKernelGGL(k_head_phase<1>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
-        else if (mode == 2) hipLaunchKernelGGL(k_head_phase<2>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
-        else hipLaunchKernelGGL(k_head_phase<0>, dim3(grid), dim3(kThreads), kSmemBytes, s, ha);
+        if (mode == 1) hipLaunchKernelGGL(k_head_phase<1>, dim3(grid), dim3(kThreads), kSmemBytes, hs, ha);
+        else if (mode == 2) hipLaunchKernelGGL(k_head_phase<2>, dim3(grid), dim3(kThreads), kSmemBytes, hs, ha);
+        else hipLaunchKernelGGL(k_head_phase<0>, dim3(grid), dim3(kThreads), kSmemBytes, hs, ha);
         if (ev) (void)hipEventRecord(ev[2 * phase + 1], s);
     }
+#ifdef GF_CUMASK
+    if (ms) {
+        (void)hipEventRecord(ms->e_head, hs);
+        (void)hipStreamWaitEvent(s, ms->e_head, 0);
+    }
+#endif
     return gf_check_launch("render_head");
 }
 
