@@ -30,9 +30,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int kThreads = 256;
 constexpr int kR = 32;             // rows per stage
 constexpr int kGroups = 5;
-constexpr int kWS = 160;           // halves per LDS row of a 128-wide operand: 80 dwords, so the four rows x 64 B a transposing read's half-wave
-                                   // touches fall on 4 x 16 distinct banks
-constexpr int kNS = 32;            // halves per LDS row of a narrow operand (<= 32 columns): 16 dwords, the same property without padding
+// LDS row strides in elements.  binary16: 160 halves = 80 dwords for a 128-wide operand, so the four rows x 64 B a transposing read's half-wave
+// touches fall on 4 x 16 distinct banks; 32 halves for a narrow one (<= 32 columns: 16 dwords, the same property without padding).
+// fp32 (ds_read_b32, 32 lanes = one row's 32 consecutive floats per pass): no padding needed.
+template <class E> constexpr int kWS = sizeof(E) == 2 ? 160 : 128;
+template <class E> constexpr int kNS = 32;
+template <class E> constexpr int kEPC = 16 / (int)sizeof(E);     // elements per 16-byte chunk
 constexpr int kMaxTiles = 6;       // accumulator tiles per wave, the largest group
 
 // sources, in the order of WgArgs::src
@@ -40,7 +43,7 @@ enum { S_F3, S_HA1, S_HA2, S_F2, S_HS1, S_HS2, S_GEO, S_HC1, S_SH, S_G_HC1, S_G_
 enum { K_G_ZC, K_G_H0, K_G_ZA, K_COUNT };
 
 struct WgArgs {
-    const _Float16* src[S_COUNT];
+    const void* src[S_COUNT];         // binary16 (k_field_wgrad<_Float16>) or fp32 (k_field_wgrad<float>) row-major matrices
     const float* skinny[K_COUNT];
     float* ws;
     uint32_t M;
@@ -78,32 +81,33 @@ template <> struct Desc<4> {   // ambient net: g_ha2 x ha1 -> dW_ambient1;  g_za
     static constexpr int PA[1] = {0}, PB[1] = {1}, PN[1] = {4};
 };
 
-template <class D> constexpr int lds_stride(int s) { return D::W[s] == 128 ? kWS : kNS; }
-template <class D> constexpr int lds_offset(int s) {            // halves
+template <class D, class E> constexpr int lds_stride(int s) { return D::W[s] == 128 ? kWS<E> : kNS<E>; }
+template <class D, class E> constexpr int lds_offset(int s) {            // elements
     int o = 0;
-    for (int i = 0; i < s; i++) o += kR * lds_stride<D>(i);
+    for (int i = 0; i < s; i++) o += kR * lds_stride<D, E>(i);
     return o;
 }
-template <class D> constexpr int lds_halves() { return lds_offset<D>(D::NS) + (D::SKC ? kR * kNS : 0); }
+template <class D, class E> constexpr int lds_elems() { return lds_offset<D, E>(D::NS) + (D::SKC ? kR * kNS<E> : 0); }
 template <class D> constexpr int n_tiles() {
     int n = D::SKC ? 1 : 0;
     for (int p = 0; p < D::NP; p++) n += D::PN[p];
     return n;
 }
-template <class D> constexpr int chunks_per_thread(int s) { return (kR * D::W[s] / 8 + kThreads - 1) / kThreads; }
-template <class D> constexpr int stage_regs() {
+template <class D, class E> constexpr int chunks_per_thread(int s) { return (kR * D::W[s] / kEPC<E> + kThreads - 1) / kThreads; }
+template <class D, class E> constexpr int stage_regs() {
     int n = 0;
-    for (int s = 0; s < D::NS; s++) n += chunks_per_thread<D>(s);
+    for (int s = 0; s < D::NS; s++) n += chunks_per_thread<D, E>(s);
     return n;
 }
-constexpr int kLdsHalves = [] {
-    int m = lds_halves<Desc<0>>();
-    if (lds_halves<Desc<1>>() > m) m = lds_halves<Desc<1>>();
-    if (lds_halves<Desc<2>>() > m) m = lds_halves<Desc<2>>();
-    if (lds_halves<Desc<3>>() > m) m = lds_halves<Desc<3>>();
-    if (lds_halves<Desc<4>>() > m) m = lds_halves<Desc<4>>();
+template <class E> constexpr int lds_elems_max() {
+    int m = lds_elems<Desc<0>, E>();
+    if (lds_elems<Desc<1>, E>() > m) m = lds_elems<Desc<1>, E>();
+    if (lds_elems<Desc<2>, E>() > m) m = lds_elems<Desc<2>, E>();
+    if (lds_elems<Desc<3>, E>() > m) m = lds_elems<Desc<3>, E>();
+    if (lds_elems<Desc<4>, E>() > m) m = lds_elems<Desc<4>, E>();
     return m;
-}();
+}
+static_assert(lds_elems_max<float>() * 4 <= 65536, "static LDS of the fp32 kernel");
 static_assert(n_tiles<Desc<0>>() <= kMaxTiles && n_tiles<Desc<1>>() <= kMaxTiles && n_tiles<Desc<3>>() <= kMaxTiles, "tiles per wave");
 
 // rows [row, row + 8) of column col0 + (lane & 31) of an LDS tile: the k-slots 8 (lane >> 5) .. + 8 of an MFMA operand whose k index is the
@@ -120,26 +124,26 @@ __device__ __forceinline__ half8 read_rows(const _Float16* T, int stride, int ro
     return half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <class D>
+template <class D, class E>
 struct Stage {
-    float4 q[stage_regs<D>()];
+    float4 q[stage_regs<D, E>()];
     float sk;
 };
 
 // global -> registers: rows [row0, row0 + kR) of every operand of the group; rows at or beyond `row_end` read as zeros
-template <class D>
-__device__ __forceinline__ void stage_load(Stage<D>& st, const WgArgs& a, uint32_t row0, uint32_t row_end, int tid) {
+template <class D, class E>
+__device__ __forceinline__ void stage_load(Stage<D, E>& st, const WgArgs& a, uint32_t row0, uint32_t row_end, int tid) {
     int k = 0;
 #pragma unroll
     for (int s = 0; s < D::NS; s++) {
-        const int cpr = D::W[s] / 8;                          // 16-byte chunks per row
-        const _Float16* __restrict__ p = a.src[D::S[s]];
+        const int cpr = D::W[s] / kEPC<E>;                    // 16-byte chunks per row
+        const E* __restrict__ p = static_cast<const E*>(a.src[D::S[s]]);
 #pragma unroll
-        for (int i = 0; i < chunks_per_thread<D>(s); i++, k++) {
+        for (int i = 0; i < chunks_per_thread<D, E>(s); i++, k++) {
             const int c = tid + kThreads * i;
             const uint32_t row = row0 + (uint32_t)(c / cpr);
             float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (c < kR * cpr && row < row_end) v = *reinterpret_cast<const float4*>(p + (size_t)row * D::W[s] + (c % cpr) * 8);
+            if (c < kR * cpr && row < row_end) v = *reinterpret_cast<const float4*>(p + (size_t)row * D::W[s] + (c % cpr) * kEPC<E>);
             st.q[k] = v;
         }
     }
@@ -150,48 +154,30 @@ __device__ __forceinline__ void stage_load(Stage<D>& st, const WgArgs& a, uint32
 }
 
 // registers -> LDS (row-major tiles)
-template <class D>
-__device__ __forceinline__ void stage_store(const Stage<D>& st, _Float16* L, int tid) {
+template <class D, class E>
+__device__ __forceinline__ void stage_store(const Stage<D, E>& st, E* L, int tid) {
     int k = 0;
 #pragma unroll
     for (int s = 0; s < D::NS; s++) {
-        const int cpr = D::W[s] / 8;
+        const int cpr = D::W[s] / kEPC<E>;
 #pragma unroll
-        for (int i = 0; i < chunks_per_thread<D>(s); i++, k++) {
+        for (int i = 0; i < chunks_per_thread<D, E>(s); i++, k++) {
             const int c = tid + kThreads * i;
-            if (c < kR * cpr) *reinterpret_cast<float4*>(L + lds_offset<D>(s) + (c / cpr) * lds_stride<D>(s) + (c % cpr) * 8) = st.q[k];
+            if (c < kR * cpr) *reinterpret_cast<float4*>(L + lds_offset<D, E>(s) + (c / cpr) * lds_stride<D, E>(s) + (c % cpr) * kEPC<E>) = st.q[k];
         }
     }
     if constexpr (D::SKC > 0) {
-        if (tid < kR * D::SKC) L[lds_offset<D>(D::NS) + (tid / D::SKC) * kNS + tid % D::SKC] = (_Float16)st.sk;
+        if (tid < kR * D::SKC) L[lds_offset<D, E>(D::NS) + (tid / D::SKC) * kNS<E> + tid % D::SKC] = (E)st.sk;
     }
 }
 
-template <int G>
-__device__ __forceinline__ void run_group(const WgArgs& a, _Float16* L, uint32_t wg_local) {
-    using D = Desc<G>;
-    constexpr int NT = n_tiles<D>();
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
-    const uint32_t rpw = a.rows_per_wg[G];
-    const uint32_t row_begin = wg_local * rpw;
-    const uint32_t row_end = row_begin + rpw < a.M ? row_begin + rpw : a.M;
-
-    // narrow tiles are read 32 columns wide: the columns nobody stages stay zero
-    for (int i = tid; i < kLdsHalves / 2; i += kThreads) reinterpret_cast<uint32_t*>(L)[i] = 0u;
-
-    floatx16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-
-    Stage<D> st;
-    if (row_begin < row_end) stage_load<D>(st, a, row_begin, row_end, tid);
-    __syncthreads();
-    for (uint32_t row0 = row_begin; row0 < row_end; row0 += kR) {
-        stage_store<D>(st, L, tid);
-        __syncthreads();
-        if (row0 + kR < row_end) stage_load<D>(st, a, row0 + kR, row_end, tid);
+// The products of one stage.  binary16: one v_mfma_f32_32x32x16_f16 per tile and 16 rows, operands through the transposing read.
+// fp32: one v_mfma_f32_32x32x2_f32 per tile and 2 rows -- lane (j, h) supplies row 2 k + h of column j, a plain ds_read_b32 (the 32 lanes
+// of a half-wave read 32 consecutive floats); nothing but LDS reads and MFMAs in the loop, because the f32 MFMA hides no VALU work (NOTES 10.1).
+template <class D, class E, int NT>
+__device__ __forceinline__ void stage_products(const E* L, floatx16 (&acc)[NT], int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    if constexpr (sizeof(E) == 2) {
 #pragma unroll
         for (int ks = 0; ks < kR / 16; ks++) {
             const int row = 16 * ks + 8 * half;
@@ -200,19 +186,70 @@ __device__ __forceinline__ void run_group(const WgArgs& a, _Float16* L, uint32_t
 #pragma unroll
             for (int p = 0; p < D::NP; p++) {
                 if (p == 0 || D::PA[p] != D::PA[p > 0 ? p - 1 : 0])
-                    A = read_rows(L + lds_offset<D>(D::PA[p]), lds_stride<D>(D::PA[p]), row, 32 * wave, lane);
+                    A = read_rows(L + lds_offset<D, E>(D::PA[p]), lds_stride<D, E>(D::PA[p]), row, 32 * wave, lane);
 #pragma unroll
                 for (int n = 0; n < D::PN[p]; n++, t++) {
-                    const half8 B = read_rows(L + lds_offset<D>(D::PB[p]), lds_stride<D>(D::PB[p]), row, 32 * n, lane);
+                    const half8 B = read_rows(L + lds_offset<D, E>(D::PB[p]), lds_stride<D, E>(D::PB[p]), row, 32 * n, lane);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[t], 0, 0, 0);
                 }
             }
             if constexpr (D::SKC > 0) {
-                const half8 As = read_rows(L + lds_offset<D>(D::NS), kNS, row, 0, lane);
-                const half8 B = read_rows(L + lds_offset<D>(D::SKB), lds_stride<D>(D::SKB), row, 32 * wave, lane);
+                const half8 As = read_rows(L + lds_offset<D, E>(D::NS), kNS<E>, row, 0, lane);
+                const half8 B = read_rows(L + lds_offset<D, E>(D::SKB), lds_stride<D, E>(D::SKB), row, 32 * wave, lane);
                 acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As, B, acc[NT - 1], 0, 0, 0);
             }
         }
+    } else {
+#pragma unroll
+        for (int k2 = 0; k2 < kR / 2; k2++) {
+            const int row = 2 * k2 + half;
+            int t = 0;
+            float A = 0.0f;
+#pragma unroll
+            for (int p = 0; p < D::NP; p++) {
+                if (p == 0 || D::PA[p] != D::PA[p > 0 ? p - 1 : 0])
+                    A = L[lds_offset<D, E>(D::PA[p]) + row * lds_stride<D, E>(D::PA[p]) + 32 * wave + j];
+#pragma unroll
+                for (int n = 0; n < D::PN[p]; n++, t++) {
+                    const float B = L[lds_offset<D, E>(D::PB[p]) + row * lds_stride<D, E>(D::PB[p]) + 32 * n + j];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, acc[t], 0, 0, 0);
+                }
+            }
+            if constexpr (D::SKC > 0) {
+                const float As = L[lds_offset<D, E>(D::NS) + row * kNS<E> + j];
+                const float B = L[lds_offset<D, E>(D::SKB) + row * lds_stride<D, E>(D::SKB) + 32 * wave + j];
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As, B, acc[NT - 1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int G, class E>
+__device__ __forceinline__ void run_group(const WgArgs& a, E* L, uint32_t wg_local) {
+    using D = Desc<G>;
+    constexpr int NT = n_tiles<D>();
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t rpw = a.rows_per_wg[G];
+    const uint32_t row_begin = wg_local * rpw;
+    const uint32_t row_end = row_begin + rpw < a.M ? row_begin + rpw : a.M;
+
+    // narrow tiles are read 32 columns wide: the columns nobody stages stay zero
+    for (int i = tid; i < lds_elems_max<E>() * (int)sizeof(E) / 4; i += kThreads) reinterpret_cast<uint32_t*>(L)[i] = 0u;
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+
+    Stage<D, E> st;
+    if (row_begin < row_end) stage_load<D, E>(st, a, row_begin, row_end, tid);
+    __syncthreads();
+    for (uint32_t row0 = row_begin; row0 < row_end; row0 += kR) {
+        stage_store<D, E>(st, L, tid);
+        __syncthreads();
+        if (row0 + kR < row_end) stage_load<D, E>(st, a, row0 + kR, row_end, tid);
+        stage_products<D, E, NT>(L, acc, wave, lane);
         __syncthreads();
     }
     float* __restrict__ out = a.ws + a.ws_base[G] + ((size_t)(wg_local * 4 + (uint32_t)wave) * NT) * 1024;
@@ -222,14 +259,25 @@ __device__ __forceinline__ void run_group(const WgArgs& a, _Float16* L, uint32_t
         for (int r = 0; r < 16; r++) out[(t * 16 + r) * 64 + lane] = acc[t][r];
 }
 
-__global__ void __launch_bounds__(kThreads, 3) k_field_wgrad16(const WgArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 L[kLdsHalves];
+template <class E>
+__device__ __forceinline__ void wgrad_body(const WgArgs& a, E* L) {
     const uint32_t b = blockIdx.x;
-    if (b < a.wg_first[1]) run_group<0>(a, L, b - a.wg_first[0]);
-    else if (b < a.wg_first[2]) run_group<1>(a, L, b - a.wg_first[1]);
-    else if (b < a.wg_first[3]) run_group<2>(a, L, b - a.wg_first[2]);
-    else if (b < a.wg_first[4]) run_group<3>(a, L, b - a.wg_first[3]);
-    else run_group<4>(a, L, b - a.wg_first[4]);
+    if (b < a.wg_first[1]) run_group<0, E>(a, L, b - a.wg_first[0]);
+    else if (b < a.wg_first[2]) run_group<1, E>(a, L, b - a.wg_first[1]);
+    else if (b < a.wg_first[3]) run_group<2, E>(a, L, b - a.wg_first[2]);
+    else if (b < a.wg_first[4]) run_group<3, E>(a, L, b - a.wg_first[3]);
+    else run_group<4, E>(a, L, b - a.wg_first[4]);
+}
+
+__global__ void __launch_bounds__(kThreads, 3) k_field_wgrad16(const WgArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 L[lds_elems_max<_Float16>()];
+    wgrad_body<_Float16>(a, L);
+}
+
+// The exact tier's products: fp32 rows (gf_field_forward_train's saves, gf_field_backward's fp32 outputs), v_mfma_f32_32x32x2_f32.
+__global__ void __launch_bounds__(kThreads, 2) k_field_wgrad32(const WgArgs a) {
+    __shared__ __attribute__((aligned(16))) float L[lds_elems_max<float>()];
+    wgrad_body<float>(a, L);
 }
 
 // One accumulator tile of the result: where its partial sums are and where its 32 x 32 values go.
@@ -271,15 +319,22 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const ReduceArgs a) {
 constexpr uint32_t kBytesPerRow[kGroups] = {3 * 256 + 32 + 12, 2 * 256 + 4, 2 * 256, 2 * 256 + 2 * 64, 3 * 256 + 8};
 constexpr uint32_t kTilesPerWave[kGroups] = {(uint32_t)n_tiles<Desc<0>>(), (uint32_t)n_tiles<Desc<1>>(), (uint32_t)n_tiles<Desc<2>>(),
                                              (uint32_t)n_tiles<Desc<3>>(), (uint32_t)n_tiles<Desc<4>>()};
-constexpr uint32_t kWgTotal = 768;     // three per CU (166 VGPRs, 34 KB of LDS): one resident generation of workgroups, no tail
+constexpr uint32_t kWgTotal16 = 768;   // three per CU (166 VGPRs, 34 KB of LDS): one resident generation of workgroups, no tail
+constexpr uint32_t kWgTotal32 = 512;   // fp32: two per CU (56 KB of LDS)
 
-// the deal of workgroups to groups for M rows: proportional to bytes per row, at least one, never more than there are stages
-void plan(uint32_t M, uint32_t (&n_wg)[kGroups], uint32_t (&rows_per_wg)[kGroups]) {
+// the deal of workgroups to groups for M rows: proportional to what a row of the group costs its workgroup -- bytes for the binary16 kernel
+// (HBM-bound), accumulator tiles = MFMAs for the fp32 one (matrix-pipe bound) --, at least one, never more than there are stages
+void plan(uint32_t M, bool f32, uint32_t (&n_wg)[kGroups], uint32_t (&rows_per_wg)[kGroups]) {
+    const uint32_t wg_total = f32 ? kWgTotal32 : kWgTotal16;
+    const uint32_t* cost = f32 ? kTilesPerWave : kBytesPerRow;
     uint32_t total = 0;
-    for (uint32_t b : kBytesPerRow) total += b;
+    for (int g = 0; g < kGroups; g++) total += cost[g];
     const uint32_t stages = gf_div_up(M, (uint32_t)kR);
+    uint32_t dealt = 0;
     for (int g = 0; g < kGroups; g++) {
-        uint32_t n = (uint32_t)(((uint64_t)kWgTotal * kBytesPerRow[g] + total / 2) / total);
+        uint32_t n = (uint32_t)(((uint64_t)wg_total * cost[g] + total / 2) / total);
+        if (g == kGroups - 1 && dealt < wg_total) n = wg_total - dealt;      // the rounding remainder: exactly one resident generation
+        dealt += n;
         if (n < 1) n = 1;
         if (n > stages) n = stages;
         n_wg[g] = n;
@@ -289,30 +344,31 @@ void plan(uint32_t M, uint32_t (&n_wg)[kGroups], uint32_t (&rows_per_wg)[kGroups
 
 }  // namespace
 
-GF_EXPORT uint64_t gf_field_wgrad16_ws_bytes(void) {
+namespace {
+uint64_t ws_bytes(bool f32) {
     uint32_t n_wg[kGroups], rpw[kGroups];
-    plan(~0u - 64u, n_wg, rpw);                      // the largest deal
+    plan(~0u - 64u, f32, n_wg, rpw);                 // the largest deal
     uint64_t floats = 0;
     for (int g = 0; g < kGroups; g++) floats += (uint64_t)n_wg[g] * 4u * kTilesPerWave[g] * 1024u;
     return floats * sizeof(float);
 }
 
-GF_EXPORT int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stream) {
-    if (!w) return gf_set_error(GF_ERR_INVALID, "field_wgrad16: null pointer");
+int wgrad_impl(bool f32, uint32_t M, const gf_field_wgrad_t* w, void* stream) {
+    if (!w) return gf_set_error(GF_ERR_INVALID, "field_wgrad: null pointer");
     const void* in[] = {w->f3, w->ha1, w->ha2, w->f2, w->hs1, w->hs2, w->geo, w->hc1, w->sh, w->g_hc1, w->g_geo, w->g_hs2, w->g_hs1, w->g_ha2, w->g_ha1,
                         w->g_zc, w->g_h0, w->g_za};
     const void* out[] = {w->gw_color1, w->gw_color0, w->gw_sigma2, w->gw_sigma1, w->gw_sigma0, w->gw_ambient2, w->gw_ambient1, w->gw_ambient0, w->workspace};
-    for (const void* p : out) if (!p) return gf_set_error(GF_ERR_INVALID, "field_wgrad16: null output buffer");
-    if (w->ld_color0 < 144 || w->ld_ambient0 < 32) return gf_set_error(GF_ERR_INVALID, "field_wgrad16: row strides of W_color0 / W_ambient0 gradients too small");
-    if (M > 0) for (const void* p : in) if (!p) return gf_set_error(GF_ERR_INVALID, "field_wgrad16: null input buffer");
+    for (const void* p : out) if (!p) return gf_set_error(GF_ERR_INVALID, "field_wgrad: null output buffer");
+    if (w->ld_color0 < 144 || w->ld_ambient0 < 32) return gf_set_error(GF_ERR_INVALID, "field_wgrad: row strides of W_color0 / W_ambient0 gradients too small");
+    if (M > 0) for (const void* p : in) if (!p) return gf_set_error(GF_ERR_INVALID, "field_wgrad: null input buffer");
 
     WgArgs a = {};
     const void* src[S_COUNT] = {w->f3, w->ha1, w->ha2, w->f2, w->hs1, w->hs2, w->geo, w->hc1, w->sh, w->g_hc1, w->g_geo, w->g_hs2, w->g_hs1, w->g_ha2, w->g_ha1};
-    for (int s = 0; s < S_COUNT; s++) a.src[s] = static_cast<const _Float16*>(src[s]);
+    for (int s = 0; s < S_COUNT; s++) a.src[s] = src[s];
     a.skinny[K_G_ZC] = w->g_zc; a.skinny[K_G_H0] = w->g_h0; a.skinny[K_G_ZA] = w->g_za;
     a.ws = w->workspace; a.M = M;
     uint32_t n_wg[kGroups];
-    plan(M ? M : 1u, n_wg, a.rows_per_wg);
+    plan(M ? M : 1u, f32, n_wg, a.rows_per_wg);
     uint32_t first = 0, base = 0;
     for (int g = 0; g < kGroups; g++) {
         a.wg_first[g] = first; first += n_wg[g];
@@ -320,7 +376,8 @@ GF_EXPORT int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stre
     }
     a.wg_first[kGroups] = first;
     if (M > 0) {
-        hipLaunchKernelGGL(k_field_wgrad16, dim3(first), dim3(kThreads), 0, gf_stream(stream), a);
+        if (f32) hipLaunchKernelGGL(k_field_wgrad32, dim3(first), dim3(kThreads), 0, gf_stream(stream), a);
+        else hipLaunchKernelGGL(k_field_wgrad16, dim3(first), dim3(kThreads), 0, gf_stream(stream), a);
         if (const int e = gf_check_launch("field_wgrad16")) return e;
     }
 
@@ -351,8 +408,14 @@ GF_EXPORT int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stre
         for (int n = 0; n < 4; n++) tile(4, wv, n, w->gw_ambient1 + (size_t)32 * wv * 128 + 32 * n, 128, 32, 32);
         tile(4, wv, 4, w->gw_ambient2 + 32 * wv, 128, 2, 32);
     }
-    if (k != kTilesTotal) return gf_set_error(GF_ERR_INVALID, "field_wgrad16: internal tile table");
+    if (k != kTilesTotal) return gf_set_error(GF_ERR_INVALID, "field_wgrad: internal tile table");
     if (M == 0) for (int i = 0; i < kTilesTotal; i++) r.t[i].n_wg = 0;     // no rows: the gradients are zeros
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(4 * kTilesTotal), dim3(256), 0, gf_stream(stream), r);
     return gf_check_launch("field_wgrad16 (reduce)");
 }
+}  // namespace
+
+GF_EXPORT uint64_t gf_field_wgrad16_ws_bytes(void) { return ws_bytes(false); }
+GF_EXPORT uint64_t gf_field_wgrad32_ws_bytes(void) { return ws_bytes(true); }
+GF_EXPORT int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stream) { return wgrad_impl(false, M, w, stream); }
+GF_EXPORT int gf_field_wgrad32(uint32_t M, const gf_field_wgrad_t* w, void* stream) { return wgrad_impl(true, M, w, stream); }

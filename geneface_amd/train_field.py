@@ -107,6 +107,30 @@ def _tall_tn(g, x, out_dtype=None):
     return gw
 
 
+def _fused_wgrad(st, half, M, dev, weights, mats):
+    """The eight weight gradients (W_color1, W_color0, W_sigma2, W_sigma1, W_sigma0, W_ambient2, W_ambient1, W_ambient0 order) as fresh fp32
+    tensors from gf_field_wgrad16 (half=True: binary16 saves and gradient rows) or gf_field_wgrad32 (fp32 ones).  The identity-code columns
+    of W_color0 and the condition columns of W_ambient0 are left for the caller."""
+    wc2, wc1, ws3, ws2, ws1, wa3, wa2, wa1 = weights
+    assert tuple(wc2.shape) == (3, 128) and wc1.shape[0] == 128 and wc1.shape[1] >= 144 and tuple(ws3.shape) == (129, 128) and \
+        tuple(ws2.shape) == (128, 128) and tuple(ws1.shape) == (128, 64) and tuple(wa3.shape) == (2, 128) and tuple(wa2.shape) == (128, 128) and \
+        wa1.shape[0] == 128 and wa1.shape[1] >= 32
+    want = torch.float16 if half else torch.float32
+    for n, t in mats.items():
+        if t.dtype != (torch.float32 if n in ("g_zc", "g_h0", "g_za") else want) or not t.is_contiguous():
+            raise RuntimeError(f"weight-gradient kernel: {n} must be a contiguous {want} matrix")
+    key = "_wgrad_ws16" if half else "_wgrad_ws32"
+    if getattr(st, key, None) is None:
+        nbytes = lib().gf_field_wgrad16_ws_bytes() if half else lib().gf_field_wgrad32_ws_bytes()
+        setattr(st, key, torch.empty(nbytes // 4, dtype=torch.float32, device=dev))
+    outs = tuple(torch.empty(w.shape, dtype=torch.float32, device=dev) for w in weights)
+    names = ("gw_color1", "gw_color0", "gw_sigma2", "gw_sigma1", "gw_sigma0", "gw_ambient2", "gw_ambient1", "gw_ambient0")
+    wg = GfFieldWgrad(**{n: t.data_ptr() for n, t in mats.items()}, **{n: t.data_ptr() for n, t in zip(names, outs)},
+                      ld_color0=wc1.shape[1], ld_ambient0=wa1.shape[1], workspace=getattr(st, key).data_ptr())
+    check((lib().gf_field_wgrad16 if half else lib().gf_field_wgrad32)(M, C.byref(wg), current_stream(dev)))
+    return outs
+
+
 def _grid_backward(enc, x01, grad, want_input_grad, level_major=False, level_max=None):
     """Table gradient (and d/d x01 through a freshly evaluated dy_dx) of GridEncoder `enc` at inputs x01 [M,D] for an output gradient
     `grad` [M, L*C] (or already [L, M, C] with level_major): the library's backward kernels, without re-entering autograd.  level_max: the
@@ -216,21 +240,35 @@ class _HeadField(torch.autograd.Function):
             check(lib().gf_field_backward(C.byref(f), ptr(stream, torch.float32), M, C.byref(g), current_stream(dev)))
         g_zc, g_h0, g_za = out["g_zc"], out["g_h0"], out["g_za"]
         g_hc1, g_geo, g_hs2, g_hs1, g_ha2, g_ha1 = (out[n] for n in ("g_hc1", "g_geo", "g_hs2", "g_hs1", "g_ha2", "g_ha1"))
-        # ---- weight gradients: tall products of the pre-activation gradients with the saved activations
+        # ---- weight gradients: tall products of the pre-activation gradients with the saved activations -- all eight in one launch + one
+        # fixed-order reduction on the f32 matrix pipe (gf_field_wgrad32, csrc/field_wgrad.hip, round 6; `model.wgrad_impl = "gemm"` keeps
+        # the batched library products)
         s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
-        g_wc2 = _tall_tn(g_zc, hc1)
-        parts = [_tall_tn(g_hc1, sh), _tall_tn(g_hc1, geo)]
         g_code = None
+        if getattr(model, "wgrad_impl", "fused") == "fused":
+            g_wc2, g_wc1, g_ws3, g_ws2, g_ws1, g_wa3, g_wa2, g_wa1 = _fused_wgrad(
+                st, False, M, dev, (wc2, wc1, ws3, ws2, ws1, wa3, wa2, wa1),
+                dict(f3=f3, ha1=ha1, ha2=ha2, f2=f2, hs1=hs1, hs2=hs2, geo=geo, hc1=hc1, sh=sh, g_hc1=g_hc1, g_geo=g_geo, g_hs2=g_hs2, g_hs1=g_hs1,
+                     g_ha2=g_ha2, g_ha1=g_ha1, g_zc=g_zc, g_h0=g_h0, g_za=g_za))
+            if ctx.has_code:
+                g_wc1[:, 144:] = torch.outer(s_hc1, ind_code.reshape(-1).float())
+            elif wc1.shape[1] > 144:
+                g_wc1[:, 144:] = 0
+            g_wa1[:, 32:] = torch.outer(s_ha1, cond)
+        else:
+            g_wc2 = _tall_tn(g_zc, hc1)
+            parts = [_tall_tn(g_hc1, sh), _tall_tn(g_hc1, geo)]
+            if ctx.has_code:
+                parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
+            g_wc1 = torch.cat(parts, dim=1)
+            g_ws3 = torch.cat([_tall_tn(g_h0.unsqueeze(1), hs2), _tall_tn(g_geo, hs2)], dim=0)
+            g_ws2 = _tall_tn(g_hs2, hs1)
+            g_ws1 = torch.cat([_tall_tn(g_hs1, f3), _tall_tn(g_hs1, f2)], dim=1)
+            g_wa3 = _tall_tn(g_za, ha2)
+            g_wa2 = _tall_tn(g_ha2, ha1)
+            g_wa1 = torch.cat([_tall_tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         if ctx.has_code:
-            parts.append(torch.outer(s_hc1, ind_code.reshape(-1).float()))
             g_code = (s_hc1 @ wc1[:, 144:]).view_as(ind_code)
-        g_wc1 = torch.cat(parts, dim=1)
-        g_ws3 = torch.cat([_tall_tn(g_h0.unsqueeze(1), hs2), _tall_tn(g_geo, hs2)], dim=0)
-        g_ws2 = _tall_tn(g_hs2, hs1)
-        g_ws1 = torch.cat([_tall_tn(g_hs1, f3), _tall_tn(g_hs1, f2)], dim=1)
-        g_wa3 = _tall_tn(g_za, ha2)
-        g_wa2 = _tall_tn(g_ha2, ha1)
-        g_wa1 = torch.cat([_tall_tn(g_ha1, f3), torch.outer(s_ha1, cond)], dim=1)
         g_cond = (s_ha1 @ wa1[:, 32:]).view_as(cond_feat)
         # ---- grid tables
         lm = level_max if M > 0 else None
@@ -357,19 +395,10 @@ class _HeadFieldAMP(torch.autograd.Function):
         s_hc1, s_ha1 = out["s_hc1"], out["s_ha1"]
         g_code = None
         if getattr(model, "amp_wgrad", "fused") == "fused":
-            if getattr(st, "_wgrad_ws", None) is None:
-                st._wgrad_ws = torch.empty(lib().gf_field_wgrad16_ws_bytes() // 4, **f32)
-            g_wc2, g_wc1, g_ws3, g_ws2, g_ws1, g_wa3, g_wa2, g_wa1 = (torch.empty(w.shape, **f32) for w in (wc2, wc1, ws3, ws2, ws1, wa3, wa2, wa1))
-            wg = GfFieldWgrad(**{n: t.data_ptr() for n, t in (("f3", f3), ("ha1", ha1), ("ha2", ha2), ("f2", f2), ("hs1", hs1), ("hs2", hs2), ("geo", geo),
-                                                              ("hc1", hc1), ("sh", sh), ("g_hc1", g_hc1), ("g_geo", g_geo), ("g_hs2", g_hs2), ("g_hs1", g_hs1),
-                                                              ("g_ha2", g_ha2), ("g_ha1", g_ha1), ("g_zc", g_zc), ("g_h0", g_h0), ("g_za", g_za),
-                                                              ("gw_color1", g_wc2), ("gw_color0", g_wc1), ("gw_sigma2", g_ws3), ("gw_sigma1", g_ws2),
-                                                              ("gw_sigma0", g_ws1), ("gw_ambient2", g_wa3), ("gw_ambient1", g_wa2), ("gw_ambient0", g_wa1),
-                                                              ("workspace", st._wgrad_ws))},
-                              ld_color0=wc1.shape[1], ld_ambient0=wa1.shape[1])
-            assert tuple(wc2.shape) == (3, 128) and wc1.shape[0] == 128 and tuple(ws3.shape) == (129, 128) and tuple(ws2.shape) == (128, 128) and \
-                tuple(ws1.shape) == (128, 64) and tuple(wa3.shape) == (2, 128) and tuple(wa2.shape) == (128, 128) and wa1.shape[0] == 128
-            check(lib().gf_field_wgrad16(M, C.byref(wg), current_stream(dev)))
+            g_wc2, g_wc1, g_ws3, g_ws2, g_ws1, g_wa3, g_wa2, g_wa1 = _fused_wgrad(
+                st, True, M, dev, (wc2, wc1, ws3, ws2, ws1, wa3, wa2, wa1),
+                dict(f3=f3, ha1=ha1, ha2=ha2, f2=f2, hs1=hs1, hs2=hs2, geo=geo, hc1=hc1, sh=sh, g_hc1=g_hc1, g_geo=g_geo, g_hs2=g_hs2, g_hs1=g_hs1,
+                     g_ha2=g_ha2, g_ha1=g_ha1, g_zc=g_zc, g_h0=g_h0, g_za=g_za))
             if ctx.has_code:
                 g_wc1[:, 144:] = torch.outer(s_hc1, ind_code.reshape(-1).float())
             elif wc1.shape[1] > 144:

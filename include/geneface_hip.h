@@ -351,6 +351,10 @@ typedef struct gf_field_wgrad {
 } gf_field_wgrad_t;
 uint64_t gf_field_wgrad16_ws_bytes(void);
 int gf_field_wgrad16(uint32_t M, const gf_field_wgrad_t* w, void* stream);
+/* The same products for the exact tier: every matrix fp32 (gf_field_forward_train's saves, gf_field_backward's outputs with out16 = 0),
+ * v_mfma_f32_32x32x2_f32 -- an exact fmaf chain per accumulator, partial sums per workgroup added in workgroup order. */
+uint64_t gf_field_wgrad32_ws_bytes(void);
+int gf_field_wgrad32(uint32_t M, const gf_field_wgrad_t* w, void* stream);
 /* gf_grid_encode_backward (gridencoder.cu:248-339) for a gradient already in [L, B, C] order whose per-level max |g| is known on the device
  * (level_max[L]; gf_field_backward produces both): the table scatter without its max pass; no input gradient.  D = 2 or 3. */
 int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,

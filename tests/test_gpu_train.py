@@ -491,37 +491,41 @@ def test_amp_training_steps_follow_the_fp32_steps():
     assert b[-1] < b[0] and a[-1] < a[0]
 
 
+@pytest.mark.parametrize("tier", ["f16", "f32"])
 @pytest.mark.parametrize("M", [1, 37, 4173, 300_001])
-def test_fused_weight_gradient_products_vs_float64(M):
-    """gf_field_wgrad16 (csrc/field_wgrad.hip): the eight tall products G^T X of the AMP backward in one launch + a fixed-order reduction.
-    Against the same binary16 operands multiplied in float64: fp32 accumulation only (1e-5 of each tensor's norm); the blocks the kernel
+def test_fused_weight_gradient_products_vs_float64(M, tier):
+    """gf_field_wgrad16 / gf_field_wgrad32 (csrc/field_wgrad.hip): the eight tall products G^T X of the backward in one launch + a fixed-order
+    reduction, on binary16 rows (AMP tier, f16 MFMA) or fp32 rows (exact tier, f32 MFMA).
+    Against the same operands multiplied in float64: fp32 accumulation only (1e-5 of each tensor's norm); the blocks the kernel
     does not own (identity-code / condition columns) untouched; the same bits on a second call; row counts that are not multiples of the
     32-row stage, below one stage, and large enough that every workgroup of every group has rows."""
     import ctypes as C
     from geneface_amd.lib import check, current_stream, lib
     from geneface_amd.train_field import GfFieldWgrad
     g = torch.Generator(device=DEV).manual_seed(11 + M)
-    h = lambda *s: (torch.randn(*s, device=DEV, generator=g) * 0.5).half()
     f = lambda *s: torch.randn(*s, device=DEV, generator=g) * 0.5
+    h = (lambda *s: f(*s).half()) if tier == "f16" else f
+    fn, ws_bytes = (lib().gf_field_wgrad16, lib().gf_field_wgrad16_ws_bytes) if tier == "f16" else (lib().gf_field_wgrad32, lib().gf_field_wgrad32_ws_bytes)
     t = {"f3": h(M, 32), "ha1": h(M, 128), "ha2": h(M, 128), "f2": h(M, 32), "hs1": h(M, 128), "hs2": h(M, 128), "geo": h(M, 128), "hc1": h(M, 128),
          "sh": h(M, 16), "g_hc1": h(M, 128), "g_geo": h(M, 128), "g_hs2": h(M, 128), "g_hs1": h(M, 128), "g_ha2": h(M, 128), "g_ha1": h(M, 128),
          "g_zc": f(M, 3), "g_h0": f(M), "g_za": f(M, 2)}
     shapes = {"gw_color1": (3, 128), "gw_color0": (128, 148), "gw_sigma2": (129, 128), "gw_sigma1": (128, 128), "gw_sigma0": (128, 64),
               "gw_ambient2": (2, 128), "gw_ambient1": (128, 128), "gw_ambient0": (128, 96)}
-    ws = torch.empty(lib().gf_field_wgrad16_ws_bytes() // 4, device=DEV)
+    ws = torch.empty(ws_bytes() // 4, device=DEV)
     runs = []
     for fill in (7.0, -3.0):
         out = {n: torch.full(s, fill, device=DEV) for n, s in shapes.items()}
         ws.fill_(float("nan"))
         wg = GfFieldWgrad(**{n: v.data_ptr() for n, v in {**t, **out}.items()}, ld_color0=148, ld_ambient0=96, workspace=ws.data_ptr())
-        check(lib().gf_field_wgrad16(M, C.byref(wg), current_stream(torch.device(DEV))))
+        check(fn(M, C.byref(wg), current_stream(torch.device(DEV))))
         torch.cuda.synchronize()
         assert bool((out["gw_color0"][:, 144:] == fill).all()) and bool((out["gw_ambient0"][:, 32:] == fill).all())
         runs.append(out)
     for n in shapes:
         assert torch.equal(runs[0][n][:, :144] if n == "gw_color0" else runs[0][n][:, :32] if n == "gw_ambient0" else runs[0][n],
                            runs[1][n][:, :144] if n == "gw_color0" else runs[1][n][:, :32] if n == "gw_ambient0" else runs[1][n]), n
-    d = {n: v.double() if v.dtype == torch.float16 else v.half().double() for n, v in t.items()}     # the skinny gradients enter as binary16
+    # the skinny gradients enter the f16 kernel as binary16
+    d = {n: v.double() if (v.dtype == torch.float16 or tier == "f32") else v.half().double() for n, v in t.items()}
     tn = lambda a, b: a.t() @ b
     want = {"gw_color1": tn(d["g_zc"], d["hc1"]), "gw_color0": torch.cat([tn(d["g_hc1"], d["sh"]), tn(d["g_hc1"], d["geo"])], 1),
             "gw_sigma2": torch.cat([tn(d["g_h0"][:, None], d["hs2"]), tn(d["g_geo"], d["hs2"])], 0), "gw_sigma1": tn(d["g_hs2"], d["hs1"]),
@@ -566,3 +570,41 @@ def test_amp_node_fused_weight_gradients_vs_library_products():
     for n, gr in res["gemm"].items():
         l2 = float((res["fused"][n] - gr).double().norm() / gr.double().norm().clamp(min=1e-20))
         assert l2 < (1e-6 if ("embedder" in n or n in ("cond", "individual_embeddings")) else 2e-3), (n, l2)
+
+
+def test_fp32_node_fused_weight_gradients_vs_library_products():
+    """The exact node with the fused weight-gradient kernel (gf_field_wgrad32, model.wgrad_impl = "fused", the default) against the same node
+    over the batched library products ("gemm"): the same fp32 operands, two summation orders."""
+    from geneface_amd.radnerf import RADNeRF
+    from geneface_amd.train_field import head_field
+    hp, sd = model_fixture(False)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    M = 70000 + 5
+    xyz = torch.rand(M, 3, device=DEV, generator=g) * 1.6 - 0.8
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, device=DEV, generator=g), dim=-1)
+    cond = torch.randn(64, device=DEV, generator=g) * 0.3
+    code = model.individual_embeddings[0]
+    ws, wc, wa = torch.rand(M, device=DEV, generator=g), torch.rand(M, 3, device=DEV, generator=g), torch.rand(M, 2, device=DEV, generator=g)
+    res = {}
+    for impl in ("gemm", "fused", "fused"):
+        model.wgrad_impl = impl
+        model.zero_grad(set_to_none=True)
+        cf = cond.clone().requires_grad_(True)
+        sigma, rgb, amb = head_field(model, xyz, dirs, cf, code)
+        ((torch.log1p(sigma) * ws).sum() + (rgb * wc).sum() + (amb * wa).sum()).backward()
+        cur = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        cur["cond"] = cf.grad.detach().clone()
+        if impl in res:                     # the fused kernel reproduces itself bit for bit
+            for n in ("ambient_net.net.0.weight", "ambient_net.net.1.weight", "ambient_net.net.2.weight", "sigma_net.net.0.weight", "sigma_net.net.1.weight",
+                      "sigma_net.net.2.weight", "color_net.net.0.weight", "color_net.net.1.weight"):
+                own = 32 if n == "ambient_net.net.0.weight" else 144 if n == "color_net.net.0.weight" else cur[n].shape[1]   # beyond: outer products
+                assert torch.equal(cur[n][:, :own], res[impl][n][:, :own]), n                                             # with atomic column sums
+        res[impl] = cur
+    del model.wgrad_impl
+    assert set(res["gemm"]) == set(res["fused"])
+    for n, gr in res["gemm"].items():
+        l2 = float((res["fused"][n] - gr).double().norm() / gr.double().norm().clamp(min=1e-20))
+        assert l2 < 2e-5, (n, l2)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--amp-f32-field", action="store_true", help="--amp with the exact-fp32 field node under autocast (RADNeRF.amp_field = 'f32': round 5's "
                     "behaviour) instead of the f16 tier")
     ap.add_argument("--amp-f32-backward", action="store_true", help="--amp with the fp32 dX chain (RADNeRF.amp_backward = 'f32': stage 1 of round 6)")
+    ap.add_argument("--gemm-wgrad", action="store_true", help="fp32 step with the weight gradients as batched library products (RADNeRF.wgrad_impl = 'gemm': "
+                    "the tree before round 6's gf_field_wgrad32)")
     ap.add_argument("--amp-gemm-wgrad", action="store_true", help="--amp with the weight gradients as batched library products (RADNeRF.amp_wgrad = 'gemm': "
                     "stage 2 of round 6) instead of the fused kernel (gf_field_wgrad16)")
     ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
@@ -55,6 +57,8 @@ def main():
         model.amp_backward = "f32"
     if args.amp_gemm_wgrad:
         model.amp_wgrad = "gemm"
+    if args.gemm_wgrad:
+        model.wgrad_impl = "gemm"
     seq = S.make_sequence(8, 512, 512, hp)
     poses = torch.from_numpy(seq["poses"]).to(dev)
     cond = torch.from_numpy(seq["cond_wins"]).to(dev)
@@ -97,6 +101,7 @@ def main():
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "amp": {"field": getattr(model, "amp_field", "f16"), "backward": getattr(model, "amp_backward", "f16"),
                               "weight_gradients": getattr(model, "amp_wgrad", "fused")} if args.amp else None,
+                      "weight_gradients": getattr(model, "amp_wgrad", "fused") if args.amp else getattr(model, "wgrad_impl", "fused"),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
 
