@@ -288,8 +288,13 @@ def legacy_nerf_baseline(seq, rays=4096, full_size=64):
                 from oracle import refshim
                 refshim.install(root=archive)
                 with refshim.cpu_mode():
+                    import modules.nerfs.commons.ray_samplers as _rs
+                    import modules.nerfs.commons.volume_rendering as _vr
                     from modules.nerfs.commons.volume_rendering import render_dynamic_face
                     from modules.nerfs.lm3d_nerf.lm3d_nerf import Lm3dNeRF
+                    # volume_rendering.py:7 / ray_samplers.py:8 pick "cuda" at import wherever a GPU is visible; B2 is the reference's
+                    # pure-PyTorch path on the HOST cores, so both module globals are pointed at the CPU
+                    _vr.device = _rs.device = torch.device("cpu")
                     torch.manual_seed(0)
                     ref_model = Lm3dNeRF({"cond_dim": 64, "hidden_size": 256, "use_window_cond": True, "cond_win_size": 1, "smo_win_size": 5,
                                           "with_att": True}).eval()

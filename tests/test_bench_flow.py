@@ -339,3 +339,25 @@ def test_pmc_traffic_is_marked_stale_when_the_kernels_moved_on(tmp_path, monkeyp
     assert bench.pmc_traffic()[2] is True
     (prof / "r9a_pmc_summary.json").write_text(json.dumps(body))          # round 1-4 summaries carry no digest: stale by definition
     assert bench.pmc_traffic()[2] is True
+
+
+def test_legacy_nerf_baseline_runs_on_the_host_where_a_gpu_is_visible(monkeypatch):
+    """bench.py's B2 leg times the reference's own modules.nerfs classes (staged archive) on the HOST cores.  Those modules pick
+    `device = "cuda"` at import wherever a GPU is visible (volume_rendering.py:7, ray_samplers.py:8) -- i.e. on every GPU box and never in the
+    build container: round 6's first driver-command run on the MI355X died there.  The leg must pin both module globals to the CPU."""
+    import torch
+    import bench
+    archive = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_refpy", "geneface_refpy.zip")
+    if not os.path.exists(archive):
+        pytest.skip("oracle/_refpy/geneface_refpy.zip not staged")
+    for name in [m for m in sys.modules if m.startswith("modules.nerfs")]:
+        del sys.modules[name]                                     # a fresh import, as in a fresh bench process
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    seq = S.make_sequence(1, 64, 64, HP.may_hparams(True))
+    rec = bench.legacy_nerf_baseline(seq, rays=64, full_size=8)
+    assert rec["kind"] == "reference" and rec["value"] > 0 and rec["whole_frame_64x64"]["finite"]
+    import modules.nerfs.commons.ray_samplers as rs
+    import modules.nerfs.commons.volume_rendering as vr
+    assert vr.device.type == "cpu" and rs.device.type == "cpu"
