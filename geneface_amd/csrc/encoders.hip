@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
 // below 2^14 quanta (1.5e-8 of the maximum) goes to the table as a float atomic instead, so every entry keeps fp32 RELATIVE accuracy over
 // the whole dynamic range (tests/test_gpu_train.py::test_grid_backward_keeps_tiny_gradients: 14 decades against an fp64 scatter).
 constexpr uint32_t kGbThreads = 1024;
-constexpr uint32_t kGbLdsEntries = 16384;   // int64 accumulators: 128 KiB, one workgroup per CU
+#ifndef GF_GB_ENTRIES
+#define GF_GB_ENTRIES 16384
+#endif
+constexpr uint32_t kGbLdsEntries = GF_GB_ENTRIES;   // int64 accumulators: 128 KiB, one workgroup per CU
 constexpr uint32_t kGbMaxParts = 8;
 constexpr float kGbFixedOne = 1099511627776.0f;   // 2^40: one quantum = 9e-13 of the level's largest gradient; 2^23 contributions of full size fit an int64
 #ifndef GF_GB_SMALL
