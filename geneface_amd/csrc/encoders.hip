@@ -195,6 +195,10 @@ constexpr uint32_t kGbThreads = 1024;
 #endif
 constexpr uint32_t kGbLdsEntries = GF_GB_ENTRIES;   // int64 accumulators: 128 KiB, one workgroup per CU
 constexpr uint32_t kGbMaxParts = 8;
+#ifndef GF_GB_BATCH
+#define GF_GB_BATCH 4
+#endif
+constexpr uint32_t kGbBatch = GF_GB_BATCH;                  // points per lane whose loads are in flight together (1 = the loop before round 6)
 constexpr float kGbFixedOne = 1099511627776.0f;   // 2^40: one quantum = 9e-13 of the level's largest gradient; 2^23 contributions of full size fit an int64
 #ifndef GF_GB_SMALL
 #define GF_GB_SMALL 16384.0f
@@ -235,12 +239,27 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
                                           uint32_t level, uint32_t B, uint32_t b0, uint32_t b1, float scale, uint32_t resolution, uint32_t hashmap_size,
                                           uint32_t gridtype, bool align_corners, uint32_t interp, const gf::LevelMeta& lm, uint32_t row0, uint32_t nrows,
                                           float to_fixed) {
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += kGbThreads) {
+    // kGbBatch points per lane and trip, their inputs and gradients loaded TOGETHER before any is processed (round 6): one workgroup per CU
+    // (the 128 KiB table) is 4 waves per SIMD, and a trip used to wait for two dependent loads (the point, then -- if in range -- its gradient)
+    // before ~100-400 instructions of work: the loop ran at the latency of those loads (tools/grid_backward_levels.py).
+    for (uint32_t bb = b0 + threadIdx.x; bb < b1; bb += kGbThreads * kGbBatch) {
+      float xs[kGbBatch][D], gsv[kGbBatch][C];
+#pragma unroll
+      for (uint32_t k = 0; k < kGbBatch; k++) {
+          const uint32_t b = bb + k * kGbThreads;
+          const bool in = b < b1;
+#pragma unroll
+          for (uint32_t d = 0; d < D; d++) xs[k][d] = in ? inputs[(size_t)b * D + d] : -1.0f;      // beyond the slice: out of range, skipped below
+#pragma unroll
+          for (uint32_t c = 0; c < C; c++) gsv[k][c] = in ? grad[((size_t)level * B + b) * C + c] : 0.0f;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kGbBatch; k++) {
         float x[D];
         bool oob = false;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
-            x[d] = inputs[(size_t)b * D + d];
+            x[d] = xs[k][d];
             oob |= !(x[d] >= 0 && x[d] <= 1);   // NaN counts as out of range: no address is ever formed from it (the fused lookups do the same)
         }
         if (oob) continue;
@@ -248,7 +267,7 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
         bool any = false;
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) {
-            g[c] = grad[((size_t)level * B + b) * C + c];
+            g[c] = gsv[k][c];
             any |= g[c] != 0.0f;
         }
         if (!any) continue;                                        // samples behind a ray's termination point carry exact zeros
@@ -313,6 +332,7 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
                 }
             }
         }
+      }
     }
 }
 

@@ -2,6 +2,7 @@
 gradient of ONE level non-zero at a time (a level whose gradient is all zero returns at once), 3-D and 2-D tables of the May config.
 
     [GF_HIP_LIB=.../libgeneface_hip_<variant>.so] python tools/grid_backward_levels.py"""
+import hashlib
 import json
 import os
 import sys
@@ -41,7 +42,7 @@ for D in (3, 2):
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
-        return best, float(ge.double().sum())
+        return best, hashlib.md5(ge.cpu().numpy().tobytes()).hexdigest()[:12] + f" {float(ge.double().sum()):.6f}"
     rec = {"rows_per_level": [int(off_h[l + 1] - off_h[l]) for l in range(16)]}
     rec["all_levels_ms"], rec["checksum"] = timed(full)
     rec["no_level_ms"], _ = timed(torch.zeros_like(full))          # the max pass + sixteen empty launches' worth of workgroups
