@@ -238,7 +238,7 @@ template <uint32_t D, uint32_t C, int MODE, bool DIRECT>
 __device__ __forceinline__ void gb_points(long long* tab, const float* __restrict__ grad, const float* __restrict__ inputs, float* __restrict__ table,
                                           uint32_t level, uint32_t B, uint32_t b0, uint32_t b1, float scale, uint32_t resolution, uint32_t hashmap_size,
                                           uint32_t gridtype, bool align_corners, uint32_t interp, const gf::LevelMeta& lm, uint32_t row0, uint32_t nrows,
-                                          float to_fixed) {
+                                          float to_fixed, const uint32_t* __restrict__ idx = nullptr /* a bin of point indices: [b0, b1) index IT */) {
     // kGbBatch points per lane and trip, their inputs and gradients loaded TOGETHER before any is processed (round 6): one workgroup per CU
     // (the 128 KiB table) is 4 waves per SIMD, and a trip used to wait for two dependent loads (the point, then -- if in range -- its gradient)
     // before ~100-400 instructions of work: the loop ran at the latency of those loads (tools/grid_backward_levels.py).
@@ -246,8 +246,9 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
       float xs[kGbBatch][D], gsv[kGbBatch][C];
 #pragma unroll
       for (uint32_t k = 0; k < kGbBatch; k++) {
-          const uint32_t b = bb + k * kGbThreads;
-          const bool in = b < b1;
+          const uint32_t bi = bb + k * kGbThreads;
+          const bool in = bi < b1;
+          const uint32_t b = (idx && in) ? idx[bi] : bi;
 #pragma unroll
           for (uint32_t d = 0; d < D; d++) xs[k][d] = in ? inputs[(size_t)b * D + d] : -1.0f;      // beyond the slice: out of range, skipped below
 #pragma unroll
@@ -336,11 +337,131 @@ __device__ __forceinline__ void gb_points(long long* tab, const float* __restric
     }
 }
 
+// What k_grid_backward decides per level, in one place (k_grid_bin must decide the same): partitions, the direct fall-back, the row rule.
+struct GbLevelPlan { uint32_t off, hashmap_size, nparts; bool direct; int mode; gf::LevelMeta lm; };
+template <uint32_t D, uint32_t C>
+__device__ __forceinline__ GbLevelPlan gb_level_plan(const int* __restrict__ offsets, const gf::GridLevels& lv, uint32_t level, uint32_t gridtype,
+                                                     bool align_corners) {
+    GbLevelPlan p;
+    p.off = (uint32_t)offsets[level];
+    p.hashmap_size = (uint32_t)offsets[level + 1] - p.off;
+    constexpr uint32_t rows_per_part = kGbLdsEntries / C;
+    p.nparts = (p.hashmap_size + rows_per_part - 1) / rows_per_part;
+    p.direct = p.nparts > kGbMaxParts;
+    if (p.direct) p.nparts = 1;
+    // Row index without the generic rule's integer modulo (grid_row): dense levels never reach the table size, wrapped levels have a
+    // power-of-two size (grid.py:118-134 caps them at 2^log2_hashmap_size) -- the same reduction the fused lookup uses (LevelMeta).
+    p.lm = gf::LevelMeta{};
+    p.mode = 0;
+    if constexpr (D <= 3) {
+        p.lm = gf::make_level_meta<D>(lv.scale[level], lv.resolution[level], offsets, level, gridtype);
+        if (!align_corners && (p.lm.mask == 0xFFFFFFFFu || (p.hashmap_size & (p.hashmap_size - 1u)) == 0u)) p.mode = p.lm.use_hash ? 1 : 2;
+    }
+    return p;
+}
+__device__ __forceinline__ bool gb_level_binned(const GbLevelPlan& p) { return !p.direct && p.nparts >= 2 && p.mode != 0; }
+
+// Binning pass (round 6): k_grid_backward's workgroup (level, partition, slice) used to examine EVERY point of its slice -- ~250 instructions to
+// find that, on a level of eight partitions, one corner in eight is its own (tools/grid_backward_levels.py: 111 M examinations of 16 M (point,
+// level) pairs per 1 M-point call).  Here one lane per point walks the levels ONCE, finds which partitions its corners touch (a cell's corners
+// touch ~2.4 of 8 on the tiled 3-D grid, ~2 on the 2-D one) and appends the point's index to those partitions' lists; the scatter then reads each
+// partition's own list.  Appending is aggregated twice -- ballot per wave, LDS counters per 1 024-lane workgroup -- so a workgroup spends ONE
+// global atomic per (level, partition) and 1 024 points: the first version took one per wave and ran 9.5 ms on 120 contended addresses.
+// The order inside a list depends on the order in which waves and workgroups arrive; a slice's integer partial depends only on WHICH points
+// it holds, and the float flush is order-dependent in the last ulp with or without lists.  counts [32][kGbMaxParts] ZEROED; bins [L][kGbMaxParts][B].  Points with an all-zero gradient at a level
+// are not listed for it.
+constexpr uint32_t kBinThreads = 1024, kBinSlots = gf::kMaxLevels * kGbMaxParts;
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBinThreads) k_grid_bin(const float* __restrict__ grad, const float* __restrict__ inputs, const int* __restrict__ offsets,
+                                                          uint32_t B, gf::GridLevels lv, uint32_t gridtype, bool align_corners,
+                                                          const uint32_t* __restrict__ lvl_max, uint32_t* __restrict__ counts, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t cnt[kBinSlots], base[kBinSlots], woff[kBinThreads / 64][kBinSlots];
+    __shared__ uint8_t msk[gf::kMaxLevels][kBinThreads];                      // the partitions of every level a lane's point goes to
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t rows_per_part = kGbLdsEntries / C;
+    for (uint32_t chunk = blockIdx.x * kBinThreads; chunk < B; chunk += gridDim.x * kBinThreads) {       // workgroup-uniform
+        if (threadIdx.x < kBinSlots) cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t b = chunk + threadIdx.x;
+        bool in = b < B;
+        float x[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            x[d] = in ? inputs[(size_t)b * D + d] : 0.0f;
+            in = in && (x[d] >= 0 && x[d] <= 1);
+        }
+        for (uint32_t level = 0; level < lv.L; level++) {
+            {
+                const float gmax = __uint_as_float(lvl_max[level]);
+                const GbLevelPlan p = gb_level_plan<D, C>(offsets, lv, level, gridtype, align_corners);
+                if ((gmax < INFINITY) && (gmax > 0.0f) && gb_level_binned(p)) {   // (k_grid_backward returns at once for the other gradients)
+                    bool any = false;
+                    if (in) {
+#pragma unroll
+                        for (uint32_t c = 0; c < C; c++) any |= grad[((size_t)level * B + b) * C + c] != 0.0f;
+                    }
+                    uint32_t term[D][2];
+                    constexpr uint32_t P1 = 2654435761u, P2 = 805459861u;
+#pragma unroll
+                    for (uint32_t d = 0; d < D; d++) {
+                        const uint32_t pg = (uint32_t)floorf(__builtin_fmaf(x[d], lv.scale[level], 0.5f));
+                        const uint32_t m = p.mode == 1 ? (d == 0 ? 1u : (d == 1 ? P1 : P2)) : (d == 0 ? 1u : (d == 1 ? p.lm.s1 : p.lm.s2));
+                        term[d][0] = pg * m;
+                        term[d][1] = term[d][0] + m;
+                    }
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (uint32_t corner = 0; corner < (1u << D); corner++) {
+                        uint32_t row = term[0][corner & 1u];
+#pragma unroll
+                        for (uint32_t d = 1; d < D; d++) row = p.mode == 1 ? (row ^ term[d][(corner >> d) & 1u]) : (row + term[d][(corner >> d) & 1u]);
+                        row &= p.lm.mask;
+                        const uint32_t part = row / rows_per_part;
+                        if (part < p.nparts) mask |= 1u << part;               // (a row beyond the level cannot happen for x in [0, 1]; k_grid_backward skips it too)
+                    }
+                    if (!any) mask = 0;
+                    msk[level][threadIdx.x] = (uint8_t)mask;
+                    for (uint32_t part = 0; part < p.nparts; part++) {         // this wave's share of the workgroup's counters
+                        const unsigned long long m = __ballot((mask >> part) & 1u);
+                        if (m != 0 && lane == 0) woff[wave][level * kGbMaxParts + part] = atomicAdd(&cnt[level * kGbMaxParts + part], (uint32_t)__popcll(m));
+                    }
+                } else {
+                    msk[level][threadIdx.x] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kBinSlots) {                                         // one global atomic per (level, partition) and workgroup trip
+            const uint32_t c = cnt[threadIdx.x];
+            base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x], c) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t level = 0; level < lv.L; level++) {
+            {
+                const uint32_t mask = msk[level][threadIdx.x];
+                if (__ballot(mask != 0) != 0) {                                // uniform per wave
+                    for (uint32_t part = 0; part < kGbMaxParts; part++) {
+                        const bool bit = (mask >> part) & 1u;
+                        const unsigned long long m = __ballot(bit);
+                        if (bit) {
+                            const uint32_t slot = level * kGbMaxParts + part;
+                            bins[(size_t)slot * B + base[slot] + woff[wave][slot] +
+                                 __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                       // woff / base are rewritten by the next trip
+    }
+}
+
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                               const int* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B,
                                                               gf::GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
-                                                              uint32_t flush_budget, uint32_t min_slices, const uint32_t* __restrict__ lvl_max) {
+                                                              uint32_t flush_budget, uint32_t min_slices, const uint32_t* __restrict__ lvl_max,
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ bins /* both NULL: no lists */) {
     __shared__ long long tab[kGbLdsEntries];
     const uint32_t level = blockIdx.y;
     const float gmax = __uint_as_float(lvl_max[level]);
@@ -353,12 +474,10 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     // 2^40 / gmax must stay finite: a level whose largest gradient is below 1e-25 scatters through the float path alone (to_fixed = 0)
     const float to_fixed = gmax > 1e-25f ? kGbFixedOne / gmax : 0.0f;
     const double from_fixed = (double)gmax / (double)kGbFixedOne;
-    const uint32_t off = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const GbLevelPlan plan = gb_level_plan<D, C>(offsets, lv, level, gridtype, align_corners);
+    const uint32_t off = plan.off, hashmap_size = plan.hashmap_size, nparts = plan.nparts;
     constexpr uint32_t rows_per_part = kGbLdsEntries / C;
-    uint32_t nparts = (hashmap_size + rows_per_part - 1) / rows_per_part;
-    const bool direct = nparts > kGbMaxParts;                      // workgroup-uniform
-    if (direct) nparts = 1;
+    const bool direct = plan.direct;                               // workgroup-uniform
     // Slices of the point list per level: a coarse level has few rows, so many slices cost little at the flush and cut the time its
     // workgroups spend serialising same-address LDS adds (neighbouring samples of a ray share the coarse cells); a fine level has
     // many rows (every one touched, every one an atomic per slice) and few conflicts, so it gets few slices.
@@ -374,18 +493,15 @@ __global__ void __launch_bounds__(kGbThreads) k_grid_backward(const float* __res
     const float scale = lv.scale[level];
     const uint32_t resolution = lv.resolution[level];
     float* table = grad_grid + (size_t)off * C;
-    // Row index without the generic rule's integer modulo (grid_row): dense levels never reach the table size, wrapped levels have a
-    // power-of-two size (grid.py:118-134 caps them at 2^log2_hashmap_size) -- the same reduction the fused lookup uses (LevelMeta).
-    gf::LevelMeta lm = {};
-    int mode = 0;                                                  // workgroup-uniform
-    if constexpr (D <= 3) {
-        lm = gf::make_level_meta<D>(scale, resolution, offsets, level, gridtype);
-        if (!align_corners && (lm.mask == 0xFFFFFFFFu || (hashmap_size & (hashmap_size - 1u)) == 0u)) mode = lm.use_hash ? 1 : 2;
-    }
-    const uint32_t per = (B + slices - 1) / slices;
-    const uint32_t b0 = slice * per < B ? slice * per : B, b1 = b0 + per < B ? b0 + per : B;
+    const gf::LevelMeta lm = plan.lm;
+    const int mode = plan.mode;                                    // workgroup-uniform
+    // the points this workgroup examines: its slice of the whole list, or -- k_grid_bin ran -- of its partition's own list
+    const uint32_t* idx = (bins && gb_level_binned(plan)) ? bins + ((size_t)level * kGbMaxParts + part) * B : nullptr;
+    const uint32_t total = idx ? counts[level * kGbMaxParts + part] : B;
+    const uint32_t per = (total + slices - 1) / slices;
+    const uint32_t b0 = slice * per < total ? slice * per : total, b1 = b0 + per < total ? b0 + per : total;
 #define GF_GB_POINTS(MODE, DIRECT) gb_points<D, C, MODE, DIRECT>(tab, grad, inputs, table, level, B, b0, b1, scale, resolution, hashmap_size, gridtype, \
-                                                               align_corners, interp, lm, row0, nrows, to_fixed)
+                                                               align_corners, interp, lm, row0, nrows, to_fixed, idx)
     if (direct) GF_GB_POINTS(0, true);
     else if (mode == 1) GF_GB_POINTS(1, false);
     else if (mode == 2) GF_GB_POINTS(2, false);
@@ -477,7 +593,8 @@ __global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __r
 
 template <uint32_t D>
 int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, const int* offsets, float* grad_grid, uint32_t B,
-                        const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s, const uint32_t* level_max = nullptr) {
+                        const gf::GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, hipStream_t s, const uint32_t* level_max = nullptr,
+                        uint32_t* counts = nullptr, uint32_t* bins = nullptr /* gf_grid_encode_backward_binned's workspace: the binning pass runs first */) {
     // workgroups per level (grid.x): partitions x slices, the surplus exits at once.  flush_budget = table floats x slices a level may
     // spend on flush atomics; min_slices keeps the fine levels' point lists short enough to balance the chip.
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
@@ -505,17 +622,24 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     }
     const dim3 mgrid(B >= (1u << 16) ? 128u : 8u, lv.L);
     const dim3 grid(wgs, lv.L), block(kGbThreads);
+    const uint32_t btrips = gf_div_up(B, kBinThreads);
+    const dim3 bgrid(btrips < 1024u ? btrips : 1024u);
+    if (bins && hipMemsetAsync(counts, 0, gf::kMaxLevels * kGbMaxParts * sizeof(uint32_t), s) != hipSuccess)
+        return gf_set_error(GF_ERR_HIP, "grid_encode_backward: hipMemsetAsync failed");
+#define GF_GB_CASE(CC)                                                                                                                          \
+    case CC:                                                                                                                                    \
+        if (own_max) hipLaunchKernelGGL((k_grid_absmax<CC>), mgrid, dim3(256), 0, s, grad, B, own_max);                                         \
+        if constexpr (D <= 3) {                                                                                                                 \
+            if (bins) hipLaunchKernelGGL((k_grid_bin<D, CC>), bgrid, dim3(kBinThreads), 0, s, grad, inputs, offsets, B, lv, gridtype, ac, lvl_max, counts, bins); \
+        }                                                                                                                                       \
+        hipLaunchKernelGGL((k_grid_backward<D, CC>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, \
+                           min_slices, lvl_max, (const uint32_t*)(D <= 3 ? counts : nullptr), (const uint32_t*)(D <= 3 ? bins : nullptr));      \
+        break;
     switch (C) {
-        case 1: if (own_max) hipLaunchKernelGGL((k_grid_absmax<1>), mgrid, dim3(256), 0, s, grad, B, own_max);
-                hipLaunchKernelGGL((k_grid_backward<D, 1>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 2: if (own_max) hipLaunchKernelGGL((k_grid_absmax<2>), mgrid, dim3(256), 0, s, grad, B, own_max);
-                hipLaunchKernelGGL((k_grid_backward<D, 2>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 4: if (own_max) hipLaunchKernelGGL((k_grid_absmax<4>), mgrid, dim3(256), 0, s, grad, B, own_max);
-                hipLaunchKernelGGL((k_grid_backward<D, 4>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
-        case 8: if (own_max) hipLaunchKernelGGL((k_grid_absmax<8>), mgrid, dim3(256), 0, s, grad, B, own_max);
-                hipLaunchKernelGGL((k_grid_backward<D, 8>), grid, block, 0, s, grad, inputs, offsets, grad_grid, B, lv, gridtype, ac, interp, flush_budget, min_slices, lvl_max); break;
+        GF_GB_CASE(1) GF_GB_CASE(2) GF_GB_CASE(4) GF_GB_CASE(8)
         default: return gf_set_error(GF_ERR_INVALID, "GridEncoding: C must be 1, 2, 4, or 8.");
     }
+#undef GF_GB_CASE
     return gf_check_launch("grid_encode_backward");
 }
 
@@ -678,6 +802,33 @@ GF_EXPORT int gf_grid_encode_backward_scaled(const float* grad, const float* inp
         case 2: return dispatch_backward_c<2>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max);
         case 3: return dispatch_backward_c<3>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max);
         default: return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_scaled: D must be 2 or 3");
+    }
+}
+
+// The same scatter with the BINNING PASS in front (k_grid_bin, round 6): every (point, level) is examined once for the row partitions its
+// corners touch, and each of k_grid_backward's workgroups then reads its own partition's list instead of every point.
+// workspace: gf_grid_backward_ws_bytes(B, L) bytes of device scratch (32 x 8 counters + L x 8 lists of B indices: sized for 288 GB of HBM, not
+// for thrift -- 512 MiB at B = 2^20, L = 16); the table gradient is the one gf_grid_encode_backward_scaled computes up to the rounding of the flush (which points
+// share a slice's integer partial changes, and the partials reach the table as float atomics in either form).
+GF_EXPORT uint64_t gf_grid_backward_ws_bytes(uint32_t B, uint32_t L) {
+    return (uint64_t)gf::kMaxLevels * kGbMaxParts * sizeof(uint32_t) + (uint64_t)L * kGbMaxParts * sizeof(uint32_t) * (uint64_t)B;
+}
+GF_EXPORT int gf_grid_encode_backward_binned(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                             uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                             const uint32_t* level_max, void* workspace, void* stream) {
+    if (B == 0) return GF_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings || !level_max || !workspace) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_binned: null pointer");
+    if (gridtype > 1 || interp > 1) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_binned: gridtype/interp must be 0 or 1");
+    gf::GridLevels lv;
+    if (gf::fill_grid_levels(lv, L, S, H) != 0) return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_binned: L must be in [1,32]");
+    hipStream_t s = gf_stream(stream);
+    const bool ac = align_corners != 0;
+    uint32_t* counts = static_cast<uint32_t*>(workspace);
+    uint32_t* bins = counts + gf::kMaxLevels * kGbMaxParts;
+    switch (D) {
+        case 2: return dispatch_backward_c<2>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max, counts, bins);
+        case 3: return dispatch_backward_c<3>(C, grad, inputs, offsets, grad_embeddings, B, lv, gridtype, ac, interp, s, level_max, counts, bins);
+        default: return gf_set_error(GF_ERR_INVALID, "grid_encode_backward_binned: D must be 2 or 3");
     }
 }
 

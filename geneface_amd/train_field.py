@@ -131,6 +131,10 @@ def _fused_wgrad(st, half, M, dev, weights, mats):
     return outs
 
 
+_GRID_BINNING = __import__("os").environ.get("GF_GRID_BINNING", "1") != "0"     # False (GF_GRID_BINNING=0): gf_grid_encode_backward_scaled without the binning pass (A/B; tests compare the two bit for bit)
+_GRID_WS = {}            # device -> uint8 workspace of gf_grid_encode_backward_binned
+
+
 def _grid_backward(enc, x01, grad, want_input_grad, level_major=False, level_max=None):
     """Table gradient (and d/d x01 through a freshly evaluated dy_dx) of GridEncoder `enc` at inputs x01 [M,D] for an output gradient
     `grad` [M, L*C] (or already [L, M, C] with level_major): the library's backward kernels, without re-entering autograd.  level_max: the
@@ -142,6 +146,16 @@ def _grid_backward(enc, x01, grad, want_input_grad, level_major=False, level_max
     S = float(np.log2(enc.per_level_scale))
     if level_max is not None and level_major and not want_input_grad:
         g_tab = torch.zeros_like(enc.embeddings)
+        if _GRID_BINNING and B >= 4096:
+            # the binning pass in front of the scatter (round 6): one workspace per device, shared by the calls of a stream (they are ordered)
+            need = L_.gf_grid_backward_ws_bytes(B, L)
+            ws = _GRID_WS.get(dev)
+            if ws is None or ws.numel() < need:
+                ws = _GRID_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+            check(L_.gf_grid_encode_backward_binned(ptr(grad, torch.float32), ptr(x01, torch.float32), ptr(enc.offsets, torch.int32), ptr(g_tab, torch.float32),
+                                                    B, D, Cc, L, S, int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
+                                                    ptr(level_max, torch.int32), ws.data_ptr(), current_stream(dev)))
+            return g_tab, None
         check(L_.gf_grid_encode_backward_scaled(ptr(grad, torch.float32), ptr(x01, torch.float32), ptr(enc.offsets, torch.int32), ptr(g_tab, torch.float32),
                                                 B, D, Cc, L, S, int(enc.base_resolution), enc.gridtype_id, int(bool(enc.align_corners)), enc.interp_id,
                                                 ptr(level_max, torch.int32), current_stream(dev)))

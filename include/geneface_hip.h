@@ -360,6 +360,14 @@ int gf_field_wgrad32(uint32_t M, const gf_field_wgrad_t* w, void* stream);
 int gf_grid_encode_backward_scaled(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
                                    uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
                                    const uint32_t* level_max, void* stream);
+/* The same scatter with a BINNING PASS in front (round 6): one lane per point walks the levels once and appends the point to the list of every
+ * row partition its corners touch; each scatter workgroup then reads its own partition's list instead of examining every point (the reference
+ * has no counterpart: its kernel issues one global atomic per point, level, corner and channel, gridencoder.cu:248-339).  workspace:
+ * gf_grid_backward_ws_bytes(B, L) bytes of device scratch.  Same table gradient as gf_grid_encode_backward_scaled. */
+uint64_t gf_grid_backward_ws_bytes(uint32_t B, uint32_t L);
+int gf_grid_encode_backward_binned(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                   uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                   const uint32_t* level_max, void* workspace, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Torso field for TRAINING (round 6): RADNeRFTorso.forward_torso (modules/radnerfs/radnerf_torso.py:51-84) on a list of M pixel coordinates
  * as two launches -- forward with every layer's activations saved, and the input-gradient chain -- replacing the ~60 + ~120 torch launches

@@ -1,5 +1,6 @@
 """-m gpu: training-tier ray-marching ops through the C ABI against the oracle, and the autograd wrappers
 of geneface_amd/raymarching.py (raymarching.py:185-342 of the reference)."""
+import numpy as np
 import pytest
 import torch
 
@@ -608,3 +609,55 @@ def test_fp32_node_fused_weight_gradients_vs_library_products():
     for n, gr in res["gemm"].items():
         l2 = float((res["fused"][n] - gr).double().norm() / gr.double().norm().clamp(min=1e-20))
         assert l2 < 2e-5, (n, l2)
+
+
+@pytest.mark.parametrize("D,gridtype,interp,B", [(3, 1, 0, 300_001), (2, 1, 0, 300_001), (3, 0, 0, 70_001), (2, 0, 1, 70_001), (3, 1, 1, 5_000)])
+def test_binned_table_scatter_is_the_unbinned_one(D, gridtype, interp, B):
+    """gf_grid_encode_backward_binned (k_grid_bin in front of the scatter: each row partition reads its own list of points) against
+    gf_grid_encode_backward_scaled on the same inputs: the same contributions in integer partials over other groupings of the points: the two
+    table gradients agree to fp32 rounding of the flush, and both agree with a float64 scatter.  Tiled and hashed tables of the May size, points out of range, zero-gradient points (terminated
+    samples), a level with an all-zero gradient."""
+    import ctypes as C
+    from geneface_amd.encoders.gridencoder import grid_offsets
+    from geneface_amd.lib import check, current_stream, lib
+    L_ = lib()
+    g = torch.Generator(device=DEV).manual_seed(100 * D + B % 97)
+    off_h = grid_offsets(D, 16, 16, 16, 2048)
+    off = torch.from_numpy(off_h).to(DEV)
+    x = torch.rand(B, D, device=DEV, generator=g)
+    x[::501] = 1.25                                         # out of range
+    x[7::733] = float("nan")
+    grad = torch.randn(16, B, 2, device=DEV, generator=g)
+    grad[:, 3::5] = 0.0                                     # samples behind a ray's end carry exact zeros at every level
+    grad[5] = 0.0                                           # a level nobody contributes to
+    S = float(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    lmax = grad.abs().amax(dim=(1, 2)).contiguous().view(torch.int32)
+    st = current_stream(torch.device(DEV))
+    ws = torch.empty(L_.gf_grid_backward_ws_bytes(B, 16), dtype=torch.uint8, device=DEV)
+    tabs = []
+    for binned in (False, True, True):
+        t = torch.zeros(int(off_h[-1]), 2, device=DEV)
+        ws.fill_(0xAB)
+        if binned:
+            check(L_.gf_grid_encode_backward_binned(grad.data_ptr(), x.data_ptr(), off.data_ptr(), t.data_ptr(), B, D, 2, 16, S, 16, gridtype, 0, interp,
+                                                    lmax.data_ptr(), ws.data_ptr(), st))
+        else:
+            check(L_.gf_grid_encode_backward_scaled(grad.data_ptr(), x.data_ptr(), off.data_ptr(), t.data_ptr(), B, D, 2, 16, S, 16, gridtype, 0, interp,
+                                                    lmax.data_ptr(), st))
+        torch.cuda.synchronize()
+        tabs.append(t)
+    plain, b1, b2 = tabs
+    scale = float(plain.abs().max())
+    assert scale > 0 and torch.isfinite(plain).all()
+    for other in (b1, b2):
+        # not bit for bit: which points share a slice's integer partial differs (list order), and every partial reaches the table as a float
+        # atomic -- last-ulp differences, as between two runs of either form
+        assert float((other - plain).abs().max()) <= 2e-6 * scale
+    assert not plain[int(off_h[5]):int(off_h[6])].any() and not b1[int(off_h[5]):int(off_h[6])].any()
+    # float64 scatter of the same contributions (the oracle's kernel, double accumulators)
+    g64 = torch.zeros(int(off_h[-1]), 2, dtype=torch.float32)
+    xc = x.cpu().clone()
+    xc[torch.isnan(xc)] = 1.25                              # the product treats NaN as out of range; the restated reference kernel must not see it
+    K.gridencoder.grid_encode_backward(grad.cpu().contiguous(), xc.contiguous(), torch.zeros_like(g64), torch.from_numpy(off_h), g64, B, D, 2, 16, S, 16,
+                                       None, None, gridtype, False, interp)
+    assert float((b1.cpu() - g64).abs().max()) < 2e-4 * max(1.0, float(g64.abs().max()))
