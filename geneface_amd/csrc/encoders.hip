@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "common.hpp"
+#include <stdlib.h>
 #include "grid_core.hpp"
 #include "sh_core.hpp"
 
@@ -599,6 +600,11 @@ int dispatch_backward_c(uint32_t C, const float* grad, const float* inputs, cons
     // spend on flush atomics; min_slices keeps the fine levels' point lists short enough to balance the chip.
     uint32_t flush_budget = 1u << 22, min_slices = B >= (1u << 19) ? 8u : (B >= (1u << 16) ? 2u : 1u), wgs = 128;
     if (B < (1u << 16)) wgs = 32;
+#ifdef GF_GB_TUNE      // A/B builds only: GF_GB_FLUSH_LOG2 / GF_GB_MIN_SLICES / GF_GB_WGS from the environment
+    if (const char* e = getenv("GF_GB_FLUSH_LOG2")) flush_budget = 1u << atoi(e);
+    if (const char* e = getenv("GF_GB_MIN_SLICES")) min_slices = (uint32_t)atoi(e);
+    if (const char* e = getenv("GF_GB_WGS")) wgs = (uint32_t)atoi(e);
+#endif
     // int64 headroom (kGbFixedOne = 2^40): an entry takes at most 2^D <= 8 full-size contributions per point of a slice, so a slice holds at most
     // 2^20 points (8 x 2^20 x 2^40 = 2^63); a point list longer than min_slices x 2^20 gets more slices (and the workgroups for them)
     const uint32_t need = (uint32_t)(((uint64_t)B + (1u << 20) - 1) >> 20);

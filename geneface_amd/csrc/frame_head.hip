@@ -327,6 +327,36 @@ __device__ __forceinline__ void obw_save(float* __restrict__ G, uint32_t gbase, 
     }
 }
 
+// The ReLU mask alone (the row itself leaves through rows32_to_global).
+template <int NT>
+__device__ __forceinline__ void obw_mask(uint16_t* __restrict__ mask, uint32_t gbase, int wave, int lane, const floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) bits |= (acc[t][r] > 0.0f ? 1u : 0u) << r;
+        mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane] = (uint16_t)bits;
+    }
+}
+
+// A layer's 128 x 128 fp32 rows from the LDS activation buffer to their [M,128] matrix (round 6; see rows16_to_global for the why): after the
+// barrier that follows the layer's write-back, 32 consecutive lanes move one whole 512-byte row, a wave instruction two complete rows.  The
+// matrix pointer stays a kernel argument and the lane adds one 32-bit byte offset (the training kernels have no register to spare): hence
+// M * 512 B < 4 GiB on this tier.  Same bits: H holds the same (ReLU'd) accumulator values.
+__device__ __forceinline__ void rows32_to_global(const float* H, float* __restrict__ G, uint32_t gbase, uint32_t Mv, int tid) {
+    __builtin_amdgcn_sched_barrier(0);
+    char* __restrict__ Gc = reinterpret_cast<char*>(G);
+    const int row0 = tid >> 5, col = (tid & 31) * 4;
+    const float* src = H + row0 * kHS + col;
+    const uint32_t dst = ((gbase + (uint32_t)row0) * 128u + (uint32_t)col) * 4u;
+#pragma unroll 1
+    for (int i = 0; i < kPass * 32 / kThreads; i++) {
+        if ((uint32_t)(row0 + 8 * i) < Mv)
+            *reinterpret_cast<float4*>(Gc + (dst + (uint32_t)i * (8u * 512u))) = *reinterpret_cast<const float4*>(src + i * 8 * kHS);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // NOUT skinny outputs of one sample on a lane pair: lane half h sums features 64h .. 64h+63 of the sample's row, the halves
 // are added with one cross-half exchange (both lanes end up with the same value).
 template <int NOUT>
@@ -495,10 +525,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(10);
     obw_store<NT, true>(Hw, A);
-    if constexpr (SAVE) obw_save<NT, true>(sv->ha1, gbase, Mv, wave, lane, A, sv->m_ha1);
+    if constexpr (SAVE) obw_mask<NT>(sv->m_ha1, gbase, wave, lane, A);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
+    if constexpr (SAVE) rows32_to_global(s.H, sv->ha1, gbase, Mv, wave * 64 + lane);
     // ---- ambient L2
     GF_PRIO_LO();
     obw_zero<NT>(A);
@@ -565,10 +596,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(20);
     obw_store<NT, true>(Hw, S);
-    if constexpr (SAVE) obw_save<NT, true>(sv->hs1, gbase, Mv, wave, lane, S, sv->m_hs1);
+    if constexpr (SAVE) obw_mask<NT>(sv->m_hs1, gbase, wave, lane, S);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
+    if constexpr (SAVE) rows32_to_global(s.H, sv->hs1, gbase, Mv, wave * 64 + lane);
     // ---- density L2
     GF_PRIO_LO();
     obw_zero<NT>(A);
@@ -585,10 +617,11 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
         skinny_publish<NT, 1>(s.H + j * kHS + 128 + wave, half, part);
     }
 #endif
-    if constexpr (SAVE) obw_save<NT, true>(sv->hs2, gbase, Mv, wave, lane, A, sv->m_hs2);
+    if constexpr (SAVE) obw_mask<NT>(sv->m_hs2, gbase, wave, lane, A);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
+    if constexpr (SAVE) rows32_to_global(s.H, sv->hs2, gbase, Mv, wave * 64 + lane);
     // ---- density L3: row 0 on the VALU (sigma = exp, trunc_exp forward has no clamp: utils.py:41), rows 1..128 = geometry feature
     float sigma = 0.0f;
     if (tile_on) {
@@ -616,10 +649,10 @@ __device__ __forceinline__ void field_round(const HeadArgs& a, const Smem& s, ui
     __syncthreads();
     GF_STAMP(28);
     obw_store<NT, false>(Hw, A);   // no activation
-    if constexpr (SAVE) obw_save<NT, false>(sv->geo, gbase, Mv, wave, lane, A);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
+    if constexpr (SAVE) rows32_to_global(s.H, sv->geo, gbase, Mv, wave * 64 + lane);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
     obw_bias<NT>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
     {
@@ -831,6 +864,9 @@ struct SaveBufs16 {
 template <bool RELU>
 __device__ __forceinline__ void obw16_save(_Float16* __restrict__ G, uint32_t gbase, uint32_t Mv, int wave, int lane, const floatx16 (&acc)[4], int nt,
                                            uint16_t* __restrict__ mask = nullptr) {
+#ifdef GF_PROBE_NO_SAVES      // timing probe only (garbage gradients): what the save stream costs the training forward / the dX chain
+    return;
+#endif
     const int half = lane >> 5, j = lane & 31;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -852,6 +888,56 @@ __device__ __forceinline__ void obw16_save(_Float16* __restrict__ G, uint32_t gb
             }
         }
     }
+}
+
+// The ReLU mask alone (the row itself leaves through rows16_to_global).
+__device__ __forceinline__ void obw16_mask(uint16_t* __restrict__ mask, uint32_t gbase, int wave, int lane, const floatx16 (&acc)[4], int nt) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t < nt) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) bits |= (acc[t][r] > 0.0f ? 1u : 0u) << r;
+            mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane] = (uint16_t)bits;
+        }
+    }
+}
+
+// A layer's 128 x 128 binary16 rows from the LDS activation buffer to their [M,128] matrix (round 6): after the barrier that follows the layer's
+// write-back the rows sit in H16 row-major, so 16 consecutive lanes move one whole 256-byte row with 16-byte loads and stores -- a wave
+// instruction writes four complete rows.  Until then every lane stored the four 8-byte pieces of ITS sample's row per tile straight from the
+// accumulators: 16 store instructions per layer and wave, each touching 32 different rows, and the whole save stream showed up on top of the
+// kernel's time (tools/visits/r6s.sh: forward 1.00 -> 0.63 ms, dX chain 1.16 -> 0.85 ms with the stores removed).  Same bits: H16 holds the
+// (_Float16) of the same ReLU'd accumulator.  Called right after the barrier, before the next layer's accumulators exist (few live registers).
+template <bool WIDE = true>
+__device__ __forceinline__ void rows16_to_global(const _Float16* H16, _Float16* __restrict__ G, uint32_t gbase, uint32_t Mv, int tid) {
+    // one per-lane offset for all eight pieces (they are 16 rows = 4 KiB apart), the chunk's base a workgroup-uniform pointer: two more live
+    // registers than the kernel had, not two per piece (k_field_backward16 stands at 256 VGPRs)
+    __builtin_amdgcn_sched_barrier(0);       // nothing of the next layer is hoisted above the copy (its operands would be live across it)
+    // the matrix pointer stays the kernel argument (scalar registers) and the lane adds ONE 32-bit byte offset: k_field_backward16 stands at 256
+    // VGPRs with its scalar registers already spilling into vector lanes -- a 64-bit per-lane address, or one more scalar pair per matrix, and
+    // the thread index went to scratch.  Hence the entry points' bound M * 256 B < 4 GiB on this tier.
+    char* __restrict__ Gc = reinterpret_cast<char*>(G);
+    if constexpr (WIDE) {
+        const int row0 = tid >> 4, col = (tid & 15) * 8;
+        const _Float16* src = H16 + row0 * kHS16 + col;
+        const uint32_t dst = ((gbase + (uint32_t)row0) * 128u + (uint32_t)col) * 2u;
+#pragma unroll 1
+        for (int i = 0; i < kPass * 16 / kThreads; i++) {
+            if ((uint32_t)(row0 + 16 * i) < Mv)
+                *reinterpret_cast<float4*>(Gc + (dst + (uint32_t)i * (16u * 256u))) = *reinterpret_cast<const float4*>(src + i * 16 * kHS16);
+        }
+    } else {      // 8-byte pieces, 32 lanes per row: two transient registers instead of four
+        const int row0 = tid >> 5, col = (tid & 31) * 4;
+        const _Float16* src = H16 + row0 * kHS16 + col;
+        const uint32_t dst = ((gbase + (uint32_t)row0) * 128u + (uint32_t)col) * 2u;
+#pragma unroll 1
+        for (int i = 0; i < kPass * 32 / kThreads; i++) {
+            if ((uint32_t)(row0 + 8 * i) < Mv)
+                *reinterpret_cast<float2*>(Gc + (dst + (uint32_t)i * (8u * 256u))) = *reinterpret_cast<const float2*>(src + i * 8 * kHS16);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // TRAIN (dense point lists only): tanh(ambient) is left in s.sdt / s.st [raw] and every layer's activations go to `sv`.
@@ -924,10 +1010,11 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     GF_STAMP(9);
     GF_STAMP(10);
     obw16_store<true>(Hw, A, nt);          // H is not read by this layer: no barrier before the write-back
-    if constexpr (TRAIN) obw16_save<true>(sv->ha1, gbase, Mv, wave, lane, A, nt, sv->m_ha1);
+    if constexpr (TRAIN) obw16_mask(sv->m_ha1, gbase, wave, lane, A, nt);
     GF_STAMP(11);
     __syncthreads();
     GF_STAMP(12);
+    if constexpr (TRAIN) rows16_to_global(H16, sv->ha1, gbase, Mv, wave * 64 + lane);
     // ---- ambient L2
     obw_zero<4>(A);
     obw16_mfma<gf::H16_AMB2, 8>(wp, Ws, lane16, Hb, A, nt);
@@ -1001,10 +1088,11 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(20);
     obw16_store<true>(Hw, A, nt);
-    if constexpr (TRAIN) obw16_save<true>(sv->hs1, gbase, Mv, wave, lane, A, nt, sv->m_hs1);
+    if constexpr (TRAIN) obw16_mask(sv->m_hs1, gbase, wave, lane, A, nt);
     GF_STAMP(21);
     __syncthreads();
     GF_STAMP(22);
+    if constexpr (TRAIN) rows16_to_global(H16, sv->hs1, gbase, Mv, wave * 64 + lane);
     // ---- density L2
     obw_zero<4>(A);
     obw16_mfma<gf::H16_SIG2, 8>(wp, Ws, lane16, Hb, A, nt);
@@ -1019,10 +1107,11 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
         skinny_publish<4, 1, kHF16>(Hf + j * kHF16 + 64 + wave, half, part);       // the row's 16 pad bytes (halves 128..135)
     }
 #endif
-    if constexpr (TRAIN) obw16_save<true>(sv->hs2, gbase, Mv, wave, lane, A, nt, sv->m_hs2);
+    if constexpr (TRAIN) obw16_mask(sv->m_hs2, gbase, wave, lane, A, nt);
     GF_STAMP(25);
     __syncthreads();
     GF_STAMP(26);
+    if constexpr (TRAIN) rows16_to_global(H16, sv->hs2, gbase, Mv, wave * 64 + lane);
     // ---- density L3: row 0 on the VALU, rows 1..128 = geometry feature
     float sigma = 0.0f;
     if (tile_on) {
@@ -1043,10 +1132,10 @@ __device__ __forceinline__ void field_round16(const HeadArgs& a, const Smem& s, 
     __syncthreads();
     GF_STAMP(28);
     obw16_store<false>(Hw, A, nt);
-    if constexpr (TRAIN) obw16_save<false>(sv->geo, gbase, Mv, wave, lane, A, nt);
     GF_STAMP(29);
     __syncthreads();
     GF_STAMP(30);
+    if constexpr (TRAIN) rows16_to_global(H16, sv->geo, gbase, Mv, wave * 64 + lane);
     // ---- colour L1: [SH(dir) 16 | geometry 128 | identity code -> bias]
     obw_bias<4>(s.P + P_SMALL + gf::HS_COLBIAS + wave * 32 + half * 16, A);
     {
@@ -2143,14 +2232,16 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
     }
     __syncthreads();
-    bwd_mask_pass<NT, O16>(Hw, u.g_hc1, u.m_hc1, gbase, Mv, wave, lane, A, cs_hc1);      // d h_c1 (pre-activation)
+    bwd_mask_pass<NT, O16>(Hw, O16 ? u.g_hc1 : nullptr, u.m_hc1, gbase, Mv, wave, lane, A, cs_hc1);      // d h_c1 (pre-activation)
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_hc1, gbase, Mv, wave * 64 + lane);
     // ---- d geo = W_c1[:, 16:144]^T d h_c1
     obw_zero<NT>(A);
     obw_mfma<NT, BG_C1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, false, O16>(Hw, u.g_geo, nullptr, gbase, Mv, wave, lane, A);
+    bwd_store<NT, false, O16>(Hw, O16 ? u.g_geo : nullptr, nullptr, gbase, Mv, wave, lane, A);
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_geo, gbase, Mv, wave * 64 + lane);
     // ---- d h_s2 = W_s3[1:]^T d geo + d h0 (x) W_s3[0], masked
     {
         const float* w0 = s.P + P_SMALL + gf::HS_SIGROW + 32 * wave + 4 * half;
@@ -2166,14 +2257,16 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
     }
     obw_mfma<NT, BG_S3, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true, O16>(Hw, u.g_hs2, u.m_hs2, gbase, Mv, wave, lane, A);
+    bwd_store<NT, true, O16>(Hw, O16 ? u.g_hs2 : nullptr, u.m_hs2, gbase, Mv, wave, lane, A);
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_hs2, gbase, Mv, wave * 64 + lane);
     // ---- d h_s1 = W_s2^T d h_s2, masked
     obw_zero<NT>(A);
     obw_mfma<NT, BG_S2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true, O16>(Hw, u.g_hs1, u.m_hs1, gbase, Mv, wave, lane, A);
+    bwd_store<NT, true, O16>(Hw, O16 ? u.g_hs1 : nullptr, u.m_hs1, gbase, Mv, wave, lane, A);
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_hs1, gbase, Mv, wave * 64 + lane);
     // ---- [d f3 (sigma branch) | d f2] = W_s1^T d h_s1   (64 real outputs, zero-padded to 128)
     obw_zero<NT>(A);
     obw_mfma<NT, BG_S1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
@@ -2225,14 +2318,16 @@ __device__ __forceinline__ void bwd_round(const HeadArgs& a, const BwdArgs& u, c
         }
     }
     __syncthreads();
-    bwd_mask_pass<NT, O16>(Hw, u.g_ha2, u.m_ha2, gbase, Mv, wave, lane, A);      // d h_a2
+    bwd_mask_pass<NT, O16>(Hw, O16 ? u.g_ha2 : nullptr, u.m_ha2, gbase, Mv, wave, lane, A);      // d h_a2
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_ha2, gbase, Mv, wave * 64 + lane);
     // ---- d h_a1 = W_a2^T d h_a2, masked
     obw_zero<NT>(A);
     obw_mfma<NT, BG_A2, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
     __syncthreads();
-    bwd_store<NT, true, O16>(Hw, u.g_ha1, u.m_ha1, gbase, Mv, wave, lane, A, cs_ha1);
+    bwd_store<NT, true, O16>(Hw, O16 ? u.g_ha1 : nullptr, u.m_ha1, gbase, Mv, wave, lane, A, cs_ha1);
     __syncthreads();
+    if constexpr (!O16) rows32_to_global(s.H, u.g_ha1, gbase, Mv, wave * 64 + lane);
     // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1   (32 real outputs, zero-padded)
     obw_zero<NT>(A);
     obw_mfma<NT, BG_A1, 16, BG_TOTAL>(wp, Ws, lane16, Hb, A);
@@ -2327,7 +2422,8 @@ __device__ __forceinline__ void bwd16_store(_Float16* Hw, _Float16* __restrict__
             uint32_t bits = 0xFFFFu;
             if (MASK) bits = mask[(((size_t)(gbase / kPass) * 4 + t) * 4 + wave) * 64 + lane];
             const bool ok = (uint32_t)(t * 32 + j) < Mv;
-            _Float16* row = G ? G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half : nullptr;
+            _Float16* row = nullptr;      // (round 6: the rows leave LDS through rows16_to_global after the barrier; G is kept for a caller that has no such window)
+            if (G) row = G + (size_t)(gbase + (uint32_t)(t * 32 + j)) * 128 + 32 * wave + 4 * half;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float4 v = {acc[t][4 * q + 0], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
@@ -2337,7 +2433,9 @@ __device__ __forceinline__ void bwd16_store(_Float16* Hw, _Float16* __restrict__
                 }
                 const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 *reinterpret_cast<half4*>(Hw + t * 32 * kHS16 + 8 * q) = h;
+#ifndef GF_PROBE_NO_SAVES
                 if (row && ok) *reinterpret_cast<half4*>(row + 8 * q) = h;
+#endif
                 if constexpr (CS) {
                     if (ok) { part[4 * q] += v.x; part[4 * q + 1] += v.y; part[4 * q + 2] += v.z; part[4 * q + 3] += v.w; }
                 }
@@ -2436,14 +2534,16 @@ __device__ __forceinline__ void bwd_round16(const HeadArgs& a, const BwdArgs& u,
         const float* const z[3] = {s.sx, s.sy, s.sz};
         rank_k_acc<3>(z, s.P + P_SMALL + gf::HS_COL2, wave, half, j, A, nt);
     }
-    bwd16_store<true, true>(Hw, G16(u.g_hc1), u.m_hc1, gbase, Mv, wave, lane, A, nt, cs_hc1);
+    bwd16_store<true, true>(Hw, nullptr, u.m_hc1, gbase, Mv, wave, lane, A, nt, cs_hc1);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_hc1), gbase, Mv, wave * 64 + lane);
     // ---- d geo = W_c1[:, 16:144]^T d h_c1
     obw_zero<4>(A);
     obw16_mfma<BH_C1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
     __syncthreads();
-    bwd16_store<false>(Hw, G16(u.g_geo), nullptr, gbase, Mv, wave, lane, A, nt);
+    bwd16_store<false>(Hw, nullptr, nullptr, gbase, Mv, wave, lane, A, nt);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_geo), gbase, Mv, wave * 64 + lane);
     // ---- d h_s2 = W_s3[1:]^T d geo + d h0 (x) W_s3[0], masked
     {
         const float* const z[1] = {s.sdt};
@@ -2451,14 +2551,16 @@ __device__ __forceinline__ void bwd_round16(const HeadArgs& a, const BwdArgs& u,
     }
     obw16_mfma<BH_S3, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
     __syncthreads();
-    bwd16_store<true>(Hw, G16(u.g_hs2), u.m_hs2, gbase, Mv, wave, lane, A, nt);
+    bwd16_store<true>(Hw, nullptr, u.m_hs2, gbase, Mv, wave, lane, A, nt);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_hs2), gbase, Mv, wave * 64 + lane);
     // ---- d h_s1 = W_s2^T d h_s2, masked
     obw_zero<4>(A);
     obw16_mfma<BH_S2, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
     __syncthreads();
-    bwd16_store<true>(Hw, G16(u.g_hs1), u.m_hs1, gbase, Mv, wave, lane, A, nt);
+    bwd16_store<true>(Hw, nullptr, u.m_hs1, gbase, Mv, wave, lane, A, nt);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_hs1), gbase, Mv, wave * 64 + lane);
     // ---- [d f3 (sigma branch) | d f2] = W_s1^T d h_s1  (64 real outputs) -> fp32 scratch
     obw_zero<4>(A);
     obw16_mfma<BH_S1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
@@ -2513,14 +2615,16 @@ __device__ __forceinline__ void bwd_round16(const HeadArgs& a, const BwdArgs& u,
         const float* const z[2] = {s.st, s.ob};
         rank_k_acc<2>(z, s.P + P_SMALL + gf::HS_AMB3, wave, half, j, A, nt);
     }
-    bwd16_store<true>(Hw, G16(u.g_ha2), u.m_ha2, gbase, Mv, wave, lane, A, nt);
+    bwd16_store<true>(Hw, nullptr, u.m_ha2, gbase, Mv, wave, lane, A, nt);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_ha2), gbase, Mv, wave * 64 + lane);
     // ---- d h_a1 = W_a2^T d h_a2, masked
     obw_zero<4>(A);
     obw16_mfma<BH_A2, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
     __syncthreads();
-    bwd16_store<true, true>(Hw, G16(u.g_ha1), u.m_ha1, gbase, Mv, wave, lane, A, nt, cs_ha1);
+    bwd16_store<true, true>(Hw, nullptr, u.m_ha1, gbase, Mv, wave, lane, A, nt, cs_ha1);
     __syncthreads();
+    rows16_to_global<true>(H16, G16(u.g_ha1), gbase, Mv, wave * 64 + lane);
     // ---- d f3 (ambient branch) = W_a1[:, :32]^T d h_a1  (32 real outputs) -> fp32 scratch, added to the sigma branch's share
     obw_zero<4>(A);
     obw16_mfma<BH_A1, 8, kHS16, BH_TOTAL>(wp, Ws, lane16, Hb, A, nt);
@@ -2941,6 +3045,7 @@ static int field_forward_impl(const gf_frame_t* f, const float* xyz, const float
     ha.gridtype = f->gridtype; ha.interp = f->interp; ha.bound = f->bound;
     PointArgs pa = {xyz, dirs, col_bias_or_null, sigma, rgb, ambient_or_null, M, {}};
     if (saves) {
+        if (M > (1u << 23) - 128u) return gf_set_error(GF_ERR_UNSUPPORTED, "field_forward_train: the saves are addressed with 32-bit byte offsets: M < 2^23");
         if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1)
             return gf_set_error(GF_ERR_INVALID, "field_forward_train: null save buffer");
         pa.sv = {saves->f3, saves->ha1, saves->ha2, saves->f2, saves->hs1, saves->hs2, saves->geo, saves->hc1,
@@ -2968,6 +3073,7 @@ GF_EXPORT int gf_field_forward_train16(const gf_frame_t* f, const float* xyz, co
     if (!saves->f3 || !saves->ha1 || !saves->ha2 || !saves->f2 || !saves->hs1 || !saves->hs2 || !saves->geo || !saves->hc1 || !saves->sh ||
         !saves->m_ha1 || !saves->m_ha2 || !saves->m_hs1 || !saves->m_hs2 || !saves->m_hc1)
         return gf_set_error(GF_ERR_INVALID, "field_forward_train16: null save buffer");
+    if (M > (1u << 24) - 128u) return gf_set_error(GF_ERR_UNSUPPORTED, "field_forward_train16: the saves are addressed with 32-bit byte offsets: M < 2^24");
     HeadArgs ha = {};
     if (gf::fill_grid_levels(ha.lv3, 16, f->pos_S, f->base_res) || gf::fill_grid_levels(ha.lv2, 16, f->amb_S, f->base_res))
         return gf_set_error(GF_ERR_INVALID, "field_forward_train16: bad grid levels");
@@ -3024,6 +3130,8 @@ GF_EXPORT int gf_field_backward(const gf_frame_t* f, const float* bwd_stream, ui
     if (const int e = gf_raise_lds_limit(lds[0], reinterpret_cast<const void*>(k_field_backward<false>), kSmemBytes, "field_backward")) return e;
     if (const int e = gf_raise_lds_limit(lds[1], reinterpret_cast<const void*>(k_field_backward<true>), kSmemBytes, "field_backward")) return e;
     const uint32_t chunks = gf_div_up(M, (uint32_t)kPass);
+    if (g->out16 == 0 && M > (1u << 23) - 128u) return gf_set_error(GF_ERR_UNSUPPORTED, "field_backward: the fp32 chain addresses its [M,128] rows with 32-bit byte offsets: M < 2^23");
+    if (g->out16 == 2 && M > (1u << 24) - 128u) return gf_set_error(GF_ERR_UNSUPPORTED, "field_backward: the f16 chain addresses its [M,128] rows with 32-bit byte offsets: M < 2^24");
     if (g->out16 == 2) {      // the whole chain on the f16 matrix pipe: bwd_stream holds gf_field_bwd16_stream_halves() binary16 values
         static GfLdsAttr lds16;
         if (const int e = gf_raise_lds_limit(lds16, reinterpret_cast<const void*>(k_field_backward16), kSmemBytes, "field_backward")) return e;
