@@ -344,6 +344,9 @@ __device__ __forceinline__ void obw_mask(uint16_t* __restrict__ mask, uint32_t g
 // matrix pointer stays a kernel argument and the lane adds one 32-bit byte offset (the training kernels have no register to spare): hence
 // M * 512 B < 4 GiB on this tier.  Same bits: H holds the same (ReLU'd) accumulator values.
 __device__ __forceinline__ void rows32_to_global(const float* H, float* __restrict__ G, uint32_t gbase, uint32_t Mv, int tid) {
+#ifdef GF_PROBE_NO_SAVES
+    return;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     char* __restrict__ Gc = reinterpret_cast<char*>(G);
     const int row0 = tid >> 5, col = (tid & 31) * 4;
@@ -911,6 +914,9 @@ __device__ __forceinline__ void obw16_mask(uint16_t* __restrict__ mask, uint32_t
 // (_Float16) of the same ReLU'd accumulator.  Called right after the barrier, before the next layer's accumulators exist (few live registers).
 template <bool WIDE = true>
 __device__ __forceinline__ void rows16_to_global(const _Float16* H16, _Float16* __restrict__ G, uint32_t gbase, uint32_t Mv, int tid) {
+#ifdef GF_PROBE_NO_SAVES
+    return;
+#endif
     // one per-lane offset for all eight pieces (they are 16 rows = 4 KiB apart), the chunk's base a workgroup-uniform pointer: two more live
     // registers than the kernel had, not two per piece (k_field_backward16 stands at 256 VGPRs)
     __builtin_amdgcn_sched_barrier(0);       // nothing of the next layer is hoisted above the copy (its operands would be live across it)

@@ -441,6 +441,9 @@ class _HeadFieldAMP(torch.autograd.Function):
         return (None, None, None, g_cond, g_code, g_pos_tab, g_amb_tab, g_wa1, g_wa2, g_wa3, g_ws1, g_ws2, g_ws3, g_wc1, g_wc2)
 
 
+_MAX_POINTS_F32, _MAX_POINTS_AMP = (1 << 23) - 4096, (1 << 24) - 4096
+
+
 def head_field(model, position, direction, cond_feat, individual_code):
     """sigma [M], color [M,3], ambient [M,2] of RADNeRF.forward with gradients to the model's tables, weights, cond_feat and code.
     Under torch.autocast(float16) with `model.amp_field == "f16"` (the default) the node runs on the f16 tier (_HeadFieldAMP), as the
@@ -450,6 +453,13 @@ def head_field(model, position, direction, cond_feat, individual_code):
     if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16 and getattr(model, "amp_field", "f16") == "f16":
         node = _HeadFieldAMP
     model._last_field_node = "amp_f16" if node is _HeadFieldAMP else "f32"      # which arithmetic the last call ran in (tests assert the tier)
+    # the training kernels address their [M,128] rows with 32-bit byte offsets (M < 2^24 binary16, 2^23 fp32: gf_field_forward_train*): a
+    # longer point list -- 65 536 rays at > 128 samples each -- goes through the node in slabs (each slab its own saves; autograd adds the
+    # parameter gradients)
+    limit = _MAX_POINTS_AMP if node is _HeadFieldAMP else _MAX_POINTS_F32
+    if position.shape[0] > limit:
+        parts = [head_field(model, position[i:i + limit], direction[i:i + limit], cond_feat, individual_code) for i in range(0, position.shape[0], limit)]
+        return tuple(torch.cat([p[k] for p in parts], dim=0) for k in range(3))
     return node.apply(model, position, direction, cond_feat, individual_code, model.position_embedder.embeddings,
                             model.ambient_embedder.embeddings, a[0].weight, a[1].weight, a[2].weight, s[0].weight, s[1].weight, s[2].weight,
                             c[0].weight, c[1].weight)

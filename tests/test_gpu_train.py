@@ -661,3 +661,42 @@ def test_binned_table_scatter_is_the_unbinned_one(D, gridtype, interp, B):
     K.gridencoder.grid_encode_backward(grad.cpu().contiguous(), xc.contiguous(), torch.zeros_like(g64), torch.from_numpy(off_h), g64, B, D, 2, 16, S, 16,
                                        None, None, gridtype, False, interp)
     assert float((b1.cpu() - g64).abs().max()) < 2e-4 * max(1.0, float(g64.abs().max()))
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_point_lists_beyond_the_kernels_row_addressing_go_through_in_slabs(amp, monkeypatch):
+    """The training kernels address their [M,128] rows with 32-bit byte offsets (M < 2^23 fp32, 2^24 binary16); head_field sends a longer list
+    through the node in slabs.  With the limit lowered to 7 000: the same outputs and the same gradients as the single call on 20 000 points."""
+    import geneface_amd.train_field as TF
+    from geneface_amd.radnerf import RADNeRF
+    hp, sd = model_fixture(False)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    M = 20000
+    xyz = torch.rand(M, 3, device=DEV, generator=g) * 1.6 - 0.8
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, device=DEV, generator=g), dim=-1)
+    cond = torch.randn(64, device=DEV, generator=g) * 0.3
+    code = model.individual_embeddings[0]
+    ws, wc, wa = torch.rand(M, device=DEV, generator=g), torch.rand(M, 3, device=DEV, generator=g), torch.rand(M, 2, device=DEV, generator=g)
+    res = []
+    for limit in (None, 7000):
+        if limit:
+            monkeypatch.setattr(TF, "_MAX_POINTS_F32", limit)
+            monkeypatch.setattr(TF, "_MAX_POINTS_AMP", limit)
+        model.zero_grad(set_to_none=True)
+        cf = cond.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            sigma, rgb, amb = TF.head_field(model, xyz, dirs, cf, code)
+        ((torch.log1p(sigma) * ws).sum() + (rgb * wc).sum() + (amb * wa).sum()).backward()
+        res.append(([t.detach().clone() for t in (sigma, rgb, amb)], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None},
+                    cf.grad.detach().float().clone()))
+    (o1, g1, c1), (o2, g2, c2) = res
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)                             # a point's outputs do not depend on its neighbours in the list
+    assert set(g1) == set(g2) and len(g1) >= 11
+    for n in g1:
+        l2 = float((g2[n] - g1[n]).double().norm() / g1[n].double().norm().clamp(min=1e-20))
+        assert l2 < 1e-5, (n, l2)                            # sums over the points in another grouping
+    assert float((c2 - c1).double().norm() / c1.double().norm()) < 1e-5
