@@ -16,7 +16,7 @@ So per SIMD (1024 of them) and launch:
 `frac` = cycles_min / 2.4 GHz (the clock the MFMA roofline is priced at) over the kernel's measured launch time (bench.py: HIP events, live);
 `frac_at_measured_clock` uses the shader clock of the launch itself (GRBM_GUI_ACTIVE / 8 XCDs / duration of the counter pass).
 
-    python tools/issue_roofline.py gpurun_out/r6d > profiles/round6/r6d_issue_roofline.json
+    python tools/issue_roofline.py gpurun_out/r6d [samples_per_frame] > profiles/round6/r6d_issue_roofline.json
 """
 import json
 import os
@@ -54,6 +54,8 @@ def main():
         if os.path.exists(p):
             res[name] = tier(p, name, kernel)
             res["_source_digest"] = json.load(open(p)).get("_source_digest")
+    if len(sys.argv) > 2:      # evaluated samples per frame of the frames the counter passes rendered (bench.py scales the mix to its own fixture)
+        res["samples_per_frame"] = float(sys.argv[2])
     print(json.dumps(res, indent=1))
 
 
