@@ -350,14 +350,24 @@ def test_legacy_nerf_baseline_runs_on_the_host_where_a_gpu_is_visible(monkeypatc
     archive = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_refpy", "geneface_refpy.zip")
     if not os.path.exists(archive):
         pytest.skip("oracle/_refpy/geneface_refpy.zip not staged")
-    for name in [m for m in sys.modules if m.startswith("modules.nerfs")]:
-        del sys.modules[name]                                     # a fresh import, as in a fresh bench process
-    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
-    from geneface_amd import hparams as HP
-    from geneface_amd import synthetic as S
-    seq = S.make_sequence(1, 64, 64, HP.may_hparams(True))
-    rec = bench.legacy_nerf_baseline(seq, rays=64, full_size=8)
-    assert rec["kind"] == "reference" and rec["value"] > 0 and rec["whole_frame_64x64"]["finite"]
-    import modules.nerfs.commons.ray_samplers as rs
-    import modules.nerfs.commons.volume_rendering as vr
-    assert vr.device.type == "cpu" and rs.device.type == "cpu"
+    # the leg imports the reference's packages from the ARCHIVE (sys.path[0]); other tests of this process import them from the reference tree:
+    # every module and path entry this test adds is removed again
+    before_modules, before_path = set(sys.modules), list(sys.path)
+    ref_pkgs = ("modules", "utils", "tasks", "data_gen", "inference", "data_util")
+    stash = {m: sys.modules.pop(m) for m in list(sys.modules) if m.split(".")[0] in ref_pkgs}     # a fresh import, as in a fresh bench process
+    try:
+        monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+        from geneface_amd import hparams as HP
+        from geneface_amd import synthetic as S
+        seq = S.make_sequence(1, 64, 64, HP.may_hparams(True))
+        rec = bench.legacy_nerf_baseline(seq, rays=64, full_size=8)
+        assert rec["kind"] == "reference" and rec["value"] > 0 and rec["whole_frame_64x64"]["finite"]
+        import modules.nerfs.commons.ray_samplers as rs
+        import modules.nerfs.commons.volume_rendering as vr
+        assert vr.device.type == "cpu" and rs.device.type == "cpu"
+    finally:
+        for m in list(sys.modules):
+            if m not in before_modules and m.split(".")[0] in ref_pkgs:
+                del sys.modules[m]
+        sys.modules.update(stash)
+        sys.path[:] = before_path
