@@ -59,37 +59,10 @@ class RADNeRF(NeRFRenderer):
 
     def cal_cond_feat(self, cond):
         """cond [smo_win, cond_win, C] (e.g. [5,1,204]) -> [cond_out_dim]."""
-        g = getattr(self, "_graphed_cond_encoder", None)
-        if g is not None and torch.is_grad_enabled() and self.training and tuple(cond.shape) == self._graphed_cond_shape:
-            return g(cond.contiguous())
         feat = self.cond_prenet(cond)
         if self.with_att:
             feat = self.cond_att_net(feat)
         return feat
-
-    def graph_cond_encoder(self, sample_cond, amp=False):
-        """Opt-in for training loops (round 6): cal_cond_feat -- AudioNet + AudioAttNet, ~50 tiny launches forward and ~50 backward per step
-        (MIOpen convolutions, GEMVs, activations, softmax; 0.4 ms of kernels and as much host time in a 5.5 ms step) -- as TWO HIP graphs
-        through torch.cuda.make_graphed_callables: one graph launch for the forward, one for the backward, gradients reach the parameters as
-        usual.  The window shape is fixed by `sample_cond` ([smo_win, cond_win, C]); under autocast the caller's context must pass
-        cache_enabled=False (torch's requirement for graphed callables).  Returns self."""
-        import torch.nn as nn
-
-        class _CondEncoder(nn.Module):
-            def __init__(self, prenet, att):
-                super().__init__()
-                self.prenet, self.att = prenet, att
-
-            def forward(self, cond):
-                feat = self.prenet(cond)
-                return self.att(feat) if self.att is not None else feat
-        enc = _CondEncoder(self.cond_prenet, self.cond_att_net if self.with_att else None)
-        sample = sample_cond.detach().clone().requires_grad_(False)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=amp, cache_enabled=False):
-            graphed = torch.cuda.make_graphed_callables(enc, (sample,))
-        object.__setattr__(self, "_graphed_cond_encoder", graphed)
-        object.__setattr__(self, "_graphed_cond_shape", tuple(sample.shape))
-        return self
 
     def _geometry(self, position, cond_feat):
         M = position.shape[0]

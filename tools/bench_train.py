@@ -27,8 +27,6 @@ def main():
     ap.add_argument("--amp-f32-field", action="store_true", help="--amp with the exact-fp32 field node under autocast (RADNeRF.amp_field = 'f32': round 5's "
                     "behaviour) instead of the f16 tier")
     ap.add_argument("--amp-f32-backward", action="store_true", help="--amp with the fp32 dX chain (RADNeRF.amp_backward = 'f32': stage 1 of round 6)")
-    ap.add_argument("--graph-cond", action="store_true", help="the condition encoder (cond_prenet + cond_att_net: ~100 tiny torch launches per step, forward and "
-                    "backward) as two HIP graphs (RADNeRF.graph_cond_encoder -> torch.cuda.make_graphed_callables)")
     ap.add_argument("--gemm-wgrad", action="store_true", help="fp32 step with the weight gradients as batched library products (RADNeRF.wgrad_impl = 'gemm': "
                     "the tree before round 6's gf_field_wgrad32)")
     ap.add_argument("--amp-gemm-wgrad", action="store_true", help="--amp with the weight gradients as batched library products (RADNeRF.amp_wgrad = 'gemm': "
@@ -73,8 +71,6 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.99), eps=1e-15, fused=not args.foreach_adam)
     torch.manual_seed(0)
     scaler = torch.amp.GradScaler("cuda", enabled=args.amp)
-    if args.graph_cond:
-        model.graph_cond_encoder(cond[0], amp=args.amp)
 
     def step(i):
         if i % hp["update_extra_interval"] == 0:
@@ -82,7 +78,7 @@ def main():
         f = i % len(poses)
         rays = utils.get_rays(poses[f:f + 1], seq["intrinsics"], 512, 512, args.n_rays)   # random pixels, as the reference's dataset draws them
         sel = rays["inds"][0]
-        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp, cache_enabled=not args.graph_cond):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             out = model.render(rays["rays_o"], rays["rays_d"], cond[f], bgc[:, sel], None, index=f, bg_color=bg[:, sel],
                                perturb=True, force_all_rays=False, **hp)
             loss = ((out["rgb_map"] - target[:, sel]) ** 2).mean() + 1e-3 * out["ambient"].mean()
@@ -106,7 +102,6 @@ def main():
                       "amp": {"field": getattr(model, "amp_field", "f16"), "backward": getattr(model, "amp_backward", "f16"),
                               "weight_gradients": getattr(model, "amp_wgrad", "fused")} if args.amp else None,
                       "weight_gradients": getattr(model, "amp_wgrad", "fused") if args.amp else getattr(model, "wgrad_impl", "fused"),
-                      "cond_encoder_graphed": bool(args.graph_cond),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
 
