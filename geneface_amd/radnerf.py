@@ -59,10 +59,18 @@ class RADNeRF(NeRFRenderer):
 
     def cal_cond_feat(self, cond):
         """cond [smo_win, cond_win, C] (e.g. [5,1,204]) -> [cond_out_dim]."""
+        if self.training and torch.is_grad_enabled() and self.cond_impl == "auto" and cond.is_cuda:
+            from . import train_cond
+            if train_cond.supported(self, cond):      # the encoder under autograd as ONE node (two launches instead of ~100)
+                return train_cond.cond_feat_train(self, cond)
         feat = self.cond_prenet(cond)
         if self.with_att:
             feat = self.cond_att_net(feat)
         return feat
+
+    #: training: "auto" = the condition encoder as one autograd node over two HIP launches (train_cond.py) whenever the kernel covers it;
+    #: "ops" = the torch modules (the reference's op graph)
+    cond_impl = "auto"
 
     def _geometry(self, position, cond_feat):
         M = position.shape[0]

@@ -244,6 +244,25 @@ int gf_cond_encode(const gf_cond_t* cond, void* stream);
  * (tasks/radnerfs/radnerf.py:119-128 -> cal_cond_feat) hoisted in front of the loop: every window of the shard is resident by then. */
 int gf_cond_encode_batch(const gf_cond_t* cond, uint32_t n_frames, void* stream);
 
+/* The same encoder under TRAINING (round 6): cal_cond_feat as one forward launch that keeps every layer's activations and one backward launch
+ * that writes the gradient of all 24 parameter tensors (two launches: the chain, then the weight sums on a grid) (cond_encoder.py:7-89 under autograd: ~100 torch launches per step).  fp32.
+ *   enc      the encoder as for gf_cond_encode (cond, S, T, C, dim_aud, weights; cond_feat = the forward's output; the bias folds are not
+ *            used).  att_lin_w = NULL: no attention net (with_att = false), S must be 1.  S <= 16, dim_aud <= 64.
+ *   acts / grads   gf_cond_train_scratch_floats(enc) floats each: the forward fills acts, the backward reads acts and uses grads.
+ *   backward g_feat [dim_aud] in; every g_* out, shaped like its weight, fully written (no accumulation). */
+typedef struct gf_cond_train {
+    const gf_cond_t* enc;
+    float* acts; float* grads;
+    const float* g_feat;
+    float* g_conv_w[4]; float* g_conv_b[4];
+    float* g_fc1_w; float* g_fc1_b; float* g_fc2_w; float* g_fc2_b;
+    float* g_att_w[5]; float* g_att_b[5];
+    float* g_att_lin_w; float* g_att_lin_b;
+} gf_cond_train_t;
+uint32_t gf_cond_train_scratch_floats(const gf_cond_t* enc);
+int gf_cond_train_forward(const gf_cond_train_t* t, void* stream);
+int gf_cond_train_backward(const gf_cond_train_t* t, void* stream);
+
 uint64_t gf_frame_sizeof(void);
 uint64_t gf_frame_workspace_bytes(uint32_t n_rays);
 uint64_t gf_frame_ctrl_offset(uint32_t n_rays);   /* byte offset of the uint32 control block inside the workspace */

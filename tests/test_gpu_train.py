@@ -700,3 +700,74 @@ def test_point_lists_beyond_the_kernels_row_addressing_go_through_in_slabs(amp, 
         l2 = float((g2[n] - g1[n]).double().norm() / g1[n].double().norm().clamp(min=1e-20))
         assert l2 < 1e-5, (n, l2)                            # sums over the points in another grouping
     assert float((c2 - c1).double().norm() / c1.double().norm()) < 1e-5
+
+
+@pytest.mark.parametrize("config", ["lm3d", "audio"])
+def test_condition_encoder_node_vs_torch_modules(config):
+    """train_cond.cond_feat_train (gf_cond_train_forward / _backward: AudioNet + AudioAttNet under autograd as two launches) against the
+    torch modules on the same weights: the features, and the gradient of every one of the encoder's 24 parameter tensors for an arbitrary
+    downstream gradient.  The landmark config (window [5, 1, 204]: the k = 3 convolutions see one tap) and the audio config (window
+    [8, 16, 44]: strided convolutions that shrink the window to 1)."""
+    from geneface_amd import hparams as HP
+    from geneface_amd import synthetic as S
+    from geneface_amd import train_cond
+    from geneface_amd.radnerf import RADNeRF
+    hp = HP.may_hparams(False) if config == "lm3d" else HP.variant_hparams("audio", False)
+    model = RADNeRF(hp)
+    model.load_state_dict(S.make_state_dict(hp, False), strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    S_, T_, C_ = int(hp["smo_win_size"]), int(hp["cond_win_size"]), int(model.cond_prenet.encoder_conv[0].in_channels)
+    cond = torch.randn(S_, T_, C_, device=DEV, generator=g) * 0.7
+    gout = torch.randn(int(model.cond_prenet.dim_aud), device=DEV, generator=g)
+    assert train_cond.supported(model, cond)
+    res = {}
+    for impl in ("ops", "auto"):
+        model.cond_impl = impl
+        model.zero_grad(set_to_none=True)
+        feat = model.cal_cond_feat(cond)
+        assert feat.shape == (int(model.cond_prenet.dim_aud),)
+        (feat * gout).sum().backward()
+        res[impl] = (feat.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    del model.cond_impl
+    (f0, g0), (f1, g1) = res["ops"], res["auto"]
+    assert float((f1 - f0).abs().max()) < 1e-5 * max(1.0, float(f0.abs().max()))
+    assert set(g0) == set(g1) and len(g1) == 24 and all(n.startswith(("cond_prenet", "cond_att_net")) for n in g1)
+    for n in g0:
+        err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
+        assert err < 2e-5, (n, err)
+    # the inference-side kernel computes the same features (same operation order: bit for bit)
+    from geneface_amd import fused
+    with torch.no_grad():
+        r = fused.cond_encode_batch(model, fused.get_state(model), cond[None].contiguous())
+    assert r is not None and torch.equal(r[0][0], f1)
+
+
+def test_condition_encoder_node_in_the_training_step():
+    """One training step of the head with the encoder as the fused node against the same step over the torch modules: the image and every
+    parameter gradient (the encoder's reach it through d cond_feat of the field node)."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    res = {}
+    for impl in ("ops", "auto"):
+        model = RADNeRF(hp)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).train()
+        model.cond_impl = impl
+        out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+        _loss(out, target).backward()
+        res[impl] = (out["rgb_map"].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (i0, g0), (i1, g1) = res["ops"], res["auto"]
+    assert float((i1 - i0).abs().max()) < 1e-5
+    assert set(g0) == set(g1)
+    for n in g0:
+        err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
+        # the two encoders agree to the last few ulp of cond_feat (different summation order in the FC layers); behind it sit the ambient
+        # coordinate's 2-D hash lookup and exp(): 6e-4 on the 3-D table, 1e-5 .. 1e-4 elsewhere (measured).  The exact comparison of the node
+        # is test_condition_encoder_node_vs_torch_modules; this one checks that the step as a whole is the same step.
+        assert err < 5e-3, (n, err)

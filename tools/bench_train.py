@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--amp-f32-field", action="store_true", help="--amp with the exact-fp32 field node under autocast (RADNeRF.amp_field = 'f32': round 5's "
                     "behaviour) instead of the f16 tier")
     ap.add_argument("--amp-f32-backward", action="store_true", help="--amp with the fp32 dX chain (RADNeRF.amp_backward = 'f32': stage 1 of round 6)")
+    ap.add_argument("--cond-ops", action="store_true", help="the condition encoder through the torch modules (RADNeRF.cond_impl = 'ops': the tree before "
+                    "round 6's gf_cond_train_forward / _backward)")
     ap.add_argument("--gemm-wgrad", action="store_true", help="fp32 step with the weight gradients as batched library products (RADNeRF.wgrad_impl = 'gemm': "
                     "the tree before round 6's gf_field_wgrad32)")
     ap.add_argument("--amp-gemm-wgrad", action="store_true", help="--amp with the weight gradients as batched library products (RADNeRF.amp_wgrad = 'gemm': "
@@ -59,6 +61,8 @@ def main():
         model.amp_wgrad = "gemm"
     if args.gemm_wgrad:
         model.wgrad_impl = "gemm"
+    if args.cond_ops:
+        model.cond_impl = "ops"
     seq = S.make_sequence(8, 512, 512, hp)
     poses = torch.from_numpy(seq["poses"]).to(dev)
     cond = torch.from_numpy(seq["cond_wins"]).to(dev)
@@ -102,6 +106,7 @@ def main():
                       "amp": {"field": getattr(model, "amp_field", "f16"), "backward": getattr(model, "amp_backward", "f16"),
                               "weight_gradients": getattr(model, "amp_wgrad", "fused")} if args.amp else None,
                       "weight_gradients": getattr(model, "amp_wgrad", "fused") if args.amp else getattr(model, "wgrad_impl", "fused"),
+                      "cond_encoder": getattr(model, "cond_impl", "auto"),
                       "reference_published": "~6 h for 250 000 steps on an RTX 3090 Ti (~11.6 steps/s), docs/train_models/train_models.md:91",
                       "data": "synthetic"}))
 
