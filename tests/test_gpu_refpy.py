@@ -192,7 +192,7 @@ def test_product_amp_step_vs_reference_python_under_autocast(ref):
     report = {}
     for n, gr in grads["reference"].items():
         gp, go = grads["product"][n], sd_g[n].grad.double()
-        report[n] = (rel(gp, gr), rel(gp, go), rel(gr, go))
+        report[n] = (float((gp - gr).norm() / go.norm().clamp(min=1e-20)), rel(gp, go), rel(gr, go))      # all three in units of the fp32 gradient's norm
         assert torch.isfinite(gp).all(), n
     print("AMP step, relative L2 (product vs reference-autocast, product vs fp32 oracle, reference-autocast vs fp32 oracle):")
     for n, v in report.items():
@@ -203,7 +203,8 @@ def test_product_amp_step_vs_reference_python_under_autocast(ref):
     # this loss scale; 0.5-1.2 % on the sigma / colour nets.  The product's tier is as close or closer to fp32 on every field tensor (6-7 %
     # where the reference has 9-12 %).  So the bar is the reference's own distance from fp32, not a constant: every field tensor no further
     # than 1.5 x that (+ 5e-3), the condition networks -- torch modules under autocast on both sides, fed by d cond_feat -- no further than
-    # 2 x (+ 2e-2), and product vs reference inside the triangle both distances span.
+    # 2 x (+ 2e-2), and product vs reference inside the triangle both distances span.  (Round 6, later: the product's condition encoder is
+    # an fp32 node whatever the autocast state -- its gradients are 4-10 % from fp32 where the reference's half arithmetic is 12-97 %.)
     field = ("embedder", "_net.net.", "individual_embeddings")
     for n, (pr, po, ro) in report.items():
         if any(k in n for k in field) and "cond" not in n:
