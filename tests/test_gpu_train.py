@@ -771,3 +771,39 @@ def test_condition_encoder_node_in_the_training_step():
         # coordinate's 2-D hash lookup and exp(): 6e-4 on the 3-D table, 1e-5 .. 1e-4 elsewhere (measured).  The exact comparison of the node
         # is test_condition_encoder_node_vs_torch_modules; this one checks that the step as a whole is the same step.
         assert err < 5e-3, (n, err)
+
+
+def test_torso_training_branch_dense_vs_compacted():
+    """RADNeRFTorso's training branch with the fused torso field on EVERY sampled pixel and the mask applied afterwards (torso_train_dense, round
+    6: no compaction, no host sync per step) against the reference's boolean-mask gather / scatter (radnerf_torso.py:174-184) on the same rays:
+    the same picture, the same alpha map, and the same gradient for every torso parameter (the sums run over other groupings of the pixels)."""
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 48, 48), 1)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    res = {}
+    for dense in (False, True):
+        model = RADNeRFTorso(hp)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).train()
+        model.torso_train_dense = dense
+        for k, p in model.named_parameters():
+            p.requires_grad_("torso" in k)
+        out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+        alphas = out["torso_alpha_map"].clamp(1e-5, 1 - 1e-5)
+        (_loss(out, target) + 1e-3 * torch.mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas))).backward()
+        res[dense] = (out["rgb_map"].detach().clone(), out["torso_alpha_map"].detach().clone(),
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, out.get("deform"))
+    (i0, a0, g0, d0), (i1, a1, g1, d1) = res[False], res[True]
+    masked = a0.reshape(-1) > 0
+    assert 0 < int(masked.sum()) < masked.numel()                  # both kinds of pixel are in the frame
+    assert float((i1 - i0).abs().max()) < 1e-6 and float((a1 - a0).abs().max()) < 1e-6
+    assert d1.shape[0] == masked.numel() and d0.shape[0] == int(masked.sum()) and not d1[~masked].any()
+    assert float((d1[masked] - d0).abs().max()) < 1e-6
+    assert set(g0) == set(g1) and len(g0) >= 8 and all("torso" in n for n in g0)
+    for n in g0:
+        err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
+        assert err < 2e-5, (n, err)

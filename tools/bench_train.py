@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--torso", action="store_true", help="the TORSO task's step (tasks/radnerfs/radnerf_torso.py:30-122): head frozen and rendered under no_grad, "
                     "only torso parameters in the optimizer (networks at lr, the 2-D grid at 10 lr), mse on rgb_map + the alpha entropy term, "
                     "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
+    ap.add_argument("--torso-compact", action="store_true", help="--torso: the reference's boolean-mask compaction of the masked pixels (one host sync per "
+                    "step: RADNeRFTorso.torso_train_dense = False) instead of the dense evaluation of round 6")
     ap.add_argument("--op-graph", action="store_true", help="--torso: pin the torso field to the torch op graph (RADNeRFTorso.field_impl = 'ops' for the torso "
                     "field only: the tree before round 6's fused node), for same-box before / after")
     args = ap.parse_args()
@@ -123,6 +125,8 @@ def main_torso(args):
     model = RADNeRFTorso(hp)
     model.load_state_dict(S.make_state_dict(hp, True), strict=True)
     model = model.to(dev).train()
+    if args.torso_compact:
+        model.torso_train_dense = False
     if args.op_graph:      # the torso field and the frozen head's condition encoder as round 5 ran them (the head's own fused field stays)
         model._fused_torso_train_ok = lambda *a, **k: False
         model._cond_feat_no_grad = model.cal_cond_feat
@@ -175,7 +179,7 @@ def main_torso(args):
     print(json.dumps({"metric": f"RAD-NeRF TORSO training steps/s (head frozen; n_rays {args.n_rays}, {'fp16 autocast' if args.amp else 'fp32'}, "
                                 f"{'foreach' if args.foreach_adam else 'fused'} Adam, torso occupancy update every 16 steps)", "value": rate,
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600,
-                      "masked_pixels_last_step": int((out["torso_alpha_map"] > 0).sum()), "head_points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
+                      "masked_pixels_last_step": int((out["torso_alpha_map"] > 0).sum()), "torso_train_dense": bool(model.torso_train_dense), "head_points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "reference_published": "~4 h for the torso on an RTX 3090 Ti, docs/train_models/train_models.md:93", "data": "synthetic"}))
 
 
