@@ -36,6 +36,13 @@ class GfTorsoTrain(C.Structure):
 _BWD_IDX = {}
 
 
+class GfTorsoWgrad(C.Structure):
+    """ctypes mirror of gf_torso_wgrad_t (include/geneface_hip.h)."""
+    _fields_ = [("M", C.c_uint32), ("_pad", C.c_uint32)] + [(n, C.c_void_p) for n in (
+        "enc", "h_d1", "h_d2", "g", "h_c1", "h_c2", "dz_d1", "dz_d2", "dz_d3", "dz_c1", "dz_c2", "dz_c3", "v", "w_d1", "w_c1",
+        "g_wd1", "g_wd2", "g_wd3", "g_wc1", "g_wc2", "g_wc3", "g_v", "workspace")]
+
+
 def _bwd_stream_index(dev):
     """Index map of the backward's A-operand streams into cat([0], W_c2^T, W_c1[:, :32]^T (rows permuted), W_d2^T) (1-based flat indices):
     the HOST packer run once on index-valued matrices, so a weight update is one device-side gather (fused._pack_index)."""
@@ -128,16 +135,30 @@ class _TorsoField(torch.autograd.Function):
         t.g_grid, t.level_max = ptr(g_grid), ptr(level_max)
         check(lib().gf_torso_train_backward(C.byref(t), current_stream(dev)))
         # weight gradients: tall products of the pre-activation gradients with the saved layer inputs; the 62 per-frame constant columns of
-        # both first layers (pose encoding 54 | identity code 8) are outer products of the column sums with that one vector
-        e42 = enc[:, :42]
-        s_d1, s_c1 = dz["dz_d1"].sum(0), dz["dz_c1"].sum(0)
-        g_wd1 = torch.cat([_tall_tn(dz["dz_d1"], e42), torch.outer(s_d1, v)], dim=1)
-        g_wd2 = _tall_tn(dz["dz_d2"], h_d1)
-        g_wd3 = _tall_tn(dz["dz_d3"], h_d2)
-        g_wc1 = torch.cat([_tall_tn(dz["dz_c1"], g), _tall_tn(dz["dz_c1"], e42), torch.outer(s_c1, v)], dim=1)
-        g_wc2 = _tall_tn(dz["dz_c2"], h_c1)
-        g_wc3 = _tall_tn(dz["dz_c3"], h_c2)
-        g_v = torch.mv(wd1.detach()[:, 42:].t().float(), s_d1) + torch.mv(wc1.detach()[:, 74:].t().float(), s_c1)
+        # both first layers (pose encoding 54 | identity code 8) are outer products of the column sums with that one vector -- all of it in two
+        # launches (gf_torso_wgrad, csrc/torso_wgrad.hip; `model.torso_wgrad_impl = "gemm"` keeps the batched library products and their glue)
+        if getattr(model, "torso_wgrad_impl", "fused") == "fused" and tuple(wd1.shape) == (64, 104) and tuple(wc1.shape) == (32, 136) \
+                and all(w.dtype == torch.float32 for w in (wd1, wd2, wd3, wc1, wc2, wc3)):
+            if getattr(st, "_torso_wgrad_ws", None) is None:
+                st._torso_wgrad_ws = torch.empty(lib().gf_torso_wgrad_ws_bytes() // 4, **f32)
+            g_wd1, g_wd2, g_wd3, g_wc1, g_wc2, g_wc3 = (torch.empty(w.shape, **f32) for w in (wd1, wd2, wd3, wc1, wc2, wc3))
+            g_v = torch.empty(62, **f32)
+            vv, w1, w2 = v.float().contiguous(), wd1.detach().contiguous(), wc1.detach().contiguous()
+            wg = GfTorsoWgrad(M=M, enc=ptr(enc), h_d1=ptr(h_d1), h_d2=ptr(h_d2), g=ptr(g), h_c1=ptr(h_c1), h_c2=ptr(h_c2),
+                              dz_d1=ptr(dz["dz_d1"]), dz_d2=ptr(dz["dz_d2"]), dz_d3=ptr(dz["dz_d3"]), dz_c1=ptr(dz["dz_c1"]), dz_c2=ptr(dz["dz_c2"]),
+                              dz_c3=ptr(dz["dz_c3"]), v=ptr(vv), w_d1=ptr(w1), w_c1=ptr(w2), g_wd1=ptr(g_wd1), g_wd2=ptr(g_wd2), g_wd3=ptr(g_wd3),
+                              g_wc1=ptr(g_wc1), g_wc2=ptr(g_wc2), g_wc3=ptr(g_wc3), g_v=ptr(g_v), workspace=ptr(st._torso_wgrad_ws))
+            check(lib().gf_torso_wgrad(C.byref(wg), current_stream(dev)))
+        else:
+            e42 = enc[:, :42]
+            s_d1, s_c1 = dz["dz_d1"].sum(0), dz["dz_c1"].sum(0)
+            g_wd1 = torch.cat([_tall_tn(dz["dz_d1"], e42), torch.outer(s_d1, v)], dim=1)
+            g_wd2 = _tall_tn(dz["dz_d2"], h_d1)
+            g_wd3 = _tall_tn(dz["dz_d3"], h_d2)
+            g_wc1 = torch.cat([_tall_tn(dz["dz_c1"], g), _tall_tn(dz["dz_c1"], e42), torch.outer(s_c1, v)], dim=1)
+            g_wc2 = _tall_tn(dz["dz_c2"], h_c1)
+            g_wc3 = _tall_tn(dz["dz_c3"], h_c2)
+            g_v = torch.mv(wd1.detach()[:, 42:].t().float(), s_d1) + torch.mv(wc1.detach()[:, 74:].t().float(), s_c1)
         g_code = g_v[54:]
         g_table, _ = _grid_backward(te, x01, g_grid, want_input_grad=False, level_major=True, level_max=level_max)
         cast = lambda gw, w: gw.to(w.dtype)

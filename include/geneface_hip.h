@@ -415,6 +415,21 @@ typedef struct gf_torso_train {
 } gf_torso_train_t;
 int gf_torso_train_forward(const gf_torso_train_t* t, void* stream);
 int gf_torso_train_backward(const gf_torso_train_t* t, void* stream);
+/* The weight gradients of the same field in two launches (round 6): the seven tall products dZ^T X, the column sums behind the 62 per-frame-constant
+ * columns of both first layers, and d v.  In: the saves of gf_torso_train_forward and the dz_* of gf_torso_train_backward (row-major, as those
+ * calls leave them), v [62] = [frequency encoding of the pose | identity code], the two first-layer weights [64,104] / [32,136].
+ * Out, fully written: g_wd1 [64,104], g_wd2 [64,64], g_wd3 [2,64], g_wc1 [32,136], g_wc2 [32,32], g_wc3 [4,32], g_v [62] (d code = g_v[54:]).
+ * workspace: gf_torso_wgrad_ws_bytes() bytes.  No atomics: the same bits every run. */
+typedef struct gf_torso_wgrad {
+    uint32_t M; uint32_t _pad;
+    const float* enc; const float* h_d1; const float* h_d2; const float* g; const float* h_c1; const float* h_c2;
+    const float* dz_d1; const float* dz_d2; const float* dz_d3; const float* dz_c1; const float* dz_c2; const float* dz_c3;
+    const float* v; const float* w_d1; const float* w_c1;
+    float* g_wd1; float* g_wd2; float* g_wd3; float* g_wc1; float* g_wc2; float* g_wc3; float* g_v;
+    float* workspace;
+} gf_torso_wgrad_t;
+uint64_t gf_torso_wgrad_ws_bytes(void);
+int gf_torso_wgrad(const gf_torso_wgrad_t* w, void* stream);
 uint32_t gf_torso_bwd_stream_floats(void);
 /* HOST: one weight matrix W [nob*32 rows][ld] as an MFMA A-operand stream [ob][step/4][lane][step%4] whose step t consumes the hidden feature
  * of accumulator position t (hidden -> hidden layers: the layout of gf_torso_pack's second layers); out [nob * nsteps * 64] floats */

@@ -38,6 +38,8 @@ def main():
                     "RADNeRFTorso.update_extra_state (the 128x128 torso occupancy) every 16 steps")
     ap.add_argument("--torso-compact", action="store_true", help="--torso: the reference's boolean-mask compaction of the masked pixels (one host sync per "
                     "step: RADNeRFTorso.torso_train_dense = False) instead of the dense evaluation of round 6")
+    ap.add_argument("--torso-gemm-wgrad", action="store_true", help="--torso: the torso weight gradients as batched library products and torch glue "
+                    "(RADNeRFTorso.torso_wgrad_impl = 'gemm') instead of gf_torso_wgrad")
     ap.add_argument("--op-graph", action="store_true", help="--torso: pin the torso field to the torch op graph (RADNeRFTorso.field_impl = 'ops' for the torso "
                     "field only: the tree before round 6's fused node), for same-box before / after")
     args = ap.parse_args()
@@ -127,6 +129,8 @@ def main_torso(args):
     model = model.to(dev).train()
     if args.torso_compact:
         model.torso_train_dense = False
+    if args.torso_gemm_wgrad:
+        model.torso_wgrad_impl = "gemm"
     if args.op_graph:      # the torso field and the frozen head's condition encoder as round 5 ran them (the head's own fused field stays)
         model._fused_torso_train_ok = lambda *a, **k: False
         model._cond_feat_no_grad = model.cal_cond_feat
