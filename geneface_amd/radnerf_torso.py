@@ -53,6 +53,9 @@ class RADNeRFTorso(RADNeRF):
     #: training branch: True = the fused torso field on every sampled pixel, masked afterwards -- no compaction, no host sync per step (round 6);
     #: False = the reference's boolean-mask gather / scatter (one compaction and one sync per step)
     torso_train_dense = True
+    #: with torso_train_dense: "fused" = mask, torso-over-background and head-over-torso blends and the clamp as one autograd node (one launch
+    #: forward, one backward); "ops" = the torch expressions of radnerf_torso.py:181-192
+    torso_blend_impl = "fused"
 
     def _torso_code(self):
         return self.torso_individual_codes[0] if self.torso_individual_embedding_dim > 0 else None
@@ -127,9 +130,23 @@ class RADNeRFTorso(RADNeRF):
                 bg_color = 1
         code = self.torso_individual_codes[index] if self.torso_individual_embedding_dim > 0 else None
         mask = self.torso_mask(bg_coords)
+        dense = self.torso_train_dense and code is not None and self._fused_torso_train_ok(bg_coords, code, None)
+        if dense and self.torso_blend_impl == "fused":
+            # the field on every sampled pixel (see below) and the whole tail -- mask, both blends, clamp -- as one autograd node over one launch
+            # each way (train_torso.torso_blend_train: the torch expressions' operations in their order, each rounded on its own)
+            from .train_torso import torso_blend_train
+            a, c, deform = self.forward_torso(bg_coords, poses, code)
+            m = mask.to(torch.float32)
+            torso_alpha, torso_rgb, rgb = torso_blend_train(a, c, m, bg_color, image, weights_sum)
+            results["deform"] = deform * m.unsqueeze(-1)
+            results["torso_alpha_map"] = torso_alpha
+            results["torso_rgb_map"] = torso_rgb
+            results["rgb_map"] = rgb.view(*prefix, 3)
+            results["depth_map"] = (torch.clamp(depth - nears, min=0) / (fars - nears)).view(*prefix)
+            return results
         torso_alpha = torch.zeros([N, 1], device=device)
         torso_color = torch.zeros([N, 3], device=device)
-        if self.torso_train_dense and code is not None and self._fused_torso_train_ok(bg_coords, code, None):
+        if dense:
             # Round 6: NO compaction and no host sync.  The fused field costs 38 us for 65 536 pixels, the boolean-mask statements of the
             # reference (radnerf_torso.py:174-184) cost a nonzero() -- a device-to-host sync in the middle of every step, so the CPU can never
             # run ahead of the GPU and the step ran at the launch rate (3.2 ms for 1.85 ms of kernels).  The field is evaluated on EVERY

@@ -186,3 +186,56 @@ def forward_torso_fused(model, x, poses, code):
     d, c = model.torso_deform_net.net, model.torso_canonicial_net.net
     return _TorsoField.apply(model, x, poses, code, model.torso_embedder.embeddings, d[0].weight, d[1].weight, d[2].weight, c[0].weight, c[1].weight,
                              c[2].weight)
+
+
+class GfTorsoBlend(C.Structure):
+    """ctypes mirror of gf_torso_blend_t (include/geneface_hip.h)."""
+    _fields_ = [("N", C.c_uint32), ("bg_stride", C.c_uint32)] + [(n, C.c_void_p) for n in (
+        "a", "c", "mask", "bg", "image", "weights_sum", "torso_alpha", "torso_rgb", "rgb", "g_alpha", "g_torso_rgb", "g_rgb", "g_a", "g_c")]
+
+
+class _TorsoBlend(torch.autograd.Function):
+    """alpha = a m, colour = c m, torso_rgb = colour alpha + bg (1 - alpha), rgb = clamp(image + (1 - weights_sum) torso_rgb, 0, 1)
+    (radnerf_torso.py:181-192): one launch forward, one backward; gradients to a and c (the head is frozen in the torso task)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, a, c, m, bg, image, weights_sum):
+        dev = a.device
+        N = a.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        a_, c_ = a.detach().reshape(N).float().contiguous(), c.detach().reshape(N, 3).float().contiguous()
+        m_, img, ws = m.reshape(N).float().contiguous(), image.detach().reshape(N, 3).float().contiguous(), weights_sum.detach().reshape(N).float().contiguous()
+        bg_ = bg.detach().float().contiguous()
+        stride = 3 if bg_.numel() == 3 * N and N > 1 else 0
+        if stride == 0 and bg_.numel() != 3:
+            bg_ = bg_.reshape(-1)[:1].expand(3).contiguous()
+        torso_alpha, torso_rgb, rgb = torch.empty(N, 1, **f32), torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
+        t = GfTorsoBlend(N=N, bg_stride=stride, a=ptr(a_), c=ptr(c_), mask=ptr(m_), bg=ptr(bg_), image=ptr(img), weights_sum=ptr(ws),
+                         torso_alpha=ptr(torso_alpha), torso_rgb=ptr(torso_rgb), rgb=ptr(rgb))
+        check(lib().gf_torso_blend_train_forward(C.byref(t), current_stream(dev)))
+        ctx.save_for_backward(a_, c_, m_, bg_, img, ws)
+        ctx.stride = stride
+        return torso_alpha, torso_rgb, rgb
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_alpha, g_torso_rgb, g_rgb):
+        a_, c_, m_, bg_, img, ws = ctx.saved_tensors
+        dev, N = a_.device, a_.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        keep = [None if g is None else g.detach().float().contiguous() for g in (g_alpha, g_torso_rgb, g_rgb)]
+        g_a, g_c = torch.empty(N, 1, **f32), torch.empty(N, 3, **f32)
+        t = GfTorsoBlend(N=N, bg_stride=ctx.stride, a=ptr(a_), c=ptr(c_), mask=ptr(m_), bg=ptr(bg_), image=ptr(img), weights_sum=ptr(ws),
+                         g_alpha=None if keep[0] is None else keep[0].data_ptr(), g_torso_rgb=None if keep[1] is None else keep[1].data_ptr(),
+                         g_rgb=None if keep[2] is None else keep[2].data_ptr(), g_a=ptr(g_a), g_c=ptr(g_c))
+        check(lib().gf_torso_blend_train_backward(C.byref(t), current_stream(dev)))
+        return g_a, g_c, None, None, None, None
+
+
+def torso_blend_train(a, c, m, bg_color, image, weights_sum):
+    """a [N,1], c [N,3] (the torso field on every sampled pixel), m [N] the mask as 0 / 1, bg_color a number, [3], or [.., N, 3], the frozen head's
+    image [N,3] and weights_sum [N] -> torso_alpha_map [N,1], torso_rgb_map [N,3], rgb_map [N,3]."""
+    if not torch.is_tensor(bg_color):
+        bg_color = torch.full((3,), float(bg_color), dtype=torch.float32, device=a.device)
+    return _TorsoBlend.apply(a, c, m, bg_color, image, weights_sum)

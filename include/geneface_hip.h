@@ -430,6 +430,20 @@ typedef struct gf_torso_wgrad {
 } gf_torso_wgrad_t;
 uint64_t gf_torso_wgrad_ws_bytes(void);
 int gf_torso_wgrad(const gf_torso_wgrad_t* w, void* stream);
+/* The tail of RADNeRFTorso.render's training branch (radnerf_torso.py:181-192) in one launch each way: alpha = a m, colour = c m (m = the torso
+ * mask as 0 / 1), torso_rgb = colour alpha + bg (1 - alpha), rgb = clamp(image + (1 - weights_sum) torso_rgb, 0, 1); every operation rounded on
+ * its own in the order of the torch expressions.  a [N], c [N,3], mask [N], bg [N,3] (bg_stride 3) or one colour [3] (bg_stride 0), image [N,3],
+ * weights_sum [N] -> torso_alpha [N], torso_rgb [N,3], rgb [N,3].  Backward: g_alpha [N] / g_torso_rgb [N,3] / g_rgb [N,3] (each or NULL) ->
+ * g_a [N], g_c [N,3] (the head is frozen in the torso task: image, weights_sum and bg are data). */
+typedef struct gf_torso_blend {
+    uint32_t N; uint32_t bg_stride;
+    const float* a; const float* c; const float* mask; const float* bg; const float* image; const float* weights_sum;
+    float* torso_alpha; float* torso_rgb; float* rgb;
+    const float* g_alpha; const float* g_torso_rgb; const float* g_rgb;
+    float* g_a; float* g_c;
+} gf_torso_blend_t;
+int gf_torso_blend_train_forward(const gf_torso_blend_t* t, void* stream);
+int gf_torso_blend_train_backward(const gf_torso_blend_t* t, void* stream);
 uint32_t gf_torso_bwd_stream_floats(void);
 /* HOST: one weight matrix W [nob*32 rows][ld] as an MFMA A-operand stream [ob][step/4][lane][step%4] whose step t consumes the hidden feature
  * of accumulator position t (hidden -> hidden layers: the layout of gf_torso_pack's second layers); out [nob * nsteps * 64] floats */

@@ -785,11 +785,12 @@ def test_torso_training_branch_dense_vs_compacted():
     to = lambda t: t.to(DEV)
     args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
     res = {}
-    for dense in (False, True):
+    for dense in (False, True, "fused_blend"):
         model = RADNeRFTorso(hp)
         model.load_state_dict(sd, strict=True)
         model = model.to(DEV).train()
-        model.torso_train_dense = dense
+        model.torso_train_dense = bool(dense)
+        model.torso_blend_impl = "fused" if dense == "fused_blend" else "ops"
         for k, p in model.named_parameters():
             p.requires_grad_("torso" in k)
         out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
@@ -797,6 +798,13 @@ def test_torso_training_branch_dense_vs_compacted():
         (_loss(out, target) + 1e-3 * torch.mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas))).backward()
         res[dense] = (out["rgb_map"].detach().clone(), out["torso_alpha_map"].detach().clone(),
                       {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, out.get("deform"))
+    # the tail (mask, both blends, clamp) as one node against the torch expressions, both on the dense field: the same operations in the same
+    # order -- the picture bit for bit, the gradients to fp32 rounding of another association
+    (i1, a1, g1, d1), (i2, a2, g2, d2) = res[True], res["fused_blend"]
+    assert torch.equal(i2, i1) and torch.equal(a2, a1) and torch.equal(d2, d1)
+    for n in g1:
+        err = float((g2[n] - g1[n]).double().norm() / g1[n].double().norm().clamp(min=1e-20))
+        assert err < 2e-6, (n, err)
     (i0, a0, g0, d0), (i1, a1, g1, d1) = res[False], res[True]
     masked = a0.reshape(-1) > 0
     assert 0 < int(masked.sum()) < masked.numel()                  # both kinds of pixel are in the frame

@@ -40,6 +40,8 @@ def main():
                     "step: RADNeRFTorso.torso_train_dense = False) instead of the dense evaluation of round 6")
     ap.add_argument("--torso-gemm-wgrad", action="store_true", help="--torso: the torso weight gradients as batched library products and torch glue "
                     "(RADNeRFTorso.torso_wgrad_impl = 'gemm') instead of gf_torso_wgrad")
+    ap.add_argument("--torso-blend-ops", action="store_true", help="--torso: the tail of the training branch (mask, blends, clamp) as torch expressions "
+                    "(RADNeRFTorso.torso_blend_impl = 'ops') instead of the fused node")
     ap.add_argument("--op-graph", action="store_true", help="--torso: pin the torso field to the torch op graph (RADNeRFTorso.field_impl = 'ops' for the torso "
                     "field only: the tree before round 6's fused node), for same-box before / after")
     args = ap.parse_args()
@@ -131,6 +133,8 @@ def main_torso(args):
         model.torso_train_dense = False
     if args.torso_gemm_wgrad:
         model.torso_wgrad_impl = "gemm"
+    if args.torso_blend_ops:
+        model.torso_blend_impl = "ops"
     if args.op_graph:      # the torso field and the frozen head's condition encoder as round 5 ran them (the head's own fused field stays)
         model._fused_torso_train_ok = lambda *a, **k: False
         model._cond_feat_no_grad = model.cal_cond_feat
