@@ -346,7 +346,11 @@ def _stamp(tensors):
 def get_state(model) -> FusedState:
     """The model's FusedState, brought up to date whenever a tensor it was packed from has changed since (training steps, train ->
     validate loops, load_state_dict, broadcast_model_, dtype / device moves): the packed copies can never go stale silently.  Values
-    changed in place are re-gathered on the device (refresh_weights); reallocated tensors or a new device rebuild everything."""
+    changed in place are re-gathered on the device (refresh_weights); reallocated tensors or a new device rebuild everything.
+    (Re)packing is fp32 arithmetic whatever the caller's autocast state: the folded bias rows are torch.mv products.)"""
+    if torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return get_state(model)
     st = getattr(model, "_fused_state", None)
     if st is None or st.device != model.density_bitfield.device:
         st = FusedState(model)
@@ -542,7 +546,8 @@ def _per_frame_vectors(model, st, cond, poses6=None, ha_branch=False):
         if r is not None:
             return r[0][0], r[1][0], (r[2][0] if r[2] is not None else None)
     cond_feat = model.cal_cond_feat(cond).reshape(-1).float()
-    amb_bias = torch.mv(st.W_cond, cond_feat)
+    with torch.autocast("cuda", enabled=False):      # (a caller under autocast must still get fp32 bias vectors)
+        amb_bias = torch.mv(st.W_cond, cond_feat)
     torso_bias = None
     if poses6 is not None:
         v = [model.torso_pose_embedder(poses6.reshape(1, 6).float()).reshape(-1)]
@@ -551,7 +556,8 @@ def _per_frame_vectors(model, st, cond, poses6=None, ha_branch=False):
         if st.head_aware:
             e0 = model.head_color_weights_encoder(torch.zeros(1, 4, device=st.device)).reshape(-1).float()
             v.append(torch.zeros_like(e0) if ha_branch else e0)
-        torso_bias = torch.mv(st.W_tconst, torch.cat(v))
+        with torch.autocast("cuda", enabled=False):
+            torso_bias = torch.mv(st.W_tconst, torch.cat(v).float())
     return cond_feat, amb_bias, torso_bias
 
 
@@ -629,8 +635,9 @@ def render_torso_fused(model, rays_o, rays_d, cond, bg_coords, poses, dt_gamma, 
 def field_forward(model, position, direction, cond_feat, individual_code):
     """RADNeRF.forward (radnerf.py:73-105) for a dense point list in one launch (gf_field_forward): sigma [M], color [M,3], ambient [M,2].
     Inference arithmetic, no autograd graph: callers are in eval / no_grad context (viewer, frozen head of torso training, op-by-op
-    render loop)."""
-    with torch.no_grad():
+    render loop).  fp32 whatever the autocast state of the caller (the torso task under the Trainer's autocast renders its frozen head through here:
+    torch.mv would hand back half bias vectors)."""
+    with torch.no_grad(), torch.autocast("cuda", enabled=False):
         st = get_state(model)
         dev = position.device
         x = position.detach().reshape(-1, 3).float().contiguous()

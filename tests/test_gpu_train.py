@@ -815,3 +815,44 @@ def test_torso_training_branch_dense_vs_compacted():
     for n in g0:
         err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
         assert err < 2e-5, (n, err)
+
+
+def test_torso_training_step_under_fp16_autocast():
+    """The torso task under the Trainer's autocast + GradScaler (base.yaml:49 amp: true applies to both tasks): the torso nodes cast their
+    inputs to fp32 (custom_fwd(cast_inputs=float32): the torso field, its weight gradients and the blend run in fp32 whatever the autocast
+    state), so a step under autocast gives the fp32 step's picture and gradients, finite at the scaler's scale, and no step is skipped."""
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 48, 48), 1)
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    res = {}
+    for amp in (False, True):
+        model = RADNeRFTorso(hp)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).train()
+        for k, p in model.named_parameters():
+            p.requires_grad_("torso" in k)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=amp)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+            loss = _loss(out, target)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(g).all() for g in grads.values())
+        scaler.step(opt)
+        scaler.update()
+        if amp:
+            assert scaler.get_scale() >= 1024.0
+        res[amp] = (out["rgb_map"].detach().float().clone(), grads)
+    (i0, g0), (i1, g1) = res[False], res[True]
+    # the frozen head's image is rendered under no_grad on the fp32 field either way; what autocast touches is torch glue around the nodes
+    assert float((i1 - i0).abs().max()) < 2e-3
+    assert set(g0) == set(g1) and len(g0) >= 8
+    for n in g0:
+        err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
+        assert err < 2e-2, (n, err)
