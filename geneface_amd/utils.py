@@ -44,6 +44,7 @@ def matrix_to_euler_angles_xyz(m: torch.Tensor) -> torch.Tensor:
     return torch.stack((a0, central, a2), -1)
 
 
+@torch.autocast("cuda", enabled=False)      # as the reference's (modules/radnerfs/utils.py:262-281): geometry stays fp32 under the Trainer's autocast
 def convert_poses(poses: torch.Tensor) -> torch.Tensor:
     """[B,4,4] cam2world -> [B,6] (XYZ euler, translation): the torso network's pose input."""
     out = torch.empty(poses.shape[0], 6, dtype=torch.float32, device=poses.device)
@@ -52,6 +53,7 @@ def convert_poses(poses: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@torch.autocast("cuda", enabled=False)      # as the reference's (modules/radnerfs/utils.py:262-281): geometry stays fp32 under the Trainer's autocast
 def get_bg_coords(H, W, device):
     X = torch.arange(H, device=device) / (H - 1) * 2 - 1
     Y = torch.arange(W, device=device) / (W - 1) * 2 - 1
@@ -59,6 +61,7 @@ def get_bg_coords(H, W, device):
     return torch.cat([xs.reshape(-1, 1), ys.reshape(-1, 1)], dim=-1).unsqueeze(0)
 
 
+@torch.autocast("cuda", enabled=False)      # as the reference's (modules/radnerfs/utils.py:262-281): geometry stays fp32 under the Trainer's autocast
 def get_rays(poses, intrinsics, H, W, N=-1, patch_size=1, rect=None):
     """Pinhole rays (modules/radnerfs/utils.py:282-363): pixel centres at +0.5, unit directions rotated by pose[:3,:3].
     N = -1: every pixel, row-major.  Training modes, same draws from torch's global generator as the reference makes: N > 0 random pixels

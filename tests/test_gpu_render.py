@@ -1259,3 +1259,62 @@ def test_variant_frame_vs_reference_golden(tag, precision, impl, monkeypatch):
     out = render_gpu(m, hp, fi)
     check(out, gold, True)
     assert (out["deform"].cpu().numpy() - gold["deform"]).shape == gold["deform"].shape and np.abs(out["deform"].cpu().numpy() - gold["deform"]).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("torso", [False, True])
+def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso):
+    """The reference wraps every entry of this path in torch.autocast (the Trainer around _training_step, which calls
+    update_extra_state: utils/commons/trainer.py:326 + tasks/radnerfs/radnerf.py:185-194; validation, test and both GUI entries:
+    radnerf.py:359, 390).  The fused path computes in fp32 whatever that state (its tiers are render_precision's, not autocast's): each call
+    under fp16 autocast must give the bytes it gives outside it -- torch glue between the launches (torch.mv bias folds, the state packing,
+    the occupancy update's reductions) must not slip into half."""
+    from geneface_amd import gui
+    from geneface_amd.infer import FramePipeline
+    seq = sequence(4, 64, 64)
+    fi = frame_inputs(seq, 1)
+    cam = gui.OrbitCamera(64, 64, r=3.35, fovy=21.24)
+    cam.update_intrinsics(seq["intrinsics"])
+    cam.orbit(30, 10)
+    res = {}
+    for amp in (False, True):
+        hp, sd, model = build(torso, "fused")        # a fresh model: the packed state is built inside the autocast region too
+        got = {}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = render_gpu(model, hp, fi)
+            got["render"] = [out[k].float().cpu() for k in sorted(out) if torch.is_tensor(out[k])]
+            g = gui.test_gui_with_editable_data(model, hp, cam.pose, cam.intrinsics, 64, 64, torch.from_numpy(seq["cond_wins"][2]), 0,
+                                                torch.from_numpy(seq["bg_img"]).view(1, -1, 3), 1, 0.5, DEV)
+            got["gui"] = [torch.from_numpy(g["image"]), torch.from_numpy(g["depth"])]
+            pipe = FramePipeline(model, hp, seq, DEV)
+            got["pipe"] = []
+            for i in range(3):
+                frame = pipe.render_frame(i)
+                pipe.wait(frame)          # the pinned host frame is valid once its copy event has passed
+                got["pipe"].append(frame.clone())
+        # the training-time occupancy update, called from inside the Trainer's autocast region with gradients enabled
+        import random
+        model.train()
+        random.seed(3)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        poses = torch.from_numpy(seq["poses"]).to(DEV)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            if torso:
+                model.poses = poses
+                for _ in range(2):
+                    model.update_extra_state(generator=gen)
+                got["occupancy"] = [model.density_grid_torso.float().cpu().clone(), torch.tensor(float(model.mean_density_torso))]
+            else:
+                model.conds = torch.from_numpy(seq["cond_wins"][:, seq["cond_wins"].shape[1] // 2]).to(DEV)
+                model.density_grid.zero_()
+                model.mark_untrained_grid(poses, seq["intrinsics"])
+                for _ in range(2):
+                    model.update_extra_state(generator=gen)
+                got["occupancy"] = [model.density_grid.float().cpu().clone(), model.density_bitfield.cpu().clone(),
+                                    torch.tensor(float(model.mean_density))]
+        res[amp] = got
+    for name in res[False]:
+        assert len(res[False][name]) == len(res[True][name]) > 0
+        for a, b in zip(res[False][name], res[True][name]):
+            assert a.dtype == b.dtype and a.shape == b.shape, name
+            assert torch.equal(a, b), (name, float((a.double() - b.double()).abs().max()))
