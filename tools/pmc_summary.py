@@ -19,6 +19,10 @@ import sys
 def main():
     out = sys.argv[1]
     prefix = sys.argv[2] if len(sys.argv) > 2 else "pmc"      # directory prefix of the passes: pmc_* (fp32 line) or pmcs_* (split tier)
+    # which kernels to keep: the frame loop's (default) or, with a third argument "train", the training step's as well
+    keep = ("k_head", "k_torso", "k_frame", "k_cond")
+    if len(sys.argv) > 3 and sys.argv[3] == "train":
+        keep += ("k_field", "k_grid", "k_wgrad", "k_composite", "k_train", "k_march")
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for path in glob.glob(os.path.join(out, prefix + "_*", "**", "*counter_collection.csv"), recursive=True):
@@ -32,7 +36,7 @@ def main():
                 dur[(k, row["Dispatch_Id"], path)] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     summary = {}
     for k, ctrs in per.items():
-        if not any(n in k for n in ("k_head", "k_torso", "k_frame", "k_cond")):
+        if not any(n in k for n in keep):
             continue
         d = {name: sum(v) / len(v) for name, v in ctrs.items()}
         d["dispatches"] = max(len(v) for v in ctrs.values())
