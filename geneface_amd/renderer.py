@@ -81,6 +81,25 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.half()` / `.to(torch.float16)` on the model or on a module that holds it (inference/nerfs/radnerf_gui.py:604-605: `nerf_task.half()`
+        when `amp` is set): the reference then keeps half parameters and computes in half.  Here a half model IS the f16 tier
+        (`render_precision = "fast"`: f16 MFMA operands packed from the masters, fp32 accumulation) and the masters stay fp32 -- the C ABI takes
+        fp32 tables and weights, and `state_dict()` keeps the precision the checkpoint had.  `.float()` afterwards restores the tier the model
+        had.  Device moves inside the same call are applied; other dtype conversions have no tier and are refused."""
+        here = next((b.device for b in self.buffers()), torch.device("cpu"))
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=here))            # what `fn` does to an fp32 tensor that lives where the model lives
+        if torch.is_tensor(probe) and probe.dtype == torch.float16:
+            if self.render_precision != "fast":
+                self._precision_before_half = self.render_precision
+                self.render_precision = "fast"
+            return super()._apply(lambda t: t.to(probe.device), *args, **kwargs)    # the device move of the same call, if there is one
+        if torch.is_tensor(probe) and probe.dtype != torch.float32:
+            raise NotImplementedError(f"NeRFRenderer has no {probe.dtype} tier: render_precision is one of 'fp32', 'split', 'fast' (= .half())")
+        if getattr(self, "_precision_before_half", None) is not None and fn(torch.zeros(1, dtype=torch.float16)).dtype == torch.float32:
+            self.render_precision, self._precision_before_half = self._precision_before_half, None       # .float() after .half()
+        return super()._apply(fn, *args, **kwargs)
+
     # --- the field interface subclasses provide (renderer.py:103-114) ---
     def cal_cond_feat(self, cond):
         raise NotImplementedError()

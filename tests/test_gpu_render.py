@@ -1318,3 +1318,30 @@ def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso):
         for a, b in zip(res[False][name], res[True][name]):
             assert a.dtype == b.dtype and a.shape == b.shape, name
             assert torch.equal(a, b), (name, float((a.double() - b.double()).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("torso", [False, True])
+def test_a_halved_model_renders_the_fast_tier(torso):
+    """The viewer's `nerf_task.half()` under `amp` (inference/nerfs/radnerf_gui.py:604-605) followed by its autocast render
+    (tasks/radnerfs/radnerf.py:388-392): the bytes of `render_precision = "fast"`, within the fast tier's bars of the oracle."""
+    hp, sd, fast = _fast_model(torso)
+    fi = frame_inputs(sequence(4, 64, 64), 1)
+    want = render_gpu(fast, hp, fi)
+    _, _, model = build(torso, "fused")
+
+    class Task(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.model = m
+
+    task = Task(model).half()
+    assert model.render_precision == "fast" and all(p.dtype == torch.float32 for p in model.parameters())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        got = render_gpu(task.model, hp, fi)
+    assert torch.equal(got["rgb_map"], want["rgb_map"]) and torch.equal(got["depth_map"], want["depth_map"])
+    ref = R.render(sd, hp, fi["rays_o"], fi["rays_d"], fi["cond"], fi["bg_coords"], fi["pose6"], fi["bg"], torso=torso)
+    _check_fast(got, ref)
+    task.float()
+    exact = render_gpu(model, hp, fi)
+    check(exact, ref, torso)                                              # back on the exact tier: the strict bars

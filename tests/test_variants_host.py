@@ -60,3 +60,41 @@ def test_coin_helper_previews_the_next_draw():
         assert (random.random() < 0.5) == c          # the very next draw is the one it looked at
         outcomes.add(c)
     assert outcomes == {True, False}
+
+
+def test_half_on_the_model_or_its_holder_selects_the_f16_tier_and_keeps_fp32_masters():
+    """inference/nerfs/radnerf_gui.py:604-605: `nerf_task = nerf_task.half()` when `amp` is set.  The reference then computes in half from half
+    parameters; here `.half()` selects `render_precision = "fast"` (the f16 tier) and leaves the fp32 masters alone -- the C ABI takes fp32
+    tables and weights.  `.float()` restores the previous tier; conversions without a tier are refused, device moves pass through."""
+    import pytest
+    import torch
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    model = RADNeRFTorso(HP.may_hparams(True))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    assert model.render_precision == "fp32" and model.half() is model
+    assert model.render_precision == "fast"
+    assert all(p.dtype == torch.float32 for p in model.parameters()) and model.density_grid.dtype == torch.float32
+    assert all(torch.equal(v, before[k]) for k, v in model.state_dict().items())
+    model.float()
+    assert model.render_precision == "fp32"
+
+    class Task(torch.nn.Module):          # what the GUI halves is the task that holds the model
+        def __init__(self, m):
+            super().__init__()
+            self.model, self.criterion = m, torch.nn.Linear(2, 2)
+
+    task = Task(model).half()
+    assert model.render_precision == "fast" and task.criterion.weight.dtype == torch.float16
+    assert next(model.parameters()).dtype == torch.float32
+    task.float()
+    assert model.render_precision == "fp32" and task.criterion.weight.dtype == torch.float32
+    model.render_precision = "split"
+    model.to(torch.float16)
+    assert model.render_precision == "fast"
+    model.to("cpu")                                                       # a device move says nothing about the tier
+    assert model.render_precision == "fast"
+    model.float()
+    assert model.render_precision == "split"
+    for convert in (model.double, model.bfloat16):
+        with pytest.raises(NotImplementedError):
+            convert()
