@@ -8,6 +8,7 @@ stream with no host synchronisation (the reference's loop, renderer.py:316-351, 
 Per-model state (packed weights, fold matrices, workspace) is built once and cached on the module.
 """
 import ctypes as C
+import itertools
 import random
 
 import numpy as np
@@ -337,10 +338,22 @@ def _watched_tensors(model):
     return t
 
 
+_untracked = itertools.count(-1, -1)
+
+
+def _ver(t) -> int:
+    """`t._version` -- or, for a tensor made under torch.inference_mode() (no version counter), a number no earlier call returned: whatever
+    is keyed on it is then rebuilt every time instead of being trusted across a change nobody can see."""
+    try:
+        return t._version
+    except RuntimeError:
+        return next(_untracked)
+
+
 def _stamp(tensors):
     # in-place updates (optimizer steps, load_state_dict, broadcast, update_extra_state) bump _version; .half() / .to() / `p.data = ...`
     # change data_ptr.  ~10 us for the ~45 tensors of a head+torso model.
-    return tuple((t._version, t.data_ptr()) for t in tensors)
+    return tuple((_ver(t), t.data_ptr()) for t in tensors)
 
 
 def get_state(model) -> FusedState:
@@ -424,7 +437,7 @@ def torso_mask_list(model, st: FusedState, bg_coords):
     module API) gets a fresh list every frame, as before."""
     grid = model.density_grid_torso
     thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
-    key = (grid._version, grid.data_ptr(), thresh, bg_coords._version, bg_coords.data_ptr(), tuple(bg_coords.shape))
+    key = (_ver(grid), grid.data_ptr(), thresh, _ver(bg_coords), bg_coords.data_ptr(), tuple(bg_coords.shape))
     hit = getattr(st, "_mask_list", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -489,7 +502,7 @@ def head_aware_coin(model, bg_coords=None) -> bool:
     if grid is None:
         return False
     thresh = float(min(model.density_thresh_torso, model.mean_density_torso))
-    key = (grid._version, grid.data_ptr(), thresh) + ((bg_coords._version, bg_coords.data_ptr(), tuple(bg_coords.shape)) if bg_coords is not None else ())
+    key = (_ver(grid), grid.data_ptr(), thresh) + ((_ver(bg_coords), bg_coords.data_ptr(), tuple(bg_coords.shape)) if bg_coords is not None else ())
     st = getattr(model, "_torso_occ_any", None)
     if st is None or st[0] != key:
         with torch.no_grad():

@@ -140,7 +140,7 @@ class FramePipeline:
         self._pre = None
         if self.impl != "fused" or self.device.type != "cuda" or stop <= first:
             return
-        from .fused import cond_encode_batch, cond_encode_batch_accepts, get_state, head_aware_coin
+        from .fused import _ver, cond_encode_batch, cond_encode_batch_accepts, get_state, head_aware_coin
         st = get_state(self.model)
         coins = None
         c = st.cond
@@ -177,7 +177,7 @@ class FramePipeline:
             ev = torch.cuda.Event()
             ev.record()
         self._pre = {"first": first, "stop": stop, "amb": r[1], "torso": torso, "stamp": st.stamp, "event": ev, "waited": set(),
-                     "inputs": (self.cond_wins._version, self.pose6._version), "coins": coins}
+                     "inputs": (_ver(self.cond_wins), _ver(self.pose6)), "coins": coins}
 
     def prepared(self, i: int):
         """(amb_bias [128], torso_bias [96] or None) of frame i from the current pass's batched launch, or None.  Called on the frame's
@@ -185,8 +185,8 @@ class FramePipeline:
         pre = getattr(self, "_pre", None)
         if pre is None or not (pre["first"] <= i < pre["stop"]):
             return None
-        from .fused import get_state
-        if get_state(self.model).stamp != pre["stamp"] or pre["inputs"] != (self.cond_wins._version, self.pose6._version):
+        from .fused import _ver, get_state
+        if get_state(self.model).stamp != pre["stamp"] or pre["inputs"] != (_ver(self.cond_wins), _ver(self.pose6)):
             self._pre = None      # the weights, or the windows / poses (edited in place), changed since the batch was encoded
             return None
         cur = torch.cuda.current_stream(self.device)

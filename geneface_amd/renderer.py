@@ -81,6 +81,15 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save of a model that has already rendered: the packed device copies and caches (fused.FusedState:
+        ctypes structures, workspaces, streams; the torso-mask cache) belong to THIS object on ITS device -- they are left behind and the copy
+        builds its own on first use (fused.get_state)."""
+        state = self.__dict__.copy()
+        for k in ("_fused_state", "_torso_occ_any"):
+            state.pop(k, None)
+        return state
+
     def _apply(self, fn, *args, **kwargs):
         """`.half()` / `.to(torch.float16)` on the model or on a module that holds it (inference/nerfs/radnerf_gui.py:604-605: `nerf_task.half()`
         when `amp` is set): the reference then keeps half parameters and computes in half.  Here a half model IS the f16 tier

@@ -1345,3 +1345,56 @@ def test_a_halved_model_renders_the_fast_tier(torso):
     task.float()
     exact = render_gpu(model, hp, fi)
     check(exact, ref, torso)                                              # back on the exact tier: the strict bars
+
+
+@pytest.mark.gpu
+def test_a_model_that_has_rendered_can_be_copied_and_pickled(tmp_path):
+    """copy.deepcopy (an EMA copy, a snapshot before fine-tuning) and torch.save(model) after the first frame: the packed device state of the
+    fused path (ctypes structures, workspaces) stays with the original; the copy renders the same bytes from a state of its own."""
+    import copy
+    hp, sd, model = build(True, "fused")
+    fi = frame_inputs(sequence(4, 64, 64), 2)
+    want = render_gpu(model, hp, fi)
+    assert hasattr(model, "_fused_state")
+    twin = copy.deepcopy(model)
+    assert not hasattr(twin, "_fused_state")
+    got = render_gpu(twin, hp, fi)
+    assert torch.equal(got["rgb_map"], want["rgb_map"]) and twin._fused_state is not model._fused_state
+    with torch.no_grad():                       # the twin's packed copies follow the twin's weights only
+        twin.sigma_net.net[0].weight.mul_(1.5)
+    assert not torch.equal(render_gpu(twin, hp, fi)["rgb_map"], want["rgb_map"])
+    assert torch.equal(render_gpu(model, hp, fi)["rgb_map"], want["rgb_map"])
+    path = tmp_path / "model.pt"
+    torch.save(model, path)
+    loaded = torch.load(path, weights_only=False)
+    assert torch.equal(render_gpu(loaded, hp, fi)["rgb_map"], want["rgb_map"])
+
+
+@pytest.mark.gpu
+def test_inference_mode_gives_the_no_grad_frames():
+    """torch.inference_mode() instead of the reference's torch.no_grad(): tensors made inside it carry no version counter, so everything this
+    package caches by `_version` (torso mask list, prepared condition batches, the head-aware coin's mask) is rebuilt instead of trusted."""
+    from geneface_amd.infer import FramePipeline
+    hp, sd, model = build(True, "fused")
+    seq = sequence(4, 64, 64)
+    fi = frame_inputs(seq, 1)
+    with torch.no_grad():
+        want = render_gpu(model, hp, fi)
+        pipe = FramePipeline(model, hp, seq, DEV)
+        frames = []
+        for i in range(3):
+            f = pipe.render_frame(i)
+            pipe.wait(f)
+            frames.append(f.clone())
+    _, _, fresh = build(True, "fused")
+    with torch.inference_mode():
+        got = render_gpu(fresh, hp, fi)
+        again = render_gpu(fresh, hp, fi)
+        pipe = FramePipeline(fresh, hp, seq, DEV)
+        pipe.prepare(0, 3)
+        for i in range(3):
+            f = pipe.render_frame(i)
+            pipe.wait(f)
+            assert torch.equal(f, frames[i]), i
+    for k in ("rgb_map", "depth_map", "torso_alpha_map"):
+        assert torch.equal(got[k], want[k]) and torch.equal(again[k], want[k]), k
