@@ -98,3 +98,29 @@ def test_half_on_the_model_or_its_holder_selects_the_f16_tier_and_keeps_fp32_mas
     for convert in (model.double, model.bfloat16):
         with pytest.raises(NotImplementedError):
             convert()
+
+
+def test_model_state_for_copies_leaves_the_packed_device_state_behind_and_versions_of_inference_tensors():
+    """Host halves of two GPU tests: NeRFRenderer.__getstate__ drops the fused path's per-object caches (so deepcopy / pickle work after a
+    render), and fused._ver answers for tensors without a version counter with a number it never gave before (so nothing keyed on it is reused)."""
+    import copy
+    import pickle
+    import torch
+    from geneface_amd import fused
+    from geneface_amd.radnerf import RADNeRF
+    model = RADNeRF(HP.may_hparams(False))
+    object.__setattr__(model, "_fused_state", object())          # what fused.get_state hangs on the module (ctypes inside: not picklable)
+    object.__setattr__(model, "_torso_occ_any", (None, True, None, None))
+    twin = copy.deepcopy(model)
+    assert not hasattr(twin, "_fused_state") and not hasattr(twin, "_torso_occ_any") and hasattr(model, "_fused_state")
+    again = pickle.loads(pickle.dumps(model))
+    assert not hasattr(again, "_fused_state")
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), again.state_dict().values()))
+    t = torch.zeros(3)
+    assert fused._ver(t) == t._version == 0
+    t.add_(1)
+    assert fused._ver(t) == 1
+    with torch.inference_mode():
+        u = torch.zeros(3)
+    a, b = fused._ver(u), fused._ver(u)
+    assert a < 0 and b < 0 and a != b
