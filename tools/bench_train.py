@@ -102,11 +102,19 @@ def main():
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = []
     for i in range(args.warmup, args.warmup + args.steps):
+        h0 = time.perf_counter()
         out = step(i)
+        host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rate = args.steps / dt
+    # how long the host needs to ENQUEUE a step (no sync inside one, except the occupancy refresh's read of mean_density every 16th): when this
+    # is below ms_per_step the device is the bound, when it equals it the step is host-bound
+    quiet = sorted(h for k, h in enumerate(host) if (args.warmup + k) % hp["update_extra_interval"] != 0)
+    print(f"host enqueue per step: median {1e3 * quiet[len(quiet) // 2]:.2f} ms, min {1e3 * quiet[0]:.2f}, max {1e3 * quiet[-1]:.2f} "
+          f"(steps without an occupancy refresh); step {1e3 * dt / args.steps:.2f} ms", file=sys.stderr)
     print(json.dumps({"metric": f"RAD-NeRF head training steps/s (n_rays {args.n_rays}, {('fp16 autocast, field on the ' + ('exact-fp32 node' if args.amp_f32_field else 'f16 tier')) if args.amp else 'fp32'}, {'foreach' if args.foreach_adam else 'fused'} Adam, grid update every 16 steps)", "value": rate,
                       "ms_per_step": 1e3 / rate, "hours_for_250k_steps": 250000 / rate / 3600, "points_last_step": int(model.step_counter[(model.local_step - 1) % 16, 0]),
                       "amp": {"field": getattr(model, "amp_field", "f16"), "backward": getattr(model, "amp_backward", "f16"),
