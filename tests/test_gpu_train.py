@@ -856,3 +856,77 @@ def test_torso_training_step_under_fp16_autocast():
     for n in g0:
         err = float((g1[n] - g0[n]).double().norm() / g0[n].double().norm().clamp(min=1e-20))
         assert err < 2e-2, (n, err)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("force_all_rays", [True, False])
+def test_training_step_on_an_empty_occupancy_grid(force_all_rays, amp):
+    """Edge case of the training branch: no ray meets an occupied cell (a bitfield of zeros -- e.g. the first steps after `reset_extra_state`,
+    or a crop that looks past the head).  The point list is empty (or all padding), the picture is the background, every gradient is finite and
+    zero where nothing was sampled, and the optimizer step goes through (no skipped step under the scaler)."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    model.density_bitfield.zero_()
+    model.density_grid.zero_()
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, enabled=amp)
+    for step in range(3):         # the second and third call run on the step counter's running mean of zero samples
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=step > 0, force_all_rays=force_all_rays, **hp)
+            loss = _loss(out, target)
+        assert torch.equal(out["rgb_map"].float().reshape(-1, 3), to(fi["bg"]).reshape(-1, 3).clamp(0, 1))
+        assert float(out["weights_sum"].abs().max()) == 0.0
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all(), n
+                assert float(p.grad.abs().max()) == 0.0, n
+    assert scaler.get_scale() >= 1024.0 or not amp
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_torso_training_step_with_an_empty_torso_mask(dense):
+    """The torso task when no sampled pixel lies on the torso (a zero torso occupancy: `mask.any()` is false, radnerf_torso.py:174): the picture
+    is head over background, every torso gradient is finite and zero, on the dense branch and on the compacting one."""
+    from geneface_amd.radnerf_torso import RADNeRFTorso
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(True)
+    fi = frame_inputs(sequence(4, 40, 40), 1)
+    model = RADNeRFTorso(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    model.torso_train_dense = dense
+    model.density_grid_torso.zero_()
+    model.mean_density_torso = 0
+    for k, p in model.named_parameters():
+        p.requires_grad_("torso" in k)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    assert float(out["torso_alpha_map"].abs().max()) == 0.0
+    loss = _loss(out, target)
+    if loss.requires_grad:
+        loss.backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) == 0.0, n
+    # the picture is the head over the plain background: the torso contributes nothing anywhere
+    from geneface_amd.radnerf import RADNeRF
+    head = RADNeRF(model_fixture(False)[0])
+    head.load_state_dict({k: v for k, v in sd.items() if k in head.state_dict()}, strict=True)
+    head = head.to(DEV).train()
+    with torch.no_grad():
+        want = head.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+    assert (want["rgb_map"] - out["rgb_map"].detach()).abs().max() < 2e-6
