@@ -930,3 +930,42 @@ def test_torso_training_step_with_an_empty_torso_mask(dense):
     with torch.no_grad():
         want = head.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
     assert (want["rgb_map"] - out["rgb_map"].detach()).abs().max() < 2e-6
+
+
+def test_grad_scaler_recovers_from_an_overflowing_scale_on_the_f16_tier():
+    """The GradScaler contract end to end on the AMP tier (utils/commons/trainer.py:307-382): with a scale far too large the f16 chain's gradients
+    leave the binary16 range, the parameter gradients the scaler inspects are non-finite, the step is SKIPPED (weights untouched) and the scale
+    halves; after enough halvings the gradients are finite, the step is taken, and no weight ever holds a non-finite value."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    model = RADNeRF(hp)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, backoff_factor=1.0 / 64, growth_interval=1000)
+    snapshot = lambda: torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+    skipped = taken = 0
+    for step in range(12):
+        before, scale = snapshot(), scaler.get_scale()
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+            loss = _loss(out, target)
+        assert model._last_field_node == "amp_f16"
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        after = snapshot()
+        assert torch.isfinite(after).all()
+        if scaler.get_scale() < scale:                    # the scaler saw a non-finite gradient: nothing may have moved
+            assert torch.equal(before, after)
+            skipped += 1
+        else:
+            assert not torch.equal(before, after)
+            taken += 1
+    assert skipped >= 1 and taken >= 1, (skipped, taken, scaler.get_scale())
