@@ -1262,13 +1262,14 @@ def test_variant_frame_vs_reference_golden(tag, precision, impl, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("torso", [False, True])
-def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso):
+def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso, dtype):
     """The reference wraps every entry of this path in torch.autocast (the Trainer around _training_step, which calls
     update_extra_state: utils/commons/trainer.py:326 + tasks/radnerfs/radnerf.py:185-194; validation, test and both GUI entries:
     radnerf.py:359, 390).  The fused path computes in fp32 whatever that state (its tiers are render_precision's, not autocast's): each call
     under fp16 autocast must give the bytes it gives outside it -- torch glue between the launches (torch.mv bias folds, the state packing,
-    the occupancy update's reductions) must not slip into half."""
+    the occupancy update's reductions) must not slip into half (or, should somebody train under bfloat16 autocast, into that)."""
     from geneface_amd import gui
     from geneface_amd.infer import FramePipeline
     seq = sequence(4, 64, 64)
@@ -1280,7 +1281,7 @@ def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso):
     for amp in (False, True):
         hp, sd, model = build(torso, "fused")        # a fresh model: the packed state is built inside the autocast region too
         got = {}
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype, enabled=amp):
             out = render_gpu(model, hp, fi)
             got["render"] = [out[k].float().cpu() for k in sorted(out) if torch.is_tensor(out[k])]
             g = gui.test_gui_with_editable_data(model, hp, cam.pose, cam.intrinsics, 64, 64, torch.from_numpy(seq["cond_wins"][2]), 0,
@@ -1298,7 +1299,7 @@ def test_everything_the_task_calls_under_its_autocast_is_the_fp32_result(torso):
         random.seed(3)
         gen = torch.Generator(device=DEV).manual_seed(5)
         poses = torch.from_numpy(seq["poses"]).to(DEV)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        with torch.autocast("cuda", dtype=dtype, enabled=amp):
             if torso:
                 model.poses = poses
                 for _ in range(2):

@@ -969,3 +969,31 @@ def test_grad_scaler_recovers_from_an_overflowing_scale_on_the_f16_tier():
             assert not torch.equal(before, after)
             taken += 1
     assert skipped >= 1 and taken >= 1, (skipped, taken, scaler.get_scale())
+
+
+def test_training_step_under_bfloat16_autocast_runs_the_exact_node():
+    """torch.autocast(bfloat16) is not what the reference trains with (torch.cuda.amp.autocast: float16), but nothing forbids it: there is no
+    bfloat16 tier, so the field takes the exact fp32 node (as `amp_field = "f32"` does under float16), every HIP op computes in fp32, and the
+    gradients are those of the fp32 step up to what torch's own bfloat16 glue (the loss arithmetic) does to them."""
+    from geneface_amd.radnerf import RADNeRF
+    from test_oracle_train import _loss
+    hp, sd = model_fixture(False)
+    fi = frame_inputs(sequence(4, 40, 40), 2)
+    to = lambda t: t.to(DEV)
+    args = (to(fi["rays_o"]), to(fi["rays_d"]), to(fi["cond"]), to(fi["bg_coords"]), to(fi["pose6"]))
+    target = torch.rand(1, fi["rays_o"].shape[1], 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+    res = {}
+    for bf in (False, True):
+        model = RADNeRF(hp)
+        model.load_state_dict(sd, strict=True)
+        model = model.to(DEV).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf):
+            out = model.render(*args, index=0, staged=False, bg_color=to(fi["bg"]), perturb=False, force_all_rays=True, **hp)
+        assert model._last_field_node == "f32" and out["rgb_map"].dtype == torch.float32
+        _loss(out, target).backward()                                       # the loss itself in fp32 on both sides: what is compared is the product
+        res[bf] = (out["rgb_map"].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(res[False][0], res[True][0])
+    assert set(res[False][1]) == set(res[True][1]) and len(res[True][1]) >= 20
+    for n, g in res[False][1].items():
+        err = float((res[True][1][n] - g).double().norm() / g.double().norm().clamp(min=1e-30))
+        assert err < 5e-4, (n, err)      # two runs of the same fp32 step differ by this much on the attention net (the few fp32 atomic sums left; cf. test_gpu_ddp.py)
