@@ -86,3 +86,38 @@ def test_reference_kernel_build_exports_the_reference_api():
             for name in expect[i]:
                 assert callable(getattr(mods[i], name)), (contract, i, name)
                 assert callable(getattr(compat, name)), (i, name)
+
+
+def test_null_descriptors_are_refused_by_every_struct_entry_point(hip_lib):
+    """The struct-taking entry points of the frame loop and of the training tier check their descriptor before they touch the device: a NULL
+    (what a binding in another host language hands over when its marshalling went wrong) gives GF_ERR_INVALID (1) and a message that names the
+    call, not a crash -- so this runs without a GPU.  Zero-sized work is success without a launch."""
+    import ctypes as C
+    L = hip_lib
+    calls = {
+        "gf_render_head": lambda: L.gf_render_head(None, None),
+        "gf_render_torso": lambda: L.gf_render_torso(None, None),
+        "gf_cond_encode": lambda: L.gf_cond_encode(None, None),
+        "gf_cond_encode_batch": lambda: L.gf_cond_encode_batch(None, C.c_uint32(3), None),
+        "gf_field_forward": lambda: L.gf_field_forward(None, None, None, C.c_uint32(5), None, None, None, None, None),
+        "gf_field_forward_train": lambda: L.gf_field_forward_train(None, None, None, C.c_uint32(5), None, None, None, None, None, None),
+        "gf_field_forward_train16": lambda: L.gf_field_forward_train16(None, None, None, C.c_uint32(5), None, None, None, None, None, None),
+        "gf_field_backward": lambda: L.gf_field_backward(None, None, C.c_uint32(5), None, None),
+        "gf_field_wgrad16": lambda: L.gf_field_wgrad16(C.c_uint32(5), None, None),
+        "gf_field_wgrad32": lambda: L.gf_field_wgrad32(C.c_uint32(5), None, None),
+        "gf_cond_train_forward": lambda: L.gf_cond_train_forward(None, None),
+        "gf_cond_train_backward": lambda: L.gf_cond_train_backward(None, None),
+        "gf_torso_train_forward": lambda: L.gf_torso_train_forward(None, None),
+        "gf_torso_train_backward": lambda: L.gf_torso_train_backward(None, None),
+        "gf_torso_wgrad": lambda: L.gf_torso_wgrad(None, None),
+        "gf_torso_blend_train_forward": lambda: L.gf_torso_blend_train_forward(None, None),
+        "gf_torso_blend_train_backward": lambda: L.gf_torso_blend_train_backward(None, None),
+    }
+    for name, call in calls.items():
+        rc = call()
+        msg = hip_lib.gf_last_error()
+        assert rc == 1, (name, rc, msg)
+        assert msg and (b"null" in msg.lower()), (name, msg)
+    # nothing to do is not an error (and needs no pointers)
+    assert L.gf_field_forward(None, None, None, C.c_uint32(0), None, None, None, None, None) == 0
+    assert L.gf_field_backward(None, None, C.c_uint32(0), None, None) == 0
