@@ -330,3 +330,35 @@ def test_postprocess_runs_the_references_ffmpeg_commands(tmp_path, monkeypatch):
     assert os.path.exists(inp["out_video_name"]) and inf.wav16k_name == wav16k
     with pytest.raises(AssertionError):
         inf.save_wav16k({"audio_source_name": str(tmp_path / "zozo.flac")})
+
+
+def test_native_png_encoder_on_drawn_sizes_contents_levels_and_strategies():
+    """gf_png_encode_rgb8 over 200 drawn pictures: 1 x 1 ... 200 x 200 (odd row lengths), noise / constant / ramps / sparse content, zlib levels 0
+    (stored blocks: the small-pool mode of NOTES 10.2), 1, 6, 9 and all four strategies -- every file decodes to the picture; a buffer that is
+    too small is refused with its size, not overrun."""
+    import ctypes as C
+    from geneface_amd.lib import lib
+    from geneface_amd.png import decode_rgb8
+    L, rng = lib(), np.random.default_rng(4)
+    for _ in range(200):
+        H, W = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        kind = rng.choice(["noise", "constant", "ramp", "sparse"])
+        if kind == "noise":
+            img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == "constant":
+            img = np.full((H, W, 3), int(rng.integers(0, 256)), np.uint8)
+        elif kind == "ramp":
+            img = (np.add.outer(np.arange(H), np.arange(W))[..., None] * np.array([1, 2, 3])).astype(np.uint8)
+        else:
+            img = np.zeros((H, W, 3), np.uint8)
+            img[rng.random((H, W)) < 0.02] = 255
+        img = np.ascontiguousarray(img)
+        level, strategy = int(rng.choice([0, 1, 6, 9])), int(rng.choice([0, 1, 2, 3]))
+        out, n = np.empty(H * (W * 3 + 1) + 8192, np.uint8), C.c_uint64(0)
+        rc = L.gf_png_encode_rgb8(img.ctypes.data, H, W, level, strategy, out.ctypes.data, out.size, C.cast(C.byref(n), C.c_void_p))
+        assert rc == 0, (L.gf_last_error(), H, W, level, strategy)
+        np.testing.assert_array_equal(decode_rgb8(out[:n.value].tobytes()), img, err_msg=f"{H}x{W} {kind} level {level} strategy {strategy}")
+    img = rng.integers(0, 256, (50, 50, 3), dtype=np.uint8)
+    out, n = np.empty(100, np.uint8), C.c_uint64(0)
+    assert L.gf_png_encode_rgb8(img.ctypes.data, 50, 50, 1, 0, out.ctypes.data, out.size, C.cast(C.byref(n), C.c_void_p)) == 1
+    assert b"too small" in L.gf_last_error()
